@@ -1,0 +1,146 @@
+/* rpt_hip.h — C ABI of the MI355X-native path-tracing core (drop-in for rpt's hot path).
+ *
+ * The reference (neevparikh/rpt, Rust, #![forbid(unsafe_code)], src/lib.rs:3) has no FFI
+ * seam.  The seam this library replaces is the private method
+ *     Renderer::sample(&self, iterations: u32, buffer: &mut Buffer)     src/renderer.rs:158-171
+ * i.e. (immutable Scene, Camera, width, height, exposure_value, max_bounces, iterations)
+ *      -> width*height linear-RGB f64 means, row-major, y = 0 at the top,
+ * which `render()` (src/renderer.rs:137-141) and `iterative_render()` (:144-156) call and
+ * feed to `Buffer::add_samples` (src/buffer.rs:32-40).  The entry points below are what a
+ * Rust `extern "C"` block (shown in INTEGRATION.md), or the C++ mirror in include/rpt.hpp,
+ * binds: plain pointers and sizes, opaque handles owned by the caller, caller-allocated
+ * output buffers, no caller pointer retained past a call (mesh data is copied at `add`).
+ *
+ * Every function returns 0 on success and a negative code on error (never aborts);
+ * rpt_last_error() returns the thread-local message of the last failure.
+ */
+#ifndef RPT_HIP_H
+#define RPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPT_OK 0
+#define RPT_ERR_INVALID (-1)   /* bad argument / would panic in the reference          */
+#define RPT_ERR_STATE (-2)     /* call order (e.g. add after commit, render before)    */
+#define RPT_ERR_DEVICE (-3)    /* HIP runtime failure (message carries hipGetErrorString) */
+#define RPT_ERR_UNSUPPORTED (-4)
+
+/* Opaque scene handle: mirrors `Scene` (src/scene.rs:12-24). */
+typedef struct rpt_scene rpt_scene;
+
+/* Shape kinds: the closed set of `impl Shape` on the hot path
+ * (src/shape/sphere.rs, cube.rs, plane.rs, mesh.rs; `Mesh = KdTree<Triangle>`). */
+enum { RPT_SHAPE_SPHERE = 0, RPT_SHAPE_CUBE = 1, RPT_SHAPE_PLANE = 2, RPT_SHAPE_MESH = 3 };
+
+/* One `Box<dyn Shape>`: a unit primitive or mesh, optionally wrapped in `Transformed<T>`
+ * (src/shape.rs:102-152).  `transform` is the composed homogeneous matrix M, row-major;
+ * chained builder calls left-multiply (src/shape.rs:237-284).  The library derives
+ * M^-1, the linear part, M^-T and det exactly as `Transformed::new` does (:112-125). */
+typedef struct rpt_shape_desc {
+    int32_t kind;            /* RPT_SHAPE_*                                              */
+    int32_t has_transform;   /* 0: bare shape, 1: Transformed<shape>                     */
+    double transform[16];    /* row-major 4x4, used iff has_transform                    */
+    double plane_normal[3];  /* Plane { normal, value } (src/shape/plane.rs:7-13)        */
+    double plane_value;
+    const double* tris;      /* n_tris * 18 doubles: v1 v2 v3 n1 n2 n3 (src/shape/mesh.rs:9-23) */
+    uint64_t n_tris;
+} rpt_shape_desc;
+
+/* `enum Material` (src/material.rs:8-23). */
+enum { RPT_MAT_LAMBERTIAN = 0, RPT_MAT_PHONG = 1, RPT_MAT_MIRROR = 2, RPT_MAT_TRANSMISSIVE = 3 };
+typedef struct rpt_material {
+    int32_t kind;
+    int32_t _pad;
+    double albedo[3];
+    double emittance;  /* Lambertian / Phong */
+    double shininess;  /* Phong */
+    double ior;        /* Transmissive */
+} rpt_material;
+
+/* `Medium` constructors (src/medium.rs:80-122): the fields are private in the reference,
+ * so these two are the closed set a user can create. */
+enum { RPT_MEDIUM_HOMOGENEOUS_ISOTROPIC = 0, RPT_MEDIUM_COLORED_GLOWING_FOG = 1 };
+
+/* `Camera` (src/camera.rs:9-27). */
+typedef struct rpt_camera {
+    double eye[3], direction[3], up[3];
+    double fov, aperture, focal_distance;
+} rpt_camera;
+
+/* The `Renderer` fields the sampling path reads (src/renderer.rs:23-56) plus tile sharding. */
+typedef struct rpt_render_params {
+    uint32_t width, height;
+    double exposure_value;
+    uint32_t max_bounces;
+    /* Multi-GPU tile sharding (no counterpart in the reference, which forks rayon tasks per
+     * row, src/renderer.rs:159-162): 32x32 pixel tiles, tile (tx,ty) is rendered iff
+     * (tx + ty) % shard_count == shard_rank; other pixels are written as 0 so a sum-reduce
+     * over ranks assembles the frame bit-exactly.  shard_count = 0 or 1: whole frame. */
+    uint32_t shard_rank, shard_count;
+} rpt_render_params;
+
+int rpt_device_count(void);
+const char* rpt_last_error(void);
+
+rpt_scene* rpt_scene_create(void);                 /* Scene::new()            src/scene.rs:26-31 */
+void rpt_scene_destroy(rpt_scene*);
+/* SceneAdd<Object>  src/scene.rs:40-44; returns the object index (>= 0) or an error. */
+int rpt_scene_add_object(rpt_scene*, const rpt_shape_desc*, const rpt_material*);
+/* SceneAdd<Light>   src/scene.rs:46-50, one entry point per `enum Light` arm (src/light.rs:7-19). */
+int rpt_scene_add_light_point(rpt_scene*, const double color[3], const double location[3]);
+int rpt_scene_add_light_ambient(rpt_scene*, const double color[3]);
+int rpt_scene_add_light_directional(rpt_scene*, const double color[3], const double direction[3]);
+/* Light::Object.  A plane is rejected (Plane::sample is unimplemented!(), src/shape/plane.rs:34). */
+int rpt_scene_add_light_object(rpt_scene*, const rpt_shape_desc*, const rpt_material*);
+/* SceneAdd<Medium>  src/scene.rs:77-81.  Only media[0] is used (src/renderer.rs:190). */
+int rpt_scene_add_medium(rpt_scene*, int32_t kind, double absorption, double scattering);
+/* Environment::Color (src/environment.rs:56-77). */
+int rpt_scene_set_environment_color(rpt_scene*, const double rgb[3]);
+/* Flatten to the device layout and upload; the scene is immutable afterwards
+ * (the reference shares `&Scene` immutably across rayon workers, src/renderer.rs:25). */
+int rpt_scene_commit(rpt_scene*, int device);
+
+/* Renderer::sample (src/renderer.rs:158-171) for `iterations` paths per pixel.
+ * out_rgb: width*height*3 doubles, row-major, y = 0 top; each pixel =
+ * mean(trace_ray) * 2^exposure_value, exactly what get_color returns (:173-184).
+ * seed / sample_offset key the counter-based RNG stream per (pixel, sample_offset + s):
+ * an additive deviation (the reference seeds from entropy, :163). */
+int rpt_render_sample(rpt_scene*, const rpt_camera*, const rpt_render_params*, uint32_t iterations,
+                      uint64_t seed, uint32_t sample_offset, double* out_rgb);
+/* Same, asynchronous: d_out_rgb is a DEVICE pointer (width*height*3 doubles) on the scene's
+ * device and hip_stream a hipStream_t (NULL = default stream).  Nothing is copied to the host. */
+int rpt_render_sample_device(rpt_scene*, const rpt_camera*, const rpt_render_params*, uint32_t iterations,
+                             uint64_t seed, uint32_t sample_offset, void* d_out_rgb, void* hip_stream);
+
+/* Renderer::get_closest_hit (src/renderer.rs:416-425) over n rays (host pointers, fp32).
+ * t = +inf, object = -1 on a miss.  normal may be NULL. */
+int rpt_intersect_batch(rpt_scene*, uint64_t n, const float* origins, const float* dirs, float* t,
+                        int32_t* object, float* normal);
+
+/* Counters of the last rpt_render_sample* call on this scene (device-side, exact):
+ * [0] camera samples, [1] closest-hit queries (rays), [2] path vertices, [3] kernel loop trips
+ * (wave-iterations summed over waves), [4] primitive tests, [5] BVH nodes visited,
+ * [6] BVH triangle tests.  Filled only when the library is built with RPT_COUNTERS or
+ * rpt_set_option("counters", 1) was called before the render; otherwise zeros. */
+int rpt_get_counters(rpt_scene*, uint64_t out[8]);
+/* Runtime options (all optional): "counters" 0/1, "chunk_spp" (samples per work item),
+ * "blocks_per_cu" (persistent grid size), returns RPT_ERR_INVALID for unknown names. */
+int rpt_set_option(const char* name, int64_t value);
+
+/* ---- device self-test hooks (each runs the device function in a one-block kernel) ---- */
+int rpt_debug_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out);
+int rpt_debug_material_sample_f(const rpt_material*, uint64_t n, const float* normals, const float* wos,
+                                uint64_t seed, float* wi, float* pdf, int32_t* some);
+int rpt_debug_material_bsdf(const rpt_material*, uint64_t n, const float* normals, const float* wos,
+                            const float* wis, float* out_rgb);
+int rpt_debug_camera_rays(const rpt_camera*, const rpt_render_params*, uint64_t seed, uint32_t sample,
+                          float* origins, float* dirs); /* one ray per pixel, width*height*3 each */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPT_HIP_H */

@@ -1,0 +1,181 @@
+"""ctypes binding of oracle/liboracle.so (the fp64 CPU restatement in rpt_oracle.cpp) and the
+lowering of an `rpt_amd.api.Scene` description onto it.  TEST INFRASTRUCTURE: see the header of
+rpt_oracle.cpp for who may use it and for the parity status ("parity unpinned" apart from the
+colour KAT of src/color.rs:30-38)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class ShapeDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("has_transform", C.c_int32), ("transform", C.c_double * 16),
+                ("plane_normal", C.c_double * 3), ("plane_value", C.c_double),
+                ("tris", C.POINTER(C.c_double)), ("n_tris", C.c_uint64)]
+
+
+class MaterialDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32), ("albedo", C.c_double * 3), ("emittance", C.c_double),
+                ("shininess", C.c_double), ("ior", C.c_double)]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("eye", C.c_double * 3), ("direction", C.c_double * 3), ("up", C.c_double * 3), ("fov", C.c_double),
+                ("aperture", C.c_double), ("focal_distance", C.c_double)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("exposure_value", C.c_double),
+                ("max_bounces", C.c_uint32), ("robust", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "obj_tests", "nodes", "tri_tests", "hits", "samples", "vertices",
+                                           "self_hits", "shadow_tests", "shadow_pass", "shadow_near")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "rpt_oracle.cpp")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "liboracle.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        P, D = C.c_void_p, C.POINTER(C.c_double)
+        L.orc_scene_new.restype = P
+        L.orc_scene_free.argtypes = [P]
+        L.orc_add_object.argtypes = [P, C.POINTER(ShapeDesc), C.POINTER(MaterialDesc)]
+        L.orc_add_light.argtypes = [P, C.c_int, D, D, C.POINTER(ShapeDesc), C.POINTER(MaterialDesc), C.c_int]
+        L.orc_add_medium.argtypes = [P, C.c_int, C.c_double, C.c_double]
+        L.orc_set_environment.argtypes = [P, D]
+        L.orc_render.argtypes = [P, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.c_uint64, C.c_uint32, P,
+                                 C.c_int, C.POINTER(Counters), P, C.c_uint64]
+        L.orc_intersect.argtypes = [P, C.c_uint64, P, P, C.c_int, P, P, P]
+        L.orc_shape_intersect.argtypes = [C.POINTER(ShapeDesc), D, D, C.c_double, C.c_double, D, D, C.c_int]
+        L.orc_mesh_kd_vs_brute.argtypes = [C.POINTER(ShapeDesc), C.c_uint64, P, P, P]
+        L.orc_mesh_kd_vs_brute.restype = C.c_int64
+        L.orc_shape_sample.argtypes = [C.POINTER(ShapeDesc), D, C.c_uint64, C.c_uint32, C.c_uint32, D, D, D]
+        L.orc_hex_color.argtypes = [C.c_uint32, D]
+        L.orc_color_bytes.argtypes = [D, C.POINTER(C.c_uint8)]
+        L.orc_rng_u32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, P]
+        L.orc_rng_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, P]
+        L.orc_material_sample_f.argtypes = [C.POINTER(MaterialDesc), D, D, C.c_uint64, C.c_uint32, C.c_uint32, D, D,
+                                            C.POINTER(C.c_int)]
+        L.orc_material_bsdf.argtypes = [C.POINTER(MaterialDesc), D, D, D, D]
+        L.orc_medium_sample_d.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, D, D, D]
+        L.orc_medium_sample_ph.argtypes = [C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, D, D]
+        L.orc_camera_cast_ray.argtypes = [C.POINTER(CameraDesc), C.c_double, C.c_double, C.c_uint64, C.c_uint32,
+                                          C.c_uint32, D, D]
+        L.orc_pixel_ndc.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, D, D]
+        L.orc_light_illuminate.argtypes = [P, C.c_int, D, C.c_uint64, C.c_uint32, C.c_uint32, D, D, D]
+        _lib = L
+    return _lib
+
+
+def _d3(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _same_shape(a, b):
+    """Geometry identity, as the product's flattener defines a light's twin object."""
+    from rpt_amd.api import Mesh, Plane
+    ba, bb = a.base(), b.base()
+    if type(ba) is not type(bb):
+        return False
+    ma, mb = a.matrix(), b.matrix()
+    if (ma is None) != (mb is None) or (ma is not None and not np.array_equal(ma, mb)):
+        return False
+    if isinstance(ba, Plane):
+        return np.array_equal(ba.normal, bb.normal) and ba.value == bb.value
+    if isinstance(ba, Mesh):
+        return ba.tris.shape == bb.tris.shape and np.array_equal(ba.tris, bb.tris)
+    return True
+
+
+class OracleScene:
+    """An `rpt_amd.api.Scene` lowered onto the oracle."""
+
+    def __init__(self, scene):
+        from rpt_amd.api import Light, material_desc, shape_desc
+        L = lib()
+        self.h = L.orc_scene_new()
+        self._keep = []
+        for o in scene.objects:
+            sd, keep = shape_desc(o.shape, ShapeDesc)
+            self._keep.append(keep)
+            assert L.orc_add_object(self.h, C.byref(sd), C.byref(material_desc(o.material_, MaterialDesc))) >= 0
+        for l in scene.lights:
+            if l.kind == Light.OBJECT:
+                sd, keep = shape_desc(l.object.shape, ShapeDesc)
+                twin = -1
+                for j, o in enumerate(scene.objects):
+                    if _same_shape(l.object.shape, o.shape):
+                        twin = j
+                        break
+                rc = L.orc_add_light(self.h, l.kind, None, None, C.byref(sd),
+                                     C.byref(material_desc(l.object.material_, MaterialDesc)), twin)
+                if rc != 0:
+                    raise ValueError("light object cannot be sampled (Plane::sample is unimplemented in rpt)")
+            else:
+                L.orc_add_light(self.h, l.kind, _d3(l.color), _d3(l.vec if l.vec is not None else np.zeros(3)), None,
+                                None, -1)
+        for m in scene.media:
+            L.orc_add_medium(self.h, m.kind, m.absorption, m.scattering)
+        L.orc_set_environment(self.h, _d3(scene.environment.color))
+
+    def render(self, camera, width, height, iterations, max_bounces, seed=0, sample_offset=0, exposure_value=0.0,
+               robust=0, threads=None, counters=False, pixels=None):
+        """Renderer::sample restated: -> (h*w, 3) fp64 means [, counters dict]."""
+        from rpt_amd.api import camera_desc
+        L = lib()
+        p = Params(width, height, exposure_value, max_bounces, robust)
+        out = np.zeros((width * height, 3), dtype=np.float64)
+        cnt = Counters()
+        if threads is None:
+            threads = os.cpu_count() or 1
+        pl, npix = None, 0
+        if pixels is not None:
+            pl = np.ascontiguousarray(pixels, dtype=np.uint32)
+            npix = pl.size
+        L.orc_render(self.h, C.byref(camera_desc(camera, CameraDesc)), C.byref(p), iterations, C.c_uint64(seed),
+                     sample_offset, out.ctypes.data_as(C.c_void_p), threads, C.byref(cnt) if counters else None,
+                     pl.ctypes.data_as(C.c_void_p) if pl is not None else None, npix)
+        return (out, cnt.as_dict()) if counters else out
+
+    def intersect(self, origins, dirs, robust=0):
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.empty(n)
+        obj = np.empty(n, dtype=np.int32)
+        nrm = np.empty((n, 3))
+        lib().orc_intersect(self.h, n, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), robust,
+                            t.ctypes.data_as(C.c_void_p), obj.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p))
+        return t, obj, nrm
+
+    def close(self):
+        if self.h:
+            lib().orc_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,468 @@
+// device_core.h — gfx950 device functions of the path-tracing core (fp32).
+// Reference line citations are relative to the rpt source tree (src/...).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gpu_layout.h"
+
+namespace rptg {
+
+#define RPT_DEV __device__ __forceinline__
+
+static constexpr float kPi = 3.14159265358979323846f;
+static constexpr float kInvPi = 0.31830988618379067154f;
+static constexpr float kInf = __builtin_huge_valf();
+
+// ------------------------------------------------------------------ vec3
+struct V {
+    float x, y, z;
+};
+RPT_DEV V mk(float x, float y, float z) { return V{x, y, z}; }
+RPT_DEV V operator+(V a, V b) { return V{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RPT_DEV V operator-(V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RPT_DEV V operator-(V a) { return V{-a.x, -a.y, -a.z}; }
+RPT_DEV V operator*(float s, V a) { return V{s * a.x, s * a.y, s * a.z}; }
+RPT_DEV V operator*(V a, float s) { return V{s * a.x, s * a.y, s * a.z}; }
+RPT_DEV V operator*(V a, V b) { return V{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RPT_DEV float dot(V a, V b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+RPT_DEV V cross(V a, V b) {
+    return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+RPT_DEV V fma3(float s, V a, V b) { return V{fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)}; }
+RPT_DEV V fma3(V s, V a, V b) { return V{fmaf(s.x, a.x, b.x), fmaf(s.y, a.y, b.y), fmaf(s.z, a.z, b.z)}; }
+RPT_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+RPT_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RPT_DEV V normalize(V a) { return rsq(dot(a, a)) * a; }
+RPT_DEV V vmin(V a, V b) { return V{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
+RPT_DEV float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+RPT_DEV float min3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+RPT_DEV V xyz(const F4& f) { return V{f.x, f.y, f.z}; }
+RPT_DEV float dot3w(const F4& r, V p) { return fmaf(r.x, p.x, fmaf(r.y, p.y, fmaf(r.z, p.z, r.w))); }
+RPT_DEV float dot3(const F4& r, V p) { return fmaf(r.x, p.x, fmaf(r.y, p.y, r.z * p.z)); }
+RPT_DEV bool is_zero(V a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
+
+// ------------------------------------------------------------------ RNG
+// xoshiro128+ seeded through splitmix64 from (seed, pixel, sample); bit-identical to the
+// oracle's Rng.  Replaces StdRng::from_entropy() per row (src/renderer.rs:163).
+RPT_DEV uint64_t mix64(uint64_t x) {
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return x;
+}
+struct Rng {
+    uint32_t s0, s1, s2, s3;
+    // `a` = mix64(seed + GOLDEN), computed on the host.
+    RPT_DEV void seed(uint64_t a, uint32_t pixel, uint32_t sample) {
+        const uint64_t G = 0x9E3779B97F4A7C15ULL;
+        uint64_t z = a ^ ((uint64_t(sample) << 32) | uint64_t(pixel));
+        uint64_t r0 = mix64(z + G), r1 = mix64(z + 2 * G);
+        s0 = uint32_t(r0);
+        s1 = uint32_t(r0 >> 32);
+        s2 = uint32_t(r1);
+        s3 = uint32_t(r1 >> 32);
+    }
+    RPT_DEV uint32_t next() {
+        uint32_t r = s0 + s3;
+        uint32_t t = s1 << 9;
+        s2 ^= s0;
+        s3 ^= s1;
+        s1 ^= s2;
+        s0 ^= s3;
+        s2 ^= t;
+        s3 = __builtin_rotateleft32(s3, 11);
+        return r;
+    }
+    // (2k+1) * 2^-24 with k = top 23 bits: open interval (0,1), exact in fp32.
+    RPT_DEV float uniform() { return float(((next() >> 9) << 1) | 1u) * 0x1p-24f; }
+    RPT_DEV float range(float a, float b) { return fmaf(b - a, uniform(), a); }
+    RPT_DEV uint32_t index(uint32_t n) { return __umulhi(next(), n); }
+    RPT_DEV void unit_disc(float& x, float& y) {  // rand_distr::UnitDisc (rejection)
+        for (;;) {
+            x = range(-1.f, 1.f);
+            y = range(-1.f, 1.f);
+            if (fmaf(x, x, y * y) <= 1.f) return;
+        }
+    }
+};
+
+// ------------------------------------------------------------------ primitive tests
+// Each returns the hit parameter or a negative value for "no hit in [tmin, tmax)".
+// `t` is shared between world and local space because the local direction is not
+// renormalised (Ray::apply_transform, src/shape.rs:65-72).
+
+// Unit sphere, src/shape/sphere.rs:14-46.  Same roots as the reference's (-b -/+ sqrt(b^2-ac))/a,
+// evaluated through the closest-approach vector so fp32 keeps the discriminant's digits.
+RPT_DEV float hit_sphere(V ol, V dl, float tmin) {
+    float a = dot(dl, dl);
+    float inv_a = rcp(a);
+    float bb = dot(dl, ol) * inv_a;
+    V l = fma3(-bb, dl, ol);
+    float disc = 1.f - dot(l, l);
+    if (disc < 0.f) return -1.f;
+    float sq = __builtin_sqrtf(disc * inv_a);
+    float t0 = -bb - sq;
+    float t1 = -bb + sq;
+    float t = (t0 < tmin) ? t1 : t0;
+    return (t < tmin) ? -1.f : t;
+}
+// Unit cube [-1/2,1/2]^3, src/shape/cube.rs:22-74.  Returns t; `axis_sign` (optional) gets the
+// face: axis | (positive ? 4 : 0).
+template <bool WANT_FACE>
+RPT_DEV float hit_cube(V ol, V dl, float tmin, uint32_t& face) {
+    float ix = rcp(dl.x), iy = rcp(dl.y), iz = rcp(dl.z);
+    float x1 = (-0.5f - ol.x) * ix, x2 = (0.5f - ol.x) * ix;
+    float y1 = (-0.5f - ol.y) * iy, y2 = (0.5f - ol.y) * iy;
+    float z1 = (-0.5f - ol.z) * iz, z2 = (0.5f - ol.z) * iz;
+    bool sx = x1 > x2, sy = y1 > y2, sz = z1 > z2;
+    float xl = sx ? x2 : x1, xh = sx ? x1 : x2;
+    float yl = sy ? y2 : y1, yh = sy ? y1 : y2;
+    float zl = sz ? z2 : z1, zh = sz ? z1 : z2;
+    float start = max3(xl, yl, zl);
+    float end = min3(xh, yh, zh);
+    if (start > end || end < tmin) return -1.f;
+    bool use_end = start < tmin;
+    if (WANT_FACE) {
+        // start face: entering through the low side (normal -1) unless swapped; end face: +1 unless swapped
+        uint32_t as, ae;
+        if (xl > yl && xl > zl) as = 0; else if (yl > zl) as = 1; else as = 2;
+        if (xh < yh && xh < zh) ae = 0; else if (yh < zh) ae = 1; else ae = 2;
+        uint32_t ax = use_end ? ae : as;
+        bool swapped = ax == 0 ? sx : (ax == 1 ? sy : sz);
+        bool positive = use_end ? !swapped : swapped;
+        face = ax | (positive ? 4u : 0u);
+    }
+    return use_end ? end : start;
+}
+// Plane, src/shape/plane.rs:17-32 (world-space (n, value)).
+RPT_DEV float hit_plane(const F4& nv, V o, V d, float tmin) {
+    float c = dot3(nv, d);
+    if (fabsf(c) < 1e-8f) return -1.f;
+    float t = (nv.w - dot3(nv, o)) * rcp(c);
+    return (t >= tmin) ? t : -1.f;
+}
+// Triangle, src/shape/mesh.rs:50-83, with the plane normal and the barycentric functionals
+// pre-solved on the host.  Accepts t in [tmin, tmax).
+RPT_DEV float hit_tri(const F4& pn, const F4& A, const F4& B, V o, V d, float tmin, float tmax) {
+    float c = dot3(pn, d);
+    if (fabsf(c) < 1e-8f) return -1.f;
+    float t = (pn.w - dot3(pn, o)) * rcp(c);
+    if (!(t >= tmin && t < tmax)) return -1.f;
+    V p = fma3(t, d, o);
+    float v = dot3w(A, p), w = dot3w(B, p);
+    float u = 1.f - v - w;
+    return (u >= 0.f && v >= 0.f && w >= 0.f) ? t : -1.f;
+}
+RPT_DEV void to_local(const XfScan& x, V o, V d, V& ol, V& dl) {
+    ol = mk(dot3w(x.r0, o), dot3w(x.r1, o), dot3w(x.r2, o));
+    dl = mk(dot3(x.r0, d), dot3(x.r1, d), dot3(x.r2, d));
+}
+
+// ------------------------------------------------------------------ closest hit
+// Renderer::get_closest_hit, src/renderer.rs:416-425: every object is tested, the closest
+// accepted hit wins, ties keep the earlier object (strict `<`).  The analytic primitives are
+// scanned with a wave-uniform index (scalar loads); BVH meshes are walked per lane.
+template <bool COUNT>
+RPT_DEV void bvh_traverse(const SceneView& sc, const MeshRef& m, V o, V d, float tmin, float& tbest,
+                          uint32_t& code, uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
+    const BvhNode* nodes = sc.nodes + m.node_base;
+    float ix = rcp(d.x), iy = rcp(d.y), iz = rcp(d.z);
+    uint32_t sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        const BvhNode nd = nodes[cur];
+        if (COUNT) c_nodes++;
+        float x1 = (nd.lo[0] - o.x) * ix, x2 = (nd.hi[0] - o.x) * ix;
+        float y1 = (nd.lo[1] - o.y) * iy, y2 = (nd.hi[1] - o.y) * iy;
+        float z1 = (nd.lo[2] - o.z) * iz, z2 = (nd.hi[2] - o.z) * iz;
+        float tn = max3(fminf(x1, x2), fminf(y1, y2), fminf(z1, z2));
+        float tf = min3(fmaxf(x1, x2), fmaxf(y1, y2), fmaxf(z1, z2));
+        bool overlap = fmaxf(tn, tmin) <= fminf(tf, tbest);
+        if (overlap) {
+            if (nd.count == 0) {
+                if (sp < 32) { stk[sp * stride] = nd.left_or_first + 1; sp++; }
+                cur = nd.left_or_first;
+                continue;
+            }
+            for (uint32_t i = 0; i < nd.count; i++) {
+                uint32_t ti = m.tri_base + nd.left_or_first + i;
+                const TriScan tr = sc.btri[ti];
+                if (COUNT) c_tris++;
+                float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
+                if (t >= 0.f) { tbest = t; code = (K_BVHTRI << 28) | ti; }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stk[sp * stride];
+    }
+}
+
+template <bool BVH, bool COUNT>
+RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code,
+                         uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
+    for (uint32_t i = 0; i < sc.n_sph; i++) {
+        const XfScan x = sc.sph[i];
+        V ol, dl;
+        to_local(x, o, d, ol, dl);
+        float t = hit_sphere(ol, dl, tmin);
+        if (t >= 0.f && t < tbest) { tbest = t; code = (K_SPHERE << 28) | i; }
+    }
+    for (uint32_t i = 0; i < sc.n_cub; i++) {
+        const XfScan x = sc.cub[i];
+        V ol, dl;
+        to_local(x, o, d, ol, dl);
+        uint32_t f;
+        float t = hit_cube<false>(ol, dl, tmin, f);
+        if (t >= 0.f && t < tbest) { tbest = t; code = (K_CUBE << 28) | i; }
+    }
+    for (uint32_t i = 0; i < sc.n_pln; i++) {
+        const F4 nv = sc.pln[i].nv;
+        float t = hit_plane(nv, o, d, tmin);
+        if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
+    }
+    for (uint32_t i = 0; i < sc.n_tri; i++) {
+        const TriScan tr = sc.tri[i];
+        float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
+        if (t >= 0.f) { tbest = t; code = (K_TRI << 28) | i; }
+    }
+    if (BVH) {
+        for (uint32_t i = 0; i < sc.n_mesh; i++) {
+            const MeshRef m = sc.meshes[i];
+            bvh_traverse<COUNT>(sc, m, o, d, tmin, tbest, code, stk, stride, c_nodes, c_tris);
+        }
+    }
+}
+
+// Normal and object of the winning primitive (per lane).
+RPT_DEV void finalize_hit(const SceneView& sc, V o, V d, float tmin, float t, uint32_t code, V& n, uint32_t& obj) {
+    uint32_t kind = code >> 28, idx = code & 0x0FFFFFFFu;
+    if (kind == K_SPHERE) {  // src/shape/sphere.rs:40-41 then src/shape.rs:131-134
+        const XfScan x = sc.sph[idx];
+        const XfShade s = sc.sph_sh[idx];
+        V ol, dl;
+        to_local(x, o, d, ol, dl);
+        V nl = normalize(fma3(t, dl, ol));
+        n = (s.r1.w != 0.f) ? normalize(mk(dot3(s.r0, nl), dot3(s.r1, nl), dot3(s.r2, nl))) : nl;
+        obj = __float_as_uint(s.r0.w);
+    } else if (kind == K_CUBE) {
+        const XfScan x = sc.cub[idx];
+        const XfShade s = sc.cub_sh[idx];
+        V ol, dl;
+        to_local(x, o, d, ol, dl);
+        uint32_t face = 0;
+        // same slab arithmetic and tmin as the scan, so the same root/face is selected
+        (void)hit_cube<true>(ol, dl, tmin, face);
+        float sg = (face & 4u) ? 1.f : -1.f;
+        uint32_t ax = face & 3u;
+        V nl = mk(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f);
+        n = (s.r1.w != 0.f) ? normalize(mk(dot3(s.r0, nl), dot3(s.r1, nl), dot3(s.r2, nl))) : nl;
+        obj = __float_as_uint(s.r0.w);
+    } else if (kind == K_PLANE) {  // src/shape/plane.rs:27: -normalize(n) * signum(cos)
+        const F4 nv = sc.pln[idx].nv;
+        const F4 s = sc.pln_sh[idx].unit_n_obj;
+        float c = dot3(nv, d);
+        float sg = __builtin_signbit(c) ? 1.f : -1.f;
+        n = sg * xyz(s);
+        obj = __float_as_uint(s.w);
+    } else {  // triangle: src/shape/mesh.rs:78, normals never face-forwarded
+        const TriScan* ta = (kind == K_TRI) ? sc.tri : sc.btri;
+        const TriShade* sa = (kind == K_TRI) ? sc.tri_sh : sc.btri_sh;
+        const TriShade s = sa[idx];
+        obj = __float_as_uint(s.n1.w);
+        if (s.n2.w != 0.f) {  // flat: n1 == n2 == n3
+            n = xyz(s.n1);
+        } else {
+            const TriScan tr = ta[idx];
+            V p = fma3(t, d, o);
+            float v = dot3w(tr.A, p), w = dot3w(tr.B, p);
+            float u = 1.f - v - w;
+            n = normalize(u * xyz(s.n1) + v * xyz(s.n2) + w * xyz(s.n3));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ materials
+struct Mat {
+    V albedo;
+    float emit;
+    uint32_t kind;
+    float shin, ior;
+};
+RPT_DEV Mat load_mat(const SceneView& sc, uint32_t obj) {
+    const Material m = sc.mats[obj];
+    return Mat{xyz(m.albedo_emit), m.albedo_emit.w, __float_as_uint(m.params.x), m.params.y, m.params.z};
+}
+RPT_DEV V mat_color(const Mat& m) { return (m.kind <= 1u) ? m.albedo : mk(0.f, 0.f, 0.f); }   // src/material.rs:107
+RPT_DEV float mat_emit(const Mat& m) { return (m.kind <= 1u) ? m.emit : 0.f; }                // src/material.rs:100
+
+// Rotation taking +Y onto `b` applied to v (nalgebra rotation_between(+Y, b)): axis k =
+// normalize(Y x b), angle acos(b.y).  `pi_fallback_x`: Lambertian's (0,1,1e-8) retry
+// (src/material.rs:186-194) is a half-turn about +X; Phong's quat_rotation falls back to identity.
+RPT_DEV V rotate_from_y(V b, V v, bool pi_fallback_x) {
+    float s2 = fmaf(b.x, b.x, b.z * b.z);
+    if (s2 > 0.f) {
+        float is = rsq(s2);
+        float s = s2 * is;           // sin(angle)
+        float kx = b.z * is, kz = -b.x * is;  // k = (b.z, 0, -b.x)/s
+        float kv = kx * v.x + kz * v.z;       // k . v
+        // k x v = (-kz*v.y, kz*v.x - kx*v.z, kx*v.y)
+        V kxv = mk(-kz * v.y, kz * v.x - kx * v.z, kx * v.y);
+        float c = b.y;
+        float omc = 1.f - c;
+        return mk(fmaf(c, v.x, fmaf(s, kxv.x, omc * kv * kx)), fmaf(c, v.y, s * kxv.y),
+                  fmaf(c, v.z, fmaf(s, kxv.z, omc * kv * kz)));
+    }
+    if (b.y < 0.f && pi_fallback_x) return mk(v.x, -v.y, -v.z);
+    return v;
+}
+RPT_DEV V reflect_neg(V w, V n) { return fma3(2.f * dot(n, w), n, -w); }  // -glm::reflect_vec(w, n)
+
+// Material::sample_f, src/material.rs:166-263.  Returns false for None (total internal reflection).
+RPT_DEV bool sample_f(const Mat& m, V n, V wo, Rng& rng, V& wi, float& pdf) {
+    if (m.kind == M_LAMBERTIAN) {
+        float r1 = rng.uniform(), r2 = rng.uniform();
+        float ct = __builtin_sqrtf(r2);             // cos(acos(sqrt(r2)))
+        float st = __builtin_sqrtf(1.f - r2);
+        pdf = ct * kInvPi;
+        V dir = mk(st * __builtin_amdgcn_cosf(r1), ct, st * __builtin_amdgcn_sinf(r1));  // phi = 2 pi r1
+        wi = normalize(rotate_from_y(n, dir, true));
+        return true;
+    } else if (m.kind == M_PHONG) {
+        float r1 = rng.uniform(), r2 = rng.uniform();
+        float ct = __powf(r2, rcp(m.shin + 1.f));
+        float st = __builtin_sqrtf(fmaxf(1.f - ct * ct, 0.f));
+        pdf = (m.shin + 1.f) * (0.5f * kInvPi) * __powf(ct, m.shin);
+        V dir = mk(st * __builtin_amdgcn_cosf(r1), ct, st * __builtin_amdgcn_sinf(r1));
+        V refl = reflect_neg(wo, n);
+        wi = normalize(rotate_from_y(normalize(refl), dir, false));
+        return true;
+    } else if (m.kind == M_MIRROR) {
+        wi = reflect_neg(wo, normalize(n));
+        pdf = 1.f;
+        return true;
+    } else {
+        bool inside = dot(n, wo) < 0.f;
+        V nn = inside ? -n : n;
+        float ci = fminf(fmaxf(dot(wo, nn), 0.f), 1.f);
+        float ni = inside ? m.ior : 1.f, nt = inside ? 1.f : m.ior;
+        float r0 = (ni - nt) * rcp(ni + nt);
+        r0 *= r0;
+        float mm = 1.f - ci;
+        float m2 = mm * mm;
+        float sr = fminf(fmaxf(fmaf(1.f - r0, m2 * m2 * mm, r0), 0.f), 1.f);
+        pdf = 1.f;
+        if (rng.uniform() < sr) {
+            wi = reflect_neg(wo, n);
+            return true;
+        }
+        float eta = ni * rcp(nt);
+        float k = 1.f - eta * eta * (1.f - ci * ci);
+        if (k < 0.f) return false;  // sqrt -> NaN -> None
+        float cost = __builtin_sqrtf(k);
+        wi = fma3(eta * ci - cost, nn, -eta * wo);
+        return true;
+    }
+}
+// Material::bsdf, src/material.rs:266-289.
+RPT_DEV V bsdf(const Mat& m, V n, V wo, V wi) {
+    float nwi = dot(n, wi), nwo = dot(n, wo);
+    if (__builtin_signbit(nwi) || __builtin_signbit(nwo)) return mk(0.f, 0.f, 0.f);
+    if (m.kind == M_LAMBERTIAN) return kInvPi * m.albedo;
+    if (m.kind == M_PHONG) {
+        V r = -normalize(fma3(-2.f * dot(n, wi), n, wi));
+        float c = fminf(fmaxf(dot(r, wo), 0.f), 1.f);
+        // powf(0, s) = 0 for s > 0, 1 for s == 0
+        float pw = (c > 0.f) ? __powf(c, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
+        return ((m.shin + 2.f) * (0.5f * kInvPi) * pw) * m.albedo;
+    }
+    return mk(1.f, 1.f, 1.f);
+}
+
+// ------------------------------------------------------------------ lights
+// Light::illuminate for Light::Object, src/light.rs:34-45, over the shape samplers
+// (src/kdtree.rs:141-146 + src/shape/mesh.rs:85-99, sphere.rs:53-65, cube.rs:76-89,
+//  Transformed::sample src/shape.rs:140-151).
+RPT_DEV void illuminate_object(const SceneView& sc, const Light& L, V pos, Rng& rng, V& intensity, V& wi,
+                               float& dist) {
+    V v, n, vl, nl;
+    float p;
+    const LightXf x = sc.lxf[L.xf];
+    const bool xf = x.nrm[1].w != 0.f;
+    const bool mesh = L.shape == LS_MESH;
+    if (mesh) {
+        uint32_t idx = rng.index(L.count);
+        const LightTri tr = sc.ltris[L.first + idx];
+        float u = rng.uniform(), vv = rng.uniform();
+        while (u + vv > 1.f) {
+            u = rng.uniform();
+            vv = rng.uniform();
+        }
+        float w = 1.f - u - vv;
+        vl = u * xyz(tr.v1) + vv * xyz(tr.v2) + w * xyz(tr.v3);  // already world space
+        nl = normalize(u * xyz(tr.n1) + vv * xyz(tr.n2) + w * xyz(tr.n3));
+        p = tr.v1.w * rcp(float(L.count));
+    } else if (L.shape == LS_SPHERE) {
+        V tl = xf ? mk(dot3w(x.inv[0], pos), dot3w(x.inv[1], pos), dot3w(x.inv[2], pos)) : pos;
+        float dx, dy;
+        rng.unit_disc(dx, dy);
+        float z = __builtin_sqrtf(fmaxf(1.f - dx * dx - dy * dy, 0.f));
+        V nn = normalize(tl);
+        bool normal_x = fabsf(nn.x) >= 1.17549435e-38f && fabsf(nn.x) < kInf;
+        V n1 = normal_x ? normalize(mk(nn.y, -nn.x, 0.f)) : normalize(mk(0.f, -nn.z, nn.y));
+        V n2 = cross(n1, nn);
+        vl = dx * n1 + dy * n2 + z * nn;
+        nl = vl;
+        p = z * kInvPi;
+    } else {
+        float a = rng.uniform() - 0.5f, b = rng.uniform() - 0.5f;
+        uint32_t f = rng.index(6);
+        switch (f) {
+            case 0: vl = mk(a, b, 0.5f); nl = mk(0, 0, 1); break;
+            case 1: vl = mk(a, b, -0.5f); nl = mk(0, 0, -1); break;
+            case 2: vl = mk(a, 0.5f, b); nl = mk(0, 1, 0); break;
+            case 3: vl = mk(a, -0.5f, b); nl = mk(0, -1, 0); break;
+            case 4: vl = mk(0.5f, a, b); nl = mk(1, 0, 0); break;
+            default: vl = mk(-0.5f, a, b); nl = mk(-1, 0, 0); break;
+        }
+        p = 1.f / 6.f;
+    }
+    if (xf) {
+        n = normalize(mk(dot3(x.nrm[0], nl), dot3(x.nrm[1], nl), dot3(x.nrm[2], nl)));
+        V ln = mk(dot3(x.lin[0], nl), dot3(x.lin[1], nl), dot3(x.lin[2], nl));
+        float height = dot(ln, n);
+        float base = x.nrm[0].w * rcp(height);
+        v = mesh ? vl : mk(dot3w(x.fwd[0], vl), dot3w(x.fwd[1], vl), dot3w(x.fwd[2], vl));
+        p = p * rcp(base);
+    } else {
+        v = vl;
+        n = nl;
+    }
+    V disp = v - pos;
+    float len2 = dot(disp, disp);
+    float ilen = rsq(len2);
+    float cosine = fmaxf(-dot(disp, n), 0.f) * ilen;
+    float surface_area = cosine * rcp(len2);
+    intensity = (surface_area * rcp(p)) * xyz(L.color);
+    wi = ilen * disp;
+    dist = len2 * ilen;
+}
+
+// ------------------------------------------------------------------ camera
+// Camera::cast_ray, src/camera.rs:65-82 (cot(fov/2)*direction and `right` hoisted to the host).
+RPT_DEV void cast_ray(const CameraG& c, float x, float y, Rng& rng, V& o, V& d) {
+    V right = mk(c.right[0], c.right[1], c.right[2]), up = mk(c.up[0], c.up[1], c.up[2]);
+    o = mk(c.eye[0], c.eye[1], c.eye[2]);
+    V nd = mk(c.ddir[0], c.ddir[1], c.ddir[2]) + x * right + y * up;
+    if (c.aperture > 0.f) {
+        V focal = fma3(c.focal_distance, normalize(nd), o);
+        float dx, dy;
+        rng.unit_disc(dx, dy);
+        o = o + c.aperture * (dx * right + dy * up);
+        nd = focal - o;
+    }
+    d = normalize(nd);
+}
+
+}  // namespace rptg

@@ -1,0 +1,115 @@
+// gpu_layout.h — flattened fp32 scene layout shared by the host flattener and the HIP kernels.
+//
+// HBM layout (all arrays 16-byte aligned, read-only during a render):
+//   * "scan" arrays are walked by every lane in lock-step with a wave-uniform index, so the
+//     compiler fetches them with scalar loads (s_load_dwordx4/x8) into SGPRs: 48 B per sphere /
+//     cube (inverse affine rows), 16 B per plane, 48 B per triangle.
+//   * "shade" arrays are indexed per lane by the winning primitive code after the scan
+//     (normal transform, vertex normals, object -> material).
+//   * large meshes are a BVH2 (32-byte nodes) + the same 48-byte triangle records, walked per lane.
+#pragma once
+#include <stdint.h>
+
+namespace rptg {
+
+struct alignas(16) F4 {
+    float x, y, z, w;
+};
+
+// Primitive code = (kind << 28) | index-within-kind.  0xFFFFFFFF = miss.
+enum : uint32_t { K_SPHERE = 0, K_CUBE = 1, K_PLANE = 2, K_TRI = 3, K_BVHTRI = 4 };
+static const uint32_t CODE_MISS = 0xFFFFFFFFu;
+
+// Sphere / cube scan record: rows of the inverse affine map (world -> unit primitive).
+// For a bare (untransformed) shape this is the identity.
+struct alignas(16) XfScan {
+    F4 r0, r1, r2;  // local = (r.xyz . p) + r.w
+};
+// Sphere / cube shade record: rows of the normal transform (M^-T of the linear part);
+// r0.w = object id (bits), r1.w = 1.0f if wrapped in Transformed (normal is re-normalised).
+struct alignas(16) XfShade {
+    F4 r0, r1, r2;
+};
+// Plane: world-space (n, value) with the reference's |n.d| < 1e-8 parallel test; shade record
+// holds the unit normal and the object id.
+struct alignas(16) PlaneScan {
+    F4 nv;
+};
+struct alignas(16) PlaneShade {
+    F4 unit_n_obj;
+};
+// World-space triangle, pre-solved: t = (pn.w - pn.o) / (pn.d); P = o + t d;
+// v = A.P + A.w, w = B.P + B.w, u = 1 - v - w  (same barycentrics as src/shape/mesh.rs:62-73).
+struct alignas(16) TriScan {
+    F4 pn, A, B;
+};
+// Vertex normals (already multiplied by M^-T for Transformed<Mesh>); n1.w = object id (bits).
+struct alignas(16) TriShade {
+    F4 n1, n2, n3;
+};
+struct alignas(16) BvhNode {
+    float lo[3];
+    uint32_t left_or_first;  // inner: index of left child (right = left+1); leaf: first triangle
+    float hi[3];
+    uint32_t count;          // 0 = inner node, else number of triangles
+};
+enum : uint32_t { M_LAMBERTIAN = 0, M_PHONG = 1, M_MIRROR = 2, M_TRANSMISSIVE = 3 };
+struct alignas(16) Material {
+    F4 albedo_emit;  // rgb albedo, emittance
+    F4 params;       // kind (bits), shininess, ior, unused
+};
+// Light record (scene.lights order is preserved: it fixes the RNG draw order).
+enum : uint32_t { L_POINT = 0, L_AMBIENT = 1, L_DIRECTIONAL = 2, L_OBJECT = 3 };
+enum : uint32_t { LS_SPHERE = 0, LS_CUBE = 1, LS_MESH = 3 };
+struct alignas(16) Light {
+    uint32_t kind;        // L_*
+    uint32_t shape;       // LS_* for L_OBJECT
+    int32_t twin_object;  // scene object identical to this light's object, or -1 (never visible)
+    uint32_t first;       // LS_MESH: first LightTri
+    uint32_t count;       // LS_MESH: triangle count
+    uint32_t xf;          // index into lxf (every object light has one)
+    uint32_t _pad[2];
+    F4 color;             // Ambient: colour;  Object: material.color() * material.emittance()
+};
+// Light-mesh triangle: world-space vertices, LOCAL vertex normals and 1/(local area): the
+// pdf / normal mapping of Transformed::sample (src/shape.rs:140-151) is applied per sample.
+struct alignas(16) LightTri {
+    F4 v1, v2, v3;  // v1.w = 1/area_local
+    F4 n1, n2, n3;
+};
+// Sphere / cube light: forward + inverse affine, normal transform, linear part, det.
+struct alignas(16) LightXf {
+    F4 fwd[3];   // local -> world
+    F4 inv[3];   // world -> local
+    F4 nrm[3];   // M^-T rows; nrm[0].w = det(linear); nrm[1].w = has_transform
+    F4 lin[3];   // linear rows
+};
+struct alignas(16) MeshRef {   // one BVH-accelerated mesh object
+    uint32_t node_base, tri_base, tri_count, object;
+};
+
+struct SceneView {
+    const XfScan* sph;     const XfShade* sph_sh;   uint32_t n_sph;
+    const XfScan* cub;     const XfShade* cub_sh;   uint32_t n_cub;
+    const PlaneScan* pln;  const PlaneShade* pln_sh; uint32_t n_pln;
+    const TriScan* tri;    const TriShade* tri_sh;  uint32_t n_tri;
+    const BvhNode* nodes;  const TriScan* btri;     const TriShade* btri_sh;
+    const MeshRef* meshes; uint32_t n_mesh;
+    const Material* mats;  uint32_t n_obj;   // one material record per scene object
+    const Light* lights;   uint32_t n_lights;
+    const LightTri* ltris; const LightXf* lxf;
+    // medium (media[0]); has_medium = 0: surface-only branch
+    uint32_t has_medium, medium_kind;
+    float sigma_a, sigma_s;
+    float medium_color[3];      // homogeneous_isotropic colour, or the y <= 250 colour
+    float medium_color_hi[3];   // colored_glowing_fog colour for y > 250
+    float medium_emission, medium_phase;
+    float env[3];
+};
+
+struct CameraG {
+    float eye[3], ddir[3], right[3], up[3];  // ddir = cot(fov/2) * direction
+    float aperture, focal_distance;
+};
+
+}  // namespace rptg

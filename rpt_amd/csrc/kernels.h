@@ -1,0 +1,50 @@
+// kernels.h — host-callable launchers of the HIP kernels (implemented in kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "gpu_layout.h"
+
+namespace rptg {
+
+struct RenderArgs {
+    SceneView sc;
+    CameraG cam;
+    uint32_t width, height;
+    float inv_dim;            // 1 / max(width, height)
+    uint32_t max_bounces;
+    uint32_t iterations;      // paths per pixel in this call
+    uint32_t sample_offset;
+    uint32_t chunk_spp;       // samples per work item
+    uint32_t n_chunks;        // ceil(iterations / chunk_spp)
+    uint64_t seed_mixed;      // mix64(seed + GOLDEN)
+    const uint32_t* tiles;    // owned 32x32 tiles (tile id = ty * tiles_x + tx)
+    uint32_t n_tiles, tiles_x;
+    uint32_t n_owned;         // n_tiles * 1024 pixel slots
+    uint32_t n_items;         // n_owned * n_chunks
+    float* slab;              // [n_chunks][n_owned] float4 partial sums
+    uint32_t* queue;          // work counter (zeroed before the launch)
+    unsigned long long* counters;  // 8 x u64 or nullptr
+    uint32_t lds_stack;       // 1: BVH stack in dynamic LDS
+};
+
+struct KernelInfo {
+    int vgprs, sgprs, lds, max_blocks_per_cu;
+};
+
+// Persistent megakernel: grid = n_blocks x 256 threads.
+hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream);
+hipError_t render_occupancy(bool medium, bool bvh, int* blocks_per_cu);
+// out[pixel] = sum_chunks slab / iterations * scale for owned pixels (others untouched).
+hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipStream_t stream);
+hipError_t launch_intersect(const SceneView& sc, uint64_t n, const float* d_o, const float* d_d, float* d_t,
+                            int32_t* d_obj, float* d_n, bool bvh, hipStream_t stream);
+hipError_t launch_debug_rng(uint64_t seed_mixed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* d_out,
+                            hipStream_t stream);
+hipError_t launch_debug_sample_f(const Material& m, uint64_t n, const float* d_n, const float* d_wo,
+                                 uint64_t seed_mixed, float* d_wi, float* d_pdf, int32_t* d_some, hipStream_t s);
+hipError_t launch_debug_bsdf(const Material& m, uint64_t n, const float* d_n, const float* d_wo, const float* d_wi,
+                             float* d_out, hipStream_t s);
+hipError_t launch_debug_camera(const CameraG& cam, uint32_t w, uint32_t h, uint64_t seed_mixed, uint32_t sample,
+                               float* d_o, float* d_d, hipStream_t s);
+
+}  // namespace rptg

@@ -1,0 +1,392 @@
+// kernels.hip — HIP kernels for gfx950 (MI355X): the persistent path-tracing megakernel,
+// the slab resolve, the batched closest-hit test hook and small device self-test kernels.
+//
+// Megakernel structure (replaces the rayon row loop + recursive trace_ray of
+// src/renderer.rs:158-322):
+//   * one lane = one in-flight path; a lane owns a work item (pixel, chunk of <= chunk_spp
+//     samples), loops over the chunk's samples and, when the item is done, pulls the next one
+//     from a global counter with ONE wave-aggregated atomic (ballot + mbcnt prefix);
+//   * the recursion is flattened into a single loop: every trip processes exactly one path
+//     vertex for every live lane (closest hit -> event -> next-event estimation -> bounce), and
+//     a lane whose path ended regenerates its next camera ray in the same trip, so lanes of a
+//     wave never wait for the longest path;
+//   * radiance is carried forward as h(x) = min(P + Q*x, R) per channel, which is closed under
+//     composition with the reference's per-vertex map x -> E + min(k*x, 100)
+//     (src/renderer.rs:308-313); in a medium there is no clamp (R = +inf) and it reduces to
+//     the usual throughput form (src/renderer.rs:229-232, 271-280);
+//   * partial sums go to slab[chunk][pixel] (fp32) and are summed in fp64 in chunk order by
+//     resolve_kernel, so the image is bit-identical for any grid size, schedule or GPU count.
+#include "device_core.h"
+#include "kernels.h"
+
+namespace rptg {
+
+RPT_DEV uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+}
+RPT_DEV uint32_t code_object(const SceneView& sc, uint32_t code) {
+    uint32_t kind = code >> 28, idx = code & 0x0FFFFFFFu;
+    float w;
+    if (kind == K_SPHERE) w = sc.sph_sh[idx].r0.w;
+    else if (kind == K_CUBE) w = sc.cub_sh[idx].r0.w;
+    else if (kind == K_PLANE) w = sc.pln_sh[idx].unit_n_obj.w;
+    else if (kind == K_TRI) w = sc.tri_sh[idx].n1.w;
+    else w = sc.btri_sh[idx].n1.w;
+    return __float_as_uint(w);
+}
+// t_min stand-in for the reference's EPSILON = 1e-12 (src/renderer.rs:17, 420), which is below
+// fp32 resolution: scaled to the magnitude of the ray origin.
+RPT_DEV float ray_tmin(V o) { return 2e-5f * (1.f + max3(fabsf(o.x), fabsf(o.y), fabsf(o.z))); }
+
+RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& y) {
+    uint32_t tl = p >> 10, within = p & 1023u, sb = within >> 6, l = within & 63u;
+    uint32_t tile = a.tiles[tl];
+    uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    x = tx * 32u + (sb & 3u) * 8u + (l & 7u);
+    y = ty * 32u + (sb >> 2) * 8u + (l >> 3);
+}
+
+template <bool MEDIUM, bool BVH, bool COUNT>
+__global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
+    extern __shared__ uint32_t dyn_lds[];
+    const SceneView& sc = a.sc;
+    uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
+    const uint32_t stride = 256;
+
+    const float sigma_t = sc.sigma_a + sc.sigma_s;
+    const float inv_sigma_t = MEDIUM ? 1.f / sigma_t : 0.f;
+    const float albedo_med = MEDIUM ? sc.sigma_s / sigma_t : 0.f;
+    const V env = mk(sc.env[0], sc.env[1], sc.env[2]);
+
+    Rng rng;
+    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    V ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    V P = mk(0, 0, 0), Q = mk(1, 1, 1), Rc = mk(kInf, kInf, kInf);
+    V acc = mk(0, 0, 0);
+    uint32_t depth = 0, slab_idx = 0, s = 0, s_end = 0, pix = 0;
+    float xn = 0.f, yn = 0.f;
+    bool alive = true, have_item = false, need_path = true;
+    uint32_t c_samples = 0, c_rays = 0, c_vertices = 0, c_trips = 0, c_nodes = 0, c_btris = 0;
+
+    for (;;) {
+        if (need_path && alive) {
+            if (s >= s_end) {
+                if (have_item) {
+                    reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+                    have_item = false;
+                }
+                for (;;) {  // wave-aggregated pull; loops only past out-of-image pixel slots
+                    uint64_t m = __ballot(1);
+                    uint32_t rank = mbcnt64(m);
+                    uint32_t base = 0;
+                    if (rank == 0) base = atomicAdd(a.queue, uint32_t(__popcll(m)));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    uint32_t item = base + rank;
+                    if (item >= a.n_items) {
+                        alive = false;
+                        break;
+                    }
+                    uint32_t chunk = item / a.n_owned, p = item - chunk * a.n_owned;
+                    uint32_t x, y;
+                    item_pixel(a, p, x, y);
+                    if (x < a.width && y < a.height) {
+                        have_item = true;
+                        slab_idx = item;
+                        acc = mk(0, 0, 0);
+                        s = chunk * a.chunk_spp;
+                        s_end = min(s + a.chunk_spp, a.iterations);
+                        pix = y * a.width + x;
+                        // src/renderer.rs:174-176
+                        xn = (float(2u * x + 1u) - float(a.width)) * a.inv_dim;
+                        yn = (float(2u * (a.height - y) - 1u) - float(a.height)) * a.inv_dim;
+                        break;
+                    }
+                }
+            }
+            if (alive) {  // src/renderer.rs:179-181
+                rng.seed(a.seed_mixed, pix, a.sample_offset + s);
+                float dx = rng.range(-a.inv_dim, a.inv_dim);
+                float dy = rng.range(-a.inv_dim, a.inv_dim);
+                cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
+                depth = 0;
+                P = mk(0, 0, 0);
+                Q = mk(1, 1, 1);
+                Rc = mk(kInf, kInf, kInf);
+                s++;
+                need_path = false;
+                if (COUNT) c_samples++;
+            }
+        }
+        if (!__any(alive)) break;
+        if (COUNT && (threadIdx.x & 63u) == 0) c_trips++;
+        if (!alive) continue;
+
+        // ---- one path vertex (one trace_ray invocation, src/renderer.rs:187-322)
+        if (COUNT) c_vertices++;
+        float dmed = kInf;
+        if (MEDIUM) {  // Medium::sample_d, src/medium.rs:133-146
+            float xi = rng.range(0.f, 1.f);
+            dmed = -__logf(xi) * inv_sigma_t;
+        }
+        const V wo = -normalize(rd);
+        const float tmin = ray_tmin(ro);
+        float t = kInf;
+        uint32_t code = CODE_MISS;
+        closest_hit<BVH, COUNT>(sc, ro, rd, tmin, t, code, stk, stride, c_nodes, c_btris);
+        if (COUNT) c_rays++;
+        const bool hit = code != CODE_MISS;
+
+        const bool ev_medium = MEDIUM && (dmed < (hit ? t : 400.f));  // src/renderer.rs:197-243
+        const bool ev_surface = !ev_medium && hit;
+        if (!ev_medium && !ev_surface) {  // miss: environment (src/renderer.rs:198-206, 288)
+            acc = acc + vmin(fma3(Q, env, P), Rc);
+            need_path = true;
+            continue;
+        }
+
+        V x, n = mk(0, 1, 0), mcol = mk(0, 0, 0), E;
+        Mat mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
+        if (ev_medium) {  // src/renderer.rs:243-255
+            x = fma3(dmed, rd, ro);
+            bool hi = sc.medium_kind == 1u && x.y > 250.f;
+            mcol = hi ? mk(sc.medium_color_hi[0], sc.medium_color_hi[1], sc.medium_color_hi[2])
+                      : mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);
+            E = (depth == 0) ? sc.medium_emission * mcol : mk(0, 0, 0);
+        } else {  // src/renderer.rs:207-216, 289-299
+            uint32_t obj;
+            finalize_hit(sc, ro, rd, tmin, t, code, n, obj);
+            mat = load_mat(sc, obj);
+            x = fma3(t, rd, ro);
+            E = (depth == 0) ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
+        }
+
+        // ---- next-event estimation: sample_lights / sample_lights_for_media
+        //      (src/renderer.rs:362-409 / 325-359); lights in scene order fix the draw order.
+        for (uint32_t li = 0; li < sc.n_lights; li++) {
+            const Light L = sc.lights[li];
+            if (L.kind == L_AMBIENT) {
+                E = fma3(xyz(L.color), ev_medium ? mcol : mat_color(mat), E);
+            } else if (L.kind == L_OBJECT) {
+                V I, wi;
+                float dist;
+                illuminate_object(sc, L, x, rng, I, wi, dist);
+                if (L.twin_object >= 0) {
+                    // Reference: contributes iff the closest hit along wi lies at dist_to_light
+                    // (|hit - dist| < 1e-12).  fp32 equivalent: the closest hit belongs to the
+                    // scene object that IS this light, at the sampled distance (rel. tol 1e-3).
+                    float ts = dist * (1.f + 1e-3f);
+                    uint32_t cs = CODE_MISS;
+                    closest_hit<BVH, COUNT>(sc, x, wi, ray_tmin(x), ts, cs, stk, stride, c_nodes, c_btris);
+                    if (COUNT) c_rays++;
+                    bool vis = cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) &&
+                               code_object(sc, cs) == uint32_t(L.twin_object);
+                    if (vis) {
+                        if (ev_medium) {
+                            E = fma3(albedo_med * sc.medium_phase, I * mcol, E);
+                        } else {
+                            V f = bsdf(mat, n, wo, wi);
+                            E = fma3(dot(wi, n), f * I, E);
+                        }
+                    }
+                }
+            }
+            // Point / Directional lights can never satisfy the reference's test (dist is the
+            // light position / +inf, src/light.rs:26-33): no draws, no contribution.
+        }
+
+        // ---- continue or end the path
+        bool bounce;
+        V wi = mk(0, 0, 1), k = mk(0, 0, 0);
+        if (ev_medium) {  // src/renderer.rs:262-281
+            bounce = rng.uniform() < 0.8f;
+            if (bounce) {
+                float ax = rng.range(-1.f, 1.f), ay = rng.range(-1.f, 1.f), az = rng.range(-1.f, 1.f);
+                wi = normalize(mk(ax, ay, az));        // src/medium.rs:87-93 (cube, then normalise)
+                k = (albedo_med * 1.25f) * mcol;       // (scat/ext) / ph_p * phase / rr_p, ph_p == phase
+            }
+        } else {
+            bounce = MEDIUM ? (rng.uniform() < 0.8f) : (depth < a.max_bounces);  // :222 / :301
+            if (bounce) {
+                float pdf;
+                bounce = sample_f(mat, n, wo, rng, wi, pdf);
+                if (bounce) {
+                    V f = bsdf(mat, n, wo, wi);
+                    float wgt = fabsf(dot(wi, n)) * rcp(MEDIUM ? pdf * 0.8f : pdf);
+                    k = wgt * f;
+                }
+            }
+        }
+        P = fma3(Q, E, P);
+        if (bounce && !is_zero(k)) {
+            if (!MEDIUM) Rc = vmin(Rc, fma3(100.f, Q, P));  // FIREFLY_CLAMP, src/renderer.rs:311-313
+            Q = Q * k;
+            ro = x;
+            rd = wi;
+            depth++;
+        } else {
+            acc = acc + vmin(P, Rc);
+            need_path = true;
+        }
+    }
+
+    if (COUNT) {
+        atomicAdd(&a.counters[0], (unsigned long long)c_samples);
+        atomicAdd(&a.counters[1], (unsigned long long)c_rays);
+        atomicAdd(&a.counters[2], (unsigned long long)c_vertices);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&a.counters[3], (unsigned long long)c_trips);
+        atomicAdd(&a.counters[5], (unsigned long long)c_nodes);
+        atomicAdd(&a.counters[6], (unsigned long long)c_btris);
+    }
+}
+
+__global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs a, double scale, double* __restrict__ out) {
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= a.n_owned) return;
+    uint32_t x, y;
+    item_pixel(a, p, x, y);
+    if (x >= a.width || y >= a.height) return;
+    double r = 0.0, g = 0.0, b = 0.0;
+    const float4* slab = reinterpret_cast<const float4*>(a.slab);
+    for (uint32_t c = 0; c < a.n_chunks; c++) {
+        float4 v = slab[size_t(c) * a.n_owned + p];
+        r += double(v.x);
+        g += double(v.y);
+        b += double(v.z);
+    }
+    size_t o = (size_t(y) * a.width + x) * 3;
+    double inv = scale / double(a.iterations);
+    out[o] = r * inv;
+    out[o + 1] = g * inv;
+    out[o + 2] = b * inv;
+}
+
+template <bool BVH>
+__global__ __launch_bounds__(256) void intersect_kernel(const SceneView sc, uint64_t n, const float* __restrict__ o,
+                                                        const float* __restrict__ d, float* __restrict__ t_out,
+                                                        int32_t* __restrict__ obj_out, float* __restrict__ n_out) {
+    extern __shared__ uint32_t dyn_lds[];
+    uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
+    uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (i >= n) return;
+    V ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    float tmin = ray_tmin(ro), t = kInf;
+    uint32_t code = CODE_MISS, c0 = 0, c1 = 0;
+    closest_hit<BVH, false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
+    V nn = mk(0, 0, 0);
+    uint32_t obj = 0xFFFFFFFFu;
+    if (code != CODE_MISS) finalize_hit(sc, ro, rd, tmin, t, code, nn, obj);
+    t_out[i] = t;
+    obj_out[i] = int32_t(obj);
+    if (n_out) {
+        n_out[3 * i] = nn.x;
+        n_out[3 * i + 1] = nn.y;
+        n_out[3 * i + 2] = nn.z;
+    }
+}
+
+__global__ void debug_rng_kernel(uint64_t seed_mixed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Rng r;
+    r.seed(seed_mixed, pixel, sample);
+    for (uint32_t i = 0; i < n; i++) out[i] = r.next();
+}
+RPT_DEV Mat mat_from(const Material& m) {
+    return Mat{xyz(m.albedo_emit), m.albedo_emit.w, __float_as_uint(m.params.x), m.params.y, m.params.z};
+}
+__global__ void debug_sample_f_kernel(const Material m, uint64_t n, const float* nrm, const float* wo, uint64_t seed_mixed,
+                                      float* wi, float* pdf, int32_t* some) {
+    uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r;
+    r.seed(seed_mixed, uint32_t(i), 0);
+    V w = mk(0, 0, 0);
+    float p = 0.f;
+    bool ok = sample_f(mat_from(m), mk(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]),
+                       mk(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]), r, w, p);
+    wi[3 * i] = w.x; wi[3 * i + 1] = w.y; wi[3 * i + 2] = w.z;
+    pdf[i] = p;
+    some[i] = ok ? 1 : 0;
+}
+__global__ void debug_bsdf_kernel(const Material m, uint64_t n, const float* nrm, const float* wo, const float* wi,
+                                  float* out) {
+    uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V f = bsdf(mat_from(m), mk(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]), mk(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]),
+               mk(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]));
+    out[3 * i] = f.x; out[3 * i + 1] = f.y; out[3 * i + 2] = f.z;
+}
+__global__ void debug_camera_kernel(const CameraG cam, uint32_t w, uint32_t h, uint64_t seed_mixed, uint32_t sample,
+                                    float* o, float* d) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    uint32_t x = i % w, y = i / w;
+    float inv_dim = 1.f / float(max(w, h));
+    float xn = (float(2u * x + 1u) - float(w)) * inv_dim;
+    float yn = (float(2u * (h - y) - 1u) - float(h)) * inv_dim;
+    Rng r;
+    r.seed(seed_mixed, i, sample);
+    float dx = r.range(-inv_dim, inv_dim), dy = r.range(-inv_dim, inv_dim);
+    V ro, rd;
+    cast_ray(cam, xn + dx, yn + dy, r, ro, rd);
+    o[3 * i] = ro.x; o[3 * i + 1] = ro.y; o[3 * i + 2] = ro.z;
+    d[3 * i] = rd.x; d[3 * i + 1] = rd.y; d[3 * i + 2] = rd.z;
+}
+
+// ------------------------------------------------------------------ launchers
+static constexpr size_t kStackBytes = 32u * 256u * sizeof(uint32_t);
+
+template <bool M, bool B, bool C>
+static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((render_kernel<M, B, C>), dim3(n_blocks), dim3(256), B ? kStackBytes : 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream) {
+    bool m = a.sc.has_medium != 0, b = a.sc.n_mesh != 0, c = a.counters != nullptr;
+    if (m) {
+        if (b) return c ? launch_render_t<true, true, true>(a, n_blocks, stream) : launch_render_t<true, true, false>(a, n_blocks, stream);
+        return c ? launch_render_t<true, false, true>(a, n_blocks, stream) : launch_render_t<true, false, false>(a, n_blocks, stream);
+    }
+    if (b) return c ? launch_render_t<false, true, true>(a, n_blocks, stream) : launch_render_t<false, true, false>(a, n_blocks, stream);
+    return c ? launch_render_t<false, false, true>(a, n_blocks, stream) : launch_render_t<false, false, false>(a, n_blocks, stream);
+}
+hipError_t render_occupancy(bool medium, bool bvh, int* blocks_per_cu) {
+    const void* f;
+    if (medium) f = bvh ? (const void*)render_kernel<true, true, false> : (const void*)render_kernel<true, false, false>;
+    else f = bvh ? (const void*)render_kernel<false, true, false> : (const void*)render_kernel<false, false, false>;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, 256, bvh ? kStackBytes : 0);
+}
+hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipStream_t stream) {
+    uint32_t blocks = (a.n_owned + 255u) / 256u;
+    hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, stream, a, scale, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_intersect(const SceneView& sc, uint64_t n, const float* d_o, const float* d_d, float* d_t,
+                            int32_t* d_obj, float* d_n, bool bvh, hipStream_t stream) {
+    uint32_t blocks = uint32_t((n + 255) / 256);
+    if (bvh) hipLaunchKernelGGL(intersect_kernel<true>, dim3(blocks), dim3(256), kStackBytes, stream, sc, n, d_o, d_d, d_t, d_obj, d_n);
+    else hipLaunchKernelGGL(intersect_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, n, d_o, d_d, d_t, d_obj, d_n);
+    return hipGetLastError();
+}
+hipError_t launch_debug_rng(uint64_t seed_mixed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* d_out,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(debug_rng_kernel, dim3(1), dim3(64), 0, stream, seed_mixed, pixel, sample, n, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_debug_sample_f(const Material& m, uint64_t n, const float* d_n, const float* d_wo,
+                                 uint64_t seed_mixed, float* d_wi, float* d_pdf, int32_t* d_some, hipStream_t s) {
+    hipLaunchKernelGGL(debug_sample_f_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, s, m, n, d_n, d_wo, seed_mixed,
+                       d_wi, d_pdf, d_some);
+    return hipGetLastError();
+}
+hipError_t launch_debug_bsdf(const Material& m, uint64_t n, const float* d_n, const float* d_wo, const float* d_wi,
+                             float* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(debug_bsdf_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, s, m, n, d_n, d_wo, d_wi, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_debug_camera(const CameraG& cam, uint32_t w, uint32_t h, uint64_t seed_mixed, uint32_t sample,
+                               float* d_o, float* d_d, hipStream_t s) {
+    hipLaunchKernelGGL(debug_camera_kernel, dim3((w * h + 255) / 256), dim3(256), 0, s, cam, w, h, seed_mixed, sample, d_o, d_d);
+    return hipGetLastError();
+}
+
+}  // namespace rptg

@@ -1,0 +1,955 @@
+// rpt_capi.cpp — host side of the C ABI (include/rpt_hip.h): fp64 scene store, flattening to
+// the fp32 device layout (gpu_layout.h), BVH build for large meshes, launches.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/rpt_hip.h"
+#include "kernels.h"
+
+using namespace rptg;
+
+// ---------------------------------------------------------------------------- errors / options
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(RPT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));       \
+    } while (0)
+
+static int64_t g_opt_counters = 0;
+static int64_t g_opt_chunk_spp = 32;
+static int64_t g_opt_blocks_per_cu = 0;  // 0 = occupancy query
+
+// ---------------------------------------------------------------------------- fp64 helpers
+namespace {
+struct D3 {
+    double x, y, z;
+};
+inline D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline D3 operator*(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline D3 normalize(D3 a) {
+    double l = std::sqrt(dot(a, a));
+    return {a.x / l, a.y / l, a.z / l};
+}
+inline D3 d3(const double* p) { return {p[0], p[1], p[2]}; }
+inline F4 f4(D3 v, double w) { return F4{float(v.x), float(v.y), float(v.z), float(w)}; }
+inline float bits_f(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// Derived matrices of Transformed::new (src/shape.rs:112-125), fp64.
+struct Xf {
+    bool has = false;
+    double M[4][4], Minv[4][4], L[3][3], N[3][3], det = 1.0;
+    D3 point(D3 p) const { return {M[0][0] * p.x + M[0][1] * p.y + M[0][2] * p.z + M[0][3], M[1][0] * p.x + M[1][1] * p.y + M[1][2] * p.z + M[1][3], M[2][0] * p.x + M[2][1] * p.y + M[2][2] * p.z + M[2][3]}; }
+    D3 normal(D3 n) const { return {N[0][0] * n.x + N[0][1] * n.y + N[0][2] * n.z, N[1][0] * n.x + N[1][1] * n.y + N[1][2] * n.z, N[2][0] * n.x + N[2][1] * n.y + N[2][2] * n.z}; }
+};
+bool invert4(const double a[4][4], double out[4][4]) {
+    double w[4][8];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            w[i][j] = a[i][j];
+            w[i][4 + j] = i == j ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 4; c++) {
+        int p = c;
+        for (int r = c + 1; r < 4; r++)
+            if (std::fabs(w[r][c]) > std::fabs(w[p][c])) p = r;
+        if (w[p][c] == 0.0) return false;
+        if (p != c)
+            for (int j = 0; j < 8; j++) std::swap(w[p][j], w[c][j]);
+        double d = w[c][c];
+        for (int j = 0; j < 8; j++) w[c][j] /= d;
+        for (int r = 0; r < 4; r++)
+            if (r != c) {
+                double f = w[r][c];
+                if (f != 0.0)
+                    for (int j = 0; j < 8; j++) w[r][j] -= f * w[c][j];
+            }
+    }
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) out[i][j] = w[i][4 + j];
+    return true;
+}
+bool make_xf(const rpt_shape_desc& d, Xf& x) {
+    x.has = d.has_transform != 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) x.M[i][j] = x.has ? d.transform[i * 4 + j] : (i == j ? 1.0 : 0.0);
+    if (!invert4(x.M, x.Minv)) return false;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) x.L[i][j] = x.M[i][j];
+    const auto& a = x.L;
+    x.det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+            a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    if (x.det == 0.0 || !(x.det == x.det)) return false;
+    // inverse transpose of the linear part
+    double inv[3][3];
+    inv[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) / x.det;
+    inv[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / x.det;
+    inv[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / x.det;
+    inv[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) / x.det;
+    inv[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / x.det;
+    inv[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / x.det;
+    inv[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) / x.det;
+    inv[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / x.det;
+    inv[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / x.det;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) x.N[i][j] = inv[j][i];
+    return true;
+}
+D3 hex_color(uint32_t v) {  // src/color.rs:10-15
+    auto ch = [](uint32_t c) { return std::pow(double(c) / 255.0, 2.2); };
+    return {ch((v >> 16) & 0xff), ch((v >> 8) & 0xff), ch(v & 0xff)};
+}
+uint64_t mix64(uint64_t x) {
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return x;
+}
+uint64_t seed_mix(uint64_t seed) { return mix64(seed + 0x9E3779B97F4A7C15ULL); }
+
+// ---------------------------------------------------------------------------- host scene
+struct HShape {
+    rpt_shape_desc d;            // tris pointer rewritten to own storage
+    std::vector<double> tris;
+};
+struct HObject {
+    HShape shape;
+    rpt_material mat;
+};
+struct HLight {
+    int kind;
+    double color[3], vec[3];
+    HObject obj;
+};
+struct HMedium {
+    int kind;
+    double absorption, scattering;
+};
+bool same_shape(const HShape& a, const HShape& b) {
+    if (a.d.kind != b.d.kind || a.d.has_transform != b.d.has_transform) return false;
+    if (a.d.has_transform && std::memcmp(a.d.transform, b.d.transform, sizeof(a.d.transform)) != 0) return false;
+    if (a.d.kind == RPT_SHAPE_PLANE)
+        return std::memcmp(a.d.plane_normal, b.d.plane_normal, 24) == 0 && a.d.plane_value == b.d.plane_value;
+    if (a.d.kind == RPT_SHAPE_MESH)
+        return a.tris.size() == b.tris.size() &&
+               (a.tris.empty() || std::memcmp(a.tris.data(), b.tris.data(), a.tris.size() * 8) == 0);
+    return true;
+}
+
+// ---------------------------------------------------------------------------- BVH build
+struct BTri {
+    float lo[3], hi[3], c[3];
+    uint32_t idx;
+};
+struct BvhBuilder {
+    std::vector<BTri>& t;
+    std::vector<BvhNode>& nodes;
+    static constexpr int kBins = 16, kMaxDepth = 28;
+    uint32_t leaf_max = 4;
+    void bounds(uint32_t first, uint32_t count, float lo[3], float hi[3], float clo[3], float chi[3]) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = clo[a] = std::numeric_limits<float>::infinity();
+            hi[a] = chi[a] = -std::numeric_limits<float>::infinity();
+        }
+        for (uint32_t i = first; i < first + count; i++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = std::min(lo[a], t[i].lo[a]);
+                hi[a] = std::max(hi[a], t[i].hi[a]);
+                clo[a] = std::min(clo[a], t[i].c[a]);
+                chi[a] = std::max(chi[a], t[i].c[a]);
+            }
+    }
+    static float area(const float lo[3], const float hi[3]) {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    void build(uint32_t node, uint32_t first, uint32_t count, int depth) {
+        float lo[3], hi[3], clo[3], chi[3];
+        bounds(first, count, lo, hi, clo, chi);
+        BvhNode& n = nodes[node];
+        for (int a = 0; a < 3; a++) {  // conservative padding for the fp32 slab test
+            float pad = 1e-6f * std::max(std::fabs(lo[a]), std::fabs(hi[a])) + 1e-30f;
+            n.lo[a] = lo[a] - pad;
+            n.hi[a] = hi[a] + pad;
+        }
+        auto make_leaf = [&]() {
+            nodes[node].left_or_first = first;
+            nodes[node].count = count;
+        };
+        if (count <= leaf_max || depth >= kMaxDepth) return make_leaf();
+        int best_axis = -1, best_bin = -1;
+        float best_cost = std::numeric_limits<float>::infinity();
+        for (int a = 0; a < 3; a++) {
+            float ext = chi[a] - clo[a];
+            if (!(ext > 0.f)) continue;
+            uint32_t cnt[kBins] = {0};
+            float blo[kBins][3], bhi[kBins][3];
+            for (int b = 0; b < kBins; b++)
+                for (int k = 0; k < 3; k++) {
+                    blo[b][k] = std::numeric_limits<float>::infinity();
+                    bhi[b][k] = -std::numeric_limits<float>::infinity();
+                }
+            float scale = float(kBins) / ext;
+            for (uint32_t i = first; i < first + count; i++) {
+                int b = std::min(kBins - 1, int((t[i].c[a] - clo[a]) * scale));
+                cnt[b]++;
+                for (int k = 0; k < 3; k++) {
+                    blo[b][k] = std::min(blo[b][k], t[i].lo[k]);
+                    bhi[b][k] = std::max(bhi[b][k], t[i].hi[k]);
+                }
+            }
+            float la[kBins], ra[kBins];
+            uint32_t lc[kBins], rc[kBins];
+            float l0[3], h0[3];
+            for (int k = 0; k < 3; k++) { l0[k] = std::numeric_limits<float>::infinity(); h0[k] = -l0[k]; }
+            uint32_t c = 0;
+            for (int b = 0; b < kBins; b++) {
+                c += cnt[b];
+                for (int k = 0; k < 3; k++) { l0[k] = std::min(l0[k], blo[b][k]); h0[k] = std::max(h0[k], bhi[b][k]); }
+                lc[b] = c;
+                la[b] = c ? area(l0, h0) : 0.f;
+            }
+            for (int k = 0; k < 3; k++) { l0[k] = std::numeric_limits<float>::infinity(); h0[k] = -l0[k]; }
+            c = 0;
+            for (int b = kBins - 1; b >= 0; b--) {
+                c += cnt[b];
+                for (int k = 0; k < 3; k++) { l0[k] = std::min(l0[k], blo[b][k]); h0[k] = std::max(h0[k], bhi[b][k]); }
+                rc[b] = c;
+                ra[b] = c ? area(l0, h0) : 0.f;
+            }
+            for (int b = 0; b < kBins - 1; b++) {
+                if (lc[b] == 0 || rc[b + 1] == 0) continue;
+                float cost = la[b] * float(lc[b]) + ra[b + 1] * float(rc[b + 1]);
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        uint32_t mid;
+        if (best_axis < 0) {
+            if (count <= 16) return make_leaf();
+            mid = first + count / 2;  // all centroids coincide: split by index
+        } else {
+            float parent_cost = area(lo, hi) * float(count);
+            if (best_cost >= parent_cost && count <= 8) return make_leaf();
+            float ext = chi[best_axis] - clo[best_axis];
+            float scale = float(kBins) / ext;
+            auto it = std::partition(t.begin() + first, t.begin() + first + count, [&](const BTri& x) {
+                int b = std::min(kBins - 1, int((x.c[best_axis] - clo[best_axis]) * scale));
+                return b <= best_bin;
+            });
+            mid = uint32_t(it - t.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        }
+        uint32_t left = uint32_t(nodes.size());
+        nodes.push_back(BvhNode{});
+        nodes.push_back(BvhNode{});
+        nodes[node].left_or_first = left;
+        nodes[node].count = 0;
+        build(left, first, mid - first, depth + 1);
+        build(left + 1, mid, first + count - mid, depth + 1);
+    }
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- rpt_scene
+struct rpt_scene {
+    std::vector<HObject> objects;
+    std::vector<HLight> lights;
+    std::vector<HMedium> media;
+    double env[3] = {0, 0, 0};
+    bool committed = false;
+    int device = 0;
+    int n_cus = 256;
+    // device memory
+    void* arena = nullptr;
+    SceneView view{};
+    // per-render cached buffers
+    uint32_t* d_tiles = nullptr;
+    size_t tiles_cap = 0;
+    float* d_slab = nullptr;
+    size_t slab_cap = 0;  // bytes
+    uint32_t* d_queue = nullptr;
+    unsigned long long* d_counters = nullptr;
+    double* d_out = nullptr;
+    size_t out_cap = 0;  // bytes
+    uint64_t last_counters[8] = {0};
+    uint64_t prims_per_ray = 0;
+    // tile cache key
+    uint32_t tk_w = 0, tk_h = 0, tk_rank = 0, tk_count = 0, n_tiles = 0, tiles_x = 0;
+};
+
+static bool copy_shape(const rpt_shape_desc* d, HShape& out, std::string& why) {
+    if (!d) { why = "null shape"; return false; }
+    if (d->kind < 0 || d->kind > RPT_SHAPE_MESH) { why = "unknown shape kind"; return false; }
+    out.d = *d;
+    out.tris.clear();
+    if (d->kind == RPT_SHAPE_MESH) {
+        if (d->n_tris == 0 || !d->tris) { why = "mesh without triangles"; return false; }
+        out.tris.assign(d->tris, d->tris + d->n_tris * 18);
+    }
+    out.d.tris = nullptr;
+    Xf x;
+    if (!make_xf(*d, x)) { why = "singular transform"; return false; }
+    return true;
+}
+static bool check_material(const rpt_material* m, std::string& why) {
+    if (!m) { why = "null material"; return false; }
+    if (m->kind < 0 || m->kind > RPT_MAT_TRANSMISSIVE) { why = "unknown material kind"; return false; }
+    return true;
+}
+
+namespace {
+struct TmpDev {
+    std::vector<void*> ptrs;
+    ~TmpDev() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T** p, size_t n) {
+        hipError_t e = hipMalloc((void**)p, std::max<size_t>(n * sizeof(T), 16));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+const char* rpt_last_error(void) { return g_err.c_str(); }
+
+int rpt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rpt_set_option(const char* name, int64_t value) {
+    if (!name) return fail(RPT_ERR_INVALID, "null option name");
+    std::string s(name);
+    if (s == "counters") g_opt_counters = value;
+    else if (s == "chunk_spp") { if (value < 1) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 1"); g_opt_chunk_spp = value; }
+    else if (s == "blocks_per_cu") g_opt_blocks_per_cu = value;
+    else return fail(RPT_ERR_INVALID, "unknown option " + s);
+    return RPT_OK;
+}
+
+rpt_scene* rpt_scene_create(void) { return new rpt_scene(); }
+
+void rpt_scene_destroy(rpt_scene* s) {
+    if (!s) return;
+    if (s->committed) {
+        (void)hipSetDevice(s->device);
+        (void)hipFree(s->arena);
+        (void)hipFree(s->d_tiles);
+        (void)hipFree(s->d_slab);
+        (void)hipFree(s->d_queue);
+        (void)hipFree(s->d_counters);
+        (void)hipFree(s->d_out);
+    }
+    delete s;
+}
+
+int rpt_scene_add_object(rpt_scene* s, const rpt_shape_desc* d, const rpt_material* m) {
+    if (!s) return fail(RPT_ERR_INVALID, "null scene");
+    if (s->committed) return fail(RPT_ERR_STATE, "scene is immutable after rpt_scene_commit");
+    std::string why;
+    HObject o;
+    if (!copy_shape(d, o.shape, why) || !check_material(m, why)) return fail(RPT_ERR_INVALID, why);
+    o.mat = *m;
+    s->objects.push_back(std::move(o));
+    return int(s->objects.size()) - 1;
+}
+static int add_simple_light(rpt_scene* s, int kind, const double* color, const double* vec) {
+    if (!s || !color) return fail(RPT_ERR_INVALID, "null argument");
+    if (s->committed) return fail(RPT_ERR_STATE, "scene is immutable after rpt_scene_commit");
+    HLight l{};
+    l.kind = kind;
+    std::memcpy(l.color, color, 24);
+    if (vec) std::memcpy(l.vec, vec, 24);
+    s->lights.push_back(std::move(l));
+    return RPT_OK;
+}
+int rpt_scene_add_light_point(rpt_scene* s, const double color[3], const double location[3]) {
+    if (!location) return fail(RPT_ERR_INVALID, "null location");
+    return add_simple_light(s, L_POINT, color, location);
+}
+int rpt_scene_add_light_ambient(rpt_scene* s, const double color[3]) { return add_simple_light(s, L_AMBIENT, color, nullptr); }
+int rpt_scene_add_light_directional(rpt_scene* s, const double color[3], const double direction[3]) {
+    if (!direction) return fail(RPT_ERR_INVALID, "null direction");
+    return add_simple_light(s, L_DIRECTIONAL, color, direction);
+}
+int rpt_scene_add_light_object(rpt_scene* s, const rpt_shape_desc* d, const rpt_material* m) {
+    if (!s) return fail(RPT_ERR_INVALID, "null scene");
+    if (s->committed) return fail(RPT_ERR_STATE, "scene is immutable after rpt_scene_commit");
+    std::string why;
+    HLight l{};
+    l.kind = L_OBJECT;
+    if (!copy_shape(d, l.obj.shape, why) || !check_material(m, why)) return fail(RPT_ERR_INVALID, why);
+    if (d->kind == RPT_SHAPE_PLANE)
+        return fail(RPT_ERR_INVALID, "a plane cannot be a Light::Object (Plane::sample is unimplemented in rpt)");
+    l.obj.mat = *m;
+    s->lights.push_back(std::move(l));
+    return RPT_OK;
+}
+int rpt_scene_add_medium(rpt_scene* s, int32_t kind, double absorption, double scattering) {
+    if (!s) return fail(RPT_ERR_INVALID, "null scene");
+    if (s->committed) return fail(RPT_ERR_STATE, "scene is immutable after rpt_scene_commit");
+    if (kind != RPT_MEDIUM_HOMOGENEOUS_ISOTROPIC && kind != RPT_MEDIUM_COLORED_GLOWING_FOG)
+        return fail(RPT_ERR_INVALID, "unknown medium kind");
+    if (!(absorption + scattering > 0.0)) return fail(RPT_ERR_INVALID, "medium extinction must be > 0");
+    s->media.push_back(HMedium{kind, absorption, scattering});
+    return RPT_OK;
+}
+int rpt_scene_set_environment_color(rpt_scene* s, const double rgb[3]) {
+    if (!s || !rgb) return fail(RPT_ERR_INVALID, "null argument");
+    if (s->committed) return fail(RPT_ERR_STATE, "scene is immutable after rpt_scene_commit");
+    std::memcpy(s->env, rgb, 24);
+    return RPT_OK;
+}
+
+// ---------------------------------------------------------------------------- commit (flatten + upload)
+static const uint64_t kLinearTriMax = 32;  // meshes up to this size are scanned linearly (scalar loads)
+
+static void push_tri(const double* t, const Xf& x, uint32_t obj, std::vector<TriScan>& scan,
+                     std::vector<TriShade>& shade) {
+    D3 v1 = x.point(d3(t)), v2 = x.point(d3(t + 3)), v3 = x.point(d3(t + 6));
+    D3 n1 = d3(t + 9), n2 = d3(t + 12), n3 = d3(t + 15);
+    bool flat = std::memcmp(t + 9, t + 12, 24) == 0 && std::memcmp(t + 9, t + 15, 24) == 0;
+    D3 w1 = x.has ? x.normal(n1) : n1, w2 = x.has ? x.normal(n2) : n2, w3 = x.has ? x.normal(n3) : n3;
+    D3 d0 = v2 - v1, d1 = v3 - v1;
+    D3 pn = normalize(cross(d0, d1));
+    double d00 = dot(d0, d0), d01 = dot(d0, d1), d11 = dot(d1, d1);
+    double denom = d00 * d11 - d01 * d01;
+    D3 A = (1.0 / denom) * (d11 * d0 - d01 * d1);
+    D3 B = (1.0 / denom) * (d00 * d1 - d01 * d0);
+    TriScan ts;
+    ts.pn = f4(pn, dot(pn, v1));
+    ts.A = f4(A, -dot(A, v1));
+    ts.B = f4(B, -dot(B, v1));
+    TriShade sh;
+    if (flat) {
+        sh.n1 = f4(normalize(w1), 0);
+        sh.n2 = f4(D3{0, 0, 0}, 1.0);
+        sh.n3 = f4(D3{0, 0, 0}, 0);
+    } else {
+        sh.n1 = f4(w1, 0);
+        sh.n2 = f4(w2, 0.0);
+        sh.n3 = f4(w3, 0);
+    }
+    sh.n1.w = bits_f(obj);
+    scan.push_back(ts);
+    shade.push_back(sh);
+}
+
+int rpt_scene_commit(rpt_scene* s, int device) {
+    if (!s) return fail(RPT_ERR_INVALID, "null scene");
+    if (s->committed) return fail(RPT_ERR_STATE, "scene already committed");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(RPT_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RPT_ERR_UNSUPPORTED, std::string("built for gfx950 (MI355X), device is ") + prop.gcnArchName);
+    s->n_cus = prop.multiProcessorCount;
+
+    std::vector<XfScan> sph, cub;
+    std::vector<XfShade> sph_sh, cub_sh;
+    std::vector<PlaneScan> pln;
+    std::vector<PlaneShade> pln_sh;
+    std::vector<TriScan> tri, btri;
+    std::vector<TriShade> tri_sh, btri_sh;
+    std::vector<BvhNode> nodes;
+    std::vector<MeshRef> meshes;
+    std::vector<Material> mats;
+    std::vector<Light> lights;
+    std::vector<LightTri> ltris;
+    std::vector<LightXf> lxf;
+
+    for (size_t oi = 0; oi < s->objects.size(); oi++) {
+        const HObject& o = s->objects[oi];
+        Xf x;
+        make_xf(o.shape.d, x);
+        const uint32_t obj = uint32_t(oi);
+        Material gm;
+        gm.albedo_emit = F4{float(o.mat.albedo[0]), float(o.mat.albedo[1]), float(o.mat.albedo[2]), float(o.mat.emittance)};
+        gm.params = F4{bits_f(uint32_t(o.mat.kind)), float(o.mat.shininess), float(o.mat.ior), 0.f};
+        mats.push_back(gm);
+        switch (o.shape.d.kind) {
+            case RPT_SHAPE_SPHERE:
+            case RPT_SHAPE_CUBE: {
+                XfScan sc;
+                sc.r0 = F4{float(x.Minv[0][0]), float(x.Minv[0][1]), float(x.Minv[0][2]), float(x.Minv[0][3])};
+                sc.r1 = F4{float(x.Minv[1][0]), float(x.Minv[1][1]), float(x.Minv[1][2]), float(x.Minv[1][3])};
+                sc.r2 = F4{float(x.Minv[2][0]), float(x.Minv[2][1]), float(x.Minv[2][2]), float(x.Minv[2][3])};
+                XfShade sh;
+                sh.r0 = F4{float(x.N[0][0]), float(x.N[0][1]), float(x.N[0][2]), bits_f(obj)};
+                sh.r1 = F4{float(x.N[1][0]), float(x.N[1][1]), float(x.N[1][2]), x.has ? 1.f : 0.f};
+                sh.r2 = F4{float(x.N[2][0]), float(x.N[2][1]), float(x.N[2][2]), 0.f};
+                if (o.shape.d.kind == RPT_SHAPE_SPHERE) { sph.push_back(sc); sph_sh.push_back(sh); }
+                else { cub.push_back(sc); cub_sh.push_back(sh); }
+                break;
+            }
+            case RPT_SHAPE_PLANE: {
+                // world-space plane: (M^-T n) . x = value + (M^-T n) . translation
+                D3 n = d3(o.shape.d.plane_normal);
+                double value = o.shape.d.plane_value;
+                if (x.has) {
+                    D3 nw = x.normal(n);
+                    value = value + dot(nw, D3{x.M[0][3], x.M[1][3], x.M[2][3]});
+                    n = nw;
+                }
+                pln.push_back(PlaneScan{f4(n, value)});
+                pln_sh.push_back(PlaneShade{f4(normalize(n), 0)});
+                pln_sh.back().unit_n_obj.w = bits_f(obj);
+                break;
+            }
+            default: {
+                uint64_t nt = o.shape.tris.size() / 18;
+                if (nt <= kLinearTriMax) {
+                    for (uint64_t i = 0; i < nt; i++) push_tri(&o.shape.tris[i * 18], x, obj, tri, tri_sh);
+                } else {
+                    std::vector<TriScan> ms;
+                    std::vector<TriShade> mh;
+                    ms.reserve(nt);
+                    mh.reserve(nt);
+                    std::vector<BTri> bt(nt);
+                    for (uint64_t i = 0; i < nt; i++) {
+                        const double* t = &o.shape.tris[i * 18];
+                        push_tri(t, x, obj, ms, mh);
+                        D3 v[3] = {x.point(d3(t)), x.point(d3(t + 3)), x.point(d3(t + 6))};
+                        for (int a = 0; a < 3; a++) {
+                            double c0 = (&v[0].x)[a], c1 = (&v[1].x)[a], c2 = (&v[2].x)[a];
+                            double lo = std::min(c0, std::min(c1, c2)), hi = std::max(c0, std::max(c1, c2));
+                            bt[i].lo[a] = std::nextafter(float(lo), -std::numeric_limits<float>::infinity());
+                            bt[i].hi[a] = std::nextafter(float(hi), std::numeric_limits<float>::infinity());
+                            bt[i].c[a] = float(0.5 * (lo + hi));
+                        }
+                        bt[i].idx = uint32_t(i);
+                    }
+                    MeshRef mr;
+                    mr.node_base = uint32_t(nodes.size());
+                    mr.tri_base = uint32_t(btri.size());
+                    mr.tri_count = uint32_t(nt);
+                    mr.object = obj;
+                    std::vector<BvhNode> local;
+                    local.reserve(nt);
+                    local.push_back(BvhNode{});
+                    BvhBuilder b{bt, local};
+                    b.build(0, 0, uint32_t(nt), 0);
+                    for (uint64_t i = 0; i < nt; i++) {
+                        btri.push_back(ms[bt[i].idx]);
+                        btri_sh.push_back(mh[bt[i].idx]);
+                    }
+                    nodes.insert(nodes.end(), local.begin(), local.end());
+                    meshes.push_back(mr);
+                }
+            }
+        }
+    }
+    if (tri.size() >= (1u << 28) || btri.size() >= (1u << 28)) return fail(RPT_ERR_UNSUPPORTED, "too many triangles");
+
+    for (const HLight& hl : s->lights) {
+        Light L{};
+        L.kind = uint32_t(hl.kind);
+        L.twin_object = -1;
+        L.color = F4{float(hl.color[0]), float(hl.color[1]), float(hl.color[2]), 0.f};
+        if (hl.kind == L_OBJECT) {
+            const HObject& o = hl.obj;
+            for (size_t j = 0; j < s->objects.size(); j++)
+                if (same_shape(o.shape, s->objects[j].shape)) { L.twin_object = int32_t(j); break; }
+            // material.color() * material.emittance() (src/light.rs:41, material.rs:100-113)
+            bool has = o.mat.kind == RPT_MAT_LAMBERTIAN || o.mat.kind == RPT_MAT_PHONG;
+            double e = has ? o.mat.emittance : 0.0;
+            L.color = F4{float(has ? o.mat.albedo[0] * e : 0.0), float(has ? o.mat.albedo[1] * e : 0.0),
+                         float(has ? o.mat.albedo[2] * e : 0.0), 0.f};
+            Xf x;
+            make_xf(o.shape.d, x);
+            LightXf gx;
+            for (int r = 0; r < 3; r++) {
+                gx.fwd[r] = F4{float(x.M[r][0]), float(x.M[r][1]), float(x.M[r][2]), float(x.M[r][3])};
+                gx.inv[r] = F4{float(x.Minv[r][0]), float(x.Minv[r][1]), float(x.Minv[r][2]), float(x.Minv[r][3])};
+                gx.nrm[r] = F4{float(x.N[r][0]), float(x.N[r][1]), float(x.N[r][2]), 0.f};
+                gx.lin[r] = F4{float(x.L[r][0]), float(x.L[r][1]), float(x.L[r][2]), 0.f};
+            }
+            gx.nrm[0].w = float(x.det);
+            gx.nrm[1].w = x.has ? 1.f : 0.f;
+            L.xf = uint32_t(lxf.size());
+            lxf.push_back(gx);
+            if (o.shape.d.kind == RPT_SHAPE_MESH) {
+                L.shape = LS_MESH;
+                L.first = uint32_t(ltris.size());
+                uint64_t nt = o.shape.tris.size() / 18;
+                L.count = uint32_t(nt);
+                for (uint64_t i = 0; i < nt; i++) {
+                    const double* t = &o.shape.tris[i * 18];
+                    D3 a = d3(t), b = d3(t + 3), c = d3(t + 6);
+                    D3 cr = cross(b - a, c - a);
+                    double area = 0.5 * std::sqrt(dot(cr, cr));  // local-space area (src/shape/mesh.rs:93)
+                    LightTri lt;
+                    lt.v1 = f4(x.point(a), 1.0 / area);
+                    lt.v2 = f4(x.point(b), 0);
+                    lt.v3 = f4(x.point(c), 0);
+                    lt.n1 = f4(d3(t + 9), 0);   // local normals; Transformed::sample maps them per sample
+                    lt.n2 = f4(d3(t + 12), 0);
+                    lt.n3 = f4(d3(t + 15), 0);
+                    ltris.push_back(lt);
+                }
+            } else {
+                L.shape = o.shape.d.kind == RPT_SHAPE_SPHERE ? LS_SPHERE : LS_CUBE;
+            }
+        }
+        lights.push_back(L);
+    }
+
+    // ---- one arena for every array
+    auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
+    size_t off = 0;
+    auto reserve = [&](size_t bytes) {
+        size_t o = off;
+        off += align(std::max<size_t>(bytes, 16));
+        return o;
+    };
+    size_t o_sph = reserve(sph.size() * sizeof(XfScan)), o_sphs = reserve(sph_sh.size() * sizeof(XfShade));
+    size_t o_cub = reserve(cub.size() * sizeof(XfScan)), o_cubs = reserve(cub_sh.size() * sizeof(XfShade));
+    size_t o_pln = reserve(pln.size() * sizeof(PlaneScan)), o_plns = reserve(pln_sh.size() * sizeof(PlaneShade));
+    size_t o_tri = reserve(tri.size() * sizeof(TriScan)), o_tris = reserve(tri_sh.size() * sizeof(TriShade));
+    size_t o_nodes = reserve(nodes.size() * sizeof(BvhNode));
+    size_t o_btri = reserve(btri.size() * sizeof(TriScan)), o_btris = reserve(btri_sh.size() * sizeof(TriShade));
+    size_t o_mesh = reserve(meshes.size() * sizeof(MeshRef));
+    size_t o_mats = reserve(mats.size() * sizeof(Material));
+    size_t o_lights = reserve(lights.size() * sizeof(Light));
+    size_t o_ltris = reserve(ltris.size() * sizeof(LightTri));
+    size_t o_lxf = reserve(lxf.size() * sizeof(LightXf));
+    std::vector<char> host(off, 0);
+    auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
+    put(o_sph, sph.data(), sph.size() * sizeof(XfScan));       put(o_sphs, sph_sh.data(), sph_sh.size() * sizeof(XfShade));
+    put(o_cub, cub.data(), cub.size() * sizeof(XfScan));       put(o_cubs, cub_sh.data(), cub_sh.size() * sizeof(XfShade));
+    put(o_pln, pln.data(), pln.size() * sizeof(PlaneScan));    put(o_plns, pln_sh.data(), pln_sh.size() * sizeof(PlaneShade));
+    put(o_tri, tri.data(), tri.size() * sizeof(TriScan));      put(o_tris, tri_sh.data(), tri_sh.size() * sizeof(TriShade));
+    put(o_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
+    put(o_btri, btri.data(), btri.size() * sizeof(TriScan));   put(o_btris, btri_sh.data(), btri_sh.size() * sizeof(TriShade));
+    put(o_mesh, meshes.data(), meshes.size() * sizeof(MeshRef));
+    put(o_mats, mats.data(), mats.size() * sizeof(Material));
+    put(o_lights, lights.data(), lights.size() * sizeof(Light));
+    put(o_ltris, ltris.data(), ltris.size() * sizeof(LightTri));
+    put(o_lxf, lxf.data(), lxf.size() * sizeof(LightXf));
+    HIP_TRY(hipMalloc(&s->arena, off));
+    HIP_TRY(hipMemcpy(s->arena, host.data(), off, hipMemcpyHostToDevice));
+    char* base = static_cast<char*>(s->arena);
+    SceneView& v = s->view;
+    v.sph = (const XfScan*)(base + o_sph);      v.sph_sh = (const XfShade*)(base + o_sphs);    v.n_sph = uint32_t(sph.size());
+    v.cub = (const XfScan*)(base + o_cub);      v.cub_sh = (const XfShade*)(base + o_cubs);    v.n_cub = uint32_t(cub.size());
+    v.pln = (const PlaneScan*)(base + o_pln);   v.pln_sh = (const PlaneShade*)(base + o_plns); v.n_pln = uint32_t(pln.size());
+    v.tri = (const TriScan*)(base + o_tri);     v.tri_sh = (const TriShade*)(base + o_tris);   v.n_tri = uint32_t(tri.size());
+    v.nodes = (const BvhNode*)(base + o_nodes); v.btri = (const TriScan*)(base + o_btri);      v.btri_sh = (const TriShade*)(base + o_btris);
+    v.meshes = (const MeshRef*)(base + o_mesh); v.n_mesh = uint32_t(meshes.size());
+    v.mats = (const Material*)(base + o_mats);  v.n_obj = uint32_t(mats.size());
+    v.lights = (const Light*)(base + o_lights); v.n_lights = uint32_t(lights.size());
+    v.ltris = (const LightTri*)(base + o_ltris); v.lxf = (const LightXf*)(base + o_lxf);
+    v.has_medium = s->media.empty() ? 0u : 1u;
+    v.medium_kind = 0;
+    v.sigma_a = v.sigma_s = 0.f;
+    v.medium_emission = 0.f;
+    v.medium_phase = 0.f;
+    for (int i = 0; i < 3; i++) v.medium_color[i] = v.medium_color_hi[i] = 0.f;
+    if (!s->media.empty()) {  // only media[0] is used (src/renderer.rs:190)
+        const HMedium& m = s->media[0];
+        v.medium_kind = uint32_t(m.kind);
+        v.sigma_a = float(m.absorption);
+        v.sigma_s = float(m.scattering);
+        const double pi = 3.14159265358979323846;
+        if (m.kind == RPT_MEDIUM_HOMOGENEOUS_ISOTROPIC) {  // src/medium.rs:80-96
+            D3 c = hex_color(0xD2B48C);
+            v.medium_color[0] = v.medium_color_hi[0] = float(c.x);
+            v.medium_color[1] = v.medium_color_hi[1] = float(c.y);
+            v.medium_color[2] = v.medium_color_hi[2] = float(c.z);
+            v.medium_emission = 0.f;
+            v.medium_phase = float(1.0 / (4.0 * pi));
+        } else {  // colored_glowing_fog, src/medium.rs:99-122 (phase `1.0 / 4.0 * pi`, sic)
+            D3 lo = hex_color(0x0000FF), hi = hex_color(0xFF0000);
+            v.medium_color[0] = float(lo.x); v.medium_color[1] = float(lo.y); v.medium_color[2] = float(lo.z);
+            v.medium_color_hi[0] = float(hi.x); v.medium_color_hi[1] = float(hi.y); v.medium_color_hi[2] = float(hi.z);
+            v.medium_emission = 10.f;
+            v.medium_phase = float(1.0 / 4.0 * pi);
+        }
+    }
+    for (int i = 0; i < 3; i++) v.env[i] = float(s->env[i]);
+    s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size();
+
+    HIP_TRY(hipMalloc((void**)&s->d_queue, 256));
+    HIP_TRY(hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)));
+    s->device = device;
+    s->committed = true;
+    return RPT_OK;
+}
+
+// ---------------------------------------------------------------------------- render
+static int prepare_render(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
+                          uint64_t seed, uint32_t sample_offset, RenderArgs& a) {
+    if (!s || !cam || !prm) return fail(RPT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RPT_ERR_STATE, "rpt_scene_commit must be called before rendering");
+    if (prm->width == 0 || prm->height == 0 || iterations == 0) return fail(RPT_ERR_INVALID, "empty render");
+    if (uint64_t(prm->width) * prm->height > (1ull << 31)) return fail(RPT_ERR_INVALID, "image too large");
+    uint32_t shard_count = prm->shard_count == 0 ? 1 : prm->shard_count;
+    if (prm->shard_rank >= shard_count) return fail(RPT_ERR_INVALID, "shard_rank >= shard_count");
+    HIP_TRY(hipSetDevice(s->device));
+
+    a.sc = s->view;
+    // Camera::cast_ray constants (src/camera.rs:66-69), fp64 then rounded once
+    D3 dir = d3(cam->direction), up = d3(cam->up);
+    double dd = 1.0 / std::tan(cam->fov / 2.0);
+    D3 right = normalize(cross(dir, up));
+    for (int i = 0; i < 3; i++) {
+        a.cam.eye[i] = float(cam->eye[i]);
+        a.cam.ddir[i] = float(dd * cam->direction[i]);
+        a.cam.right[i] = float((&right.x)[i]);
+        a.cam.up[i] = float(cam->up[i]);
+    }
+    a.cam.aperture = float(cam->aperture);
+    a.cam.focal_distance = float(cam->focal_distance);
+    a.width = prm->width;
+    a.height = prm->height;
+    a.inv_dim = float(1.0 / double(std::max(prm->width, prm->height)));
+    a.max_bounces = prm->max_bounces;
+    a.iterations = iterations;
+    a.sample_offset = sample_offset;
+    a.chunk_spp = uint32_t(std::min<int64_t>(g_opt_chunk_spp, iterations));
+    a.n_chunks = (iterations + a.chunk_spp - 1) / a.chunk_spp;
+    a.seed_mixed = seed_mix(seed);
+
+    // owned tiles
+    uint32_t tiles_x = (prm->width + 31) / 32, tiles_y = (prm->height + 31) / 32;
+    if (s->tk_w != prm->width || s->tk_h != prm->height || s->tk_rank != prm->shard_rank || s->tk_count != shard_count ||
+        !s->d_tiles) {
+        std::vector<uint32_t> tiles;
+        for (uint32_t ty = 0; ty < tiles_y; ty++)
+            for (uint32_t tx = 0; tx < tiles_x; tx++)
+                if ((tx + ty) % shard_count == prm->shard_rank) tiles.push_back(ty * tiles_x + tx);
+        if (tiles.size() > s->tiles_cap) {
+            if (s->d_tiles) HIP_TRY(hipFree(s->d_tiles));
+            HIP_TRY(hipMalloc((void**)&s->d_tiles, std::max<size_t>(tiles.size(), 1) * 4));
+            s->tiles_cap = tiles.size();
+        }
+        if (!tiles.empty()) HIP_TRY(hipMemcpy(s->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+        s->tk_w = prm->width; s->tk_h = prm->height; s->tk_rank = prm->shard_rank; s->tk_count = shard_count;
+        s->n_tiles = uint32_t(tiles.size());
+        s->tiles_x = tiles_x;
+    }
+    a.tiles = s->d_tiles;
+    a.n_tiles = s->n_tiles;
+    a.tiles_x = s->tiles_x;
+    a.n_owned = a.n_tiles * 1024u;
+    uint64_t n_items = uint64_t(a.n_owned) * a.n_chunks;
+    if (n_items >= (1ull << 32) - (1ull << 24)) return fail(RPT_ERR_INVALID, "too many work items; raise chunk_spp");
+    a.n_items = uint32_t(n_items);
+    size_t slab_bytes = std::max<size_t>(size_t(n_items) * 16, 16);
+    if (slab_bytes > s->slab_cap) {
+        if (s->d_slab) HIP_TRY(hipFree(s->d_slab));
+        HIP_TRY(hipMalloc((void**)&s->d_slab, slab_bytes));
+        s->slab_cap = slab_bytes;
+    }
+    a.slab = s->d_slab;
+    a.queue = s->d_queue;
+    a.counters = g_opt_counters ? s->d_counters : nullptr;
+    a.lds_stack = s->view.n_mesh ? 1u : 0u;
+    return RPT_OK;
+}
+
+static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(a.queue, 0, 4, st));
+    if (a.counters) HIP_TRY(hipMemsetAsync(a.counters, 0, 64, st));
+    uint32_t shard_count = prm->shard_count == 0 ? 1 : prm->shard_count;
+    if (shard_count > 1) HIP_TRY(hipMemsetAsync(d_out, 0, size_t(prm->width) * prm->height * 24, st));
+    if (a.n_items) {
+        int bpc = int(g_opt_blocks_per_cu);
+        if (bpc <= 0) {
+            HIP_TRY(render_occupancy(a.sc.has_medium != 0, a.sc.n_mesh != 0, &bpc));
+            if (bpc < 1) bpc = 1;
+        }
+        uint64_t want = (uint64_t(a.n_items) + 255) / 256;
+        int n_blocks = int(std::min<uint64_t>(uint64_t(s->n_cus) * bpc, want));
+        HIP_TRY(launch_render(a, n_blocks, st));
+        HIP_TRY(launch_resolve(a, std::pow(2.0, prm->exposure_value), d_out, st));
+    }
+    return RPT_OK;
+}
+static int fetch_counters(rpt_scene* s, const RenderArgs& a) {
+    std::memset(s->last_counters, 0, sizeof(s->last_counters));
+    if (a.counters) {
+        HIP_TRY(hipMemcpy(s->last_counters, a.counters, 64, hipMemcpyDeviceToHost));
+        s->last_counters[4] = s->last_counters[1] * s->prims_per_ray;
+    }
+    return RPT_OK;
+}
+
+int rpt_render_sample_device(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
+                             uint64_t seed, uint32_t sample_offset, void* d_out_rgb, void* hip_stream) {
+    if (!d_out_rgb) return fail(RPT_ERR_INVALID, "null output");
+    RenderArgs a{};
+    int rc = prepare_render(s, cam, prm, iterations, seed, sample_offset, a);
+    if (rc) return rc;
+    rc = run_render(s, prm, a, static_cast<double*>(d_out_rgb), static_cast<hipStream_t>(hip_stream));
+    if (rc) return rc;
+    if (a.counters) {
+        HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+        return fetch_counters(s, a);
+    }
+    return RPT_OK;
+}
+
+int rpt_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
+                      uint64_t seed, uint32_t sample_offset, double* out_rgb) {
+    if (!out_rgb) return fail(RPT_ERR_INVALID, "null output");
+    RenderArgs a{};
+    int rc = prepare_render(s, cam, prm, iterations, seed, sample_offset, a);
+    if (rc) return rc;
+    size_t bytes = size_t(prm->width) * prm->height * 24;
+    if (bytes > s->out_cap) {
+        if (s->d_out) HIP_TRY(hipFree(s->d_out));
+        HIP_TRY(hipMalloc((void**)&s->d_out, bytes));
+        s->out_cap = bytes;
+    }
+    rc = run_render(s, prm, a, s->d_out, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out_rgb, s->d_out, bytes, hipMemcpyDeviceToHost));
+    return fetch_counters(s, a);
+}
+
+int rpt_get_counters(rpt_scene* s, uint64_t out[8]) {
+    if (!s || !out) return fail(RPT_ERR_INVALID, "null argument");
+    std::memcpy(out, s->last_counters, 64);
+    return RPT_OK;
+}
+
+// ---------------------------------------------------------------------------- test hooks
+int rpt_intersect_batch(rpt_scene* s, uint64_t n, const float* origins, const float* dirs, float* t, int32_t* object,
+                        float* normal) {
+    if (!s || !origins || !dirs || !t || !object) return fail(RPT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RPT_ERR_STATE, "rpt_scene_commit must be called first");
+    if (n == 0) return RPT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    TmpDev tmp;
+    float *d_o, *d_d, *d_t, *d_n;
+    int32_t* d_obj;
+    HIP_TRY(tmp.alloc(&d_o, n * 3));
+    HIP_TRY(tmp.alloc(&d_d, n * 3));
+    HIP_TRY(tmp.alloc(&d_t, n));
+    HIP_TRY(tmp.alloc(&d_n, n * 3));
+    HIP_TRY(tmp.alloc(&d_obj, n));
+    HIP_TRY(hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, dirs, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(launch_intersect(s->view, n, d_o, d_d, d_t, d_obj, d_n, s->view.n_mesh != 0, nullptr));
+    HIP_TRY(hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(object, d_obj, n * 4, hipMemcpyDeviceToHost));
+    if (normal) HIP_TRY(hipMemcpy(normal, d_n, n * 12, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+
+int rpt_debug_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out) {
+    if (!out) return fail(RPT_ERR_INVALID, "null argument");
+    TmpDev tmp;
+    uint32_t* d;
+    HIP_TRY(tmp.alloc(&d, n));
+    HIP_TRY(launch_debug_rng(seed_mix(seed), pixel, sample, n, d, nullptr));
+    HIP_TRY(hipMemcpy(out, d, size_t(n) * 4, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+static Material to_gpu_material(const rpt_material* m) {
+    Material g;
+    g.albedo_emit = F4{float(m->albedo[0]), float(m->albedo[1]), float(m->albedo[2]), float(m->emittance)};
+    g.params = F4{bits_f(uint32_t(m->kind)), float(m->shininess), float(m->ior), 0.f};
+    return g;
+}
+int rpt_debug_material_sample_f(const rpt_material* m, uint64_t n, const float* normals, const float* wos, uint64_t seed,
+                                float* wi, float* pdf, int32_t* some) {
+    std::string why;
+    if (!check_material(m, why) || !normals || !wos || !wi || !pdf || !some) return fail(RPT_ERR_INVALID, "bad argument");
+    TmpDev tmp;
+    float *d_n, *d_wo, *d_wi, *d_pdf;
+    int32_t* d_some;
+    HIP_TRY(tmp.alloc(&d_n, n * 3));
+    HIP_TRY(tmp.alloc(&d_wo, n * 3));
+    HIP_TRY(tmp.alloc(&d_wi, n * 3));
+    HIP_TRY(tmp.alloc(&d_pdf, n));
+    HIP_TRY(tmp.alloc(&d_some, n));
+    HIP_TRY(hipMemcpy(d_n, normals, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_wo, wos, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(launch_debug_sample_f(to_gpu_material(m), n, d_n, d_wo, seed_mix(seed), d_wi, d_pdf, d_some, nullptr));
+    HIP_TRY(hipMemcpy(wi, d_wi, n * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf, d_pdf, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(some, d_some, n * 4, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+int rpt_debug_material_bsdf(const rpt_material* m, uint64_t n, const float* normals, const float* wos, const float* wis,
+                            float* out_rgb) {
+    std::string why;
+    if (!check_material(m, why) || !normals || !wos || !wis || !out_rgb) return fail(RPT_ERR_INVALID, "bad argument");
+    TmpDev tmp;
+    float *d_n, *d_wo, *d_wi, *d_out;
+    HIP_TRY(tmp.alloc(&d_n, n * 3));
+    HIP_TRY(tmp.alloc(&d_wo, n * 3));
+    HIP_TRY(tmp.alloc(&d_wi, n * 3));
+    HIP_TRY(tmp.alloc(&d_out, n * 3));
+    HIP_TRY(hipMemcpy(d_n, normals, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_wo, wos, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_wi, wis, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(launch_debug_bsdf(to_gpu_material(m), n, d_n, d_wo, d_wi, d_out, nullptr));
+    HIP_TRY(hipMemcpy(out_rgb, d_out, n * 12, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+int rpt_debug_camera_rays(const rpt_camera* cam, const rpt_render_params* prm, uint64_t seed, uint32_t sample,
+                          float* origins, float* dirs) {
+    if (!cam || !prm || !origins || !dirs) return fail(RPT_ERR_INVALID, "null argument");
+    CameraG c;
+    D3 dir = d3(cam->direction), up = d3(cam->up);
+    double dd = 1.0 / std::tan(cam->fov / 2.0);
+    D3 right = normalize(cross(dir, up));
+    for (int i = 0; i < 3; i++) {
+        c.eye[i] = float(cam->eye[i]);
+        c.ddir[i] = float(dd * cam->direction[i]);
+        c.right[i] = float((&right.x)[i]);
+        c.up[i] = float(cam->up[i]);
+    }
+    c.aperture = float(cam->aperture);
+    c.focal_distance = float(cam->focal_distance);
+    size_t n = size_t(prm->width) * prm->height;
+    TmpDev tmp;
+    float *d_o, *d_d;
+    HIP_TRY(tmp.alloc(&d_o, n * 3));
+    HIP_TRY(tmp.alloc(&d_d, n * 3));
+    HIP_TRY(launch_debug_camera(c, prm->width, prm->height, seed_mix(seed), sample, d_o, d_d, nullptr));
+    HIP_TRY(hipMemcpy(origins, d_o, n * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dirs, d_d, n * 12, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+
+}  // extern "C"
