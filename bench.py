@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3]
+
+One "step" = one pass of the hot path over the whole workload: Renderer::sample of the
+lampshade scene in fog (BASELINE config C3, examples/volumetric_pathtrace_lampshade.rs) at
+1024x1024 pixels x 256 paths per pixel, scene resident in HBM before the timed region.  With
+N > 1 (launched by torch.distributed.run, one rank per GPU) the 32x32 pixel tiles are sharded
+over the ranks and the frame is assembled on rank 0 with one RCCL sum-reduce per step; the
+total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def algorithmic_work(scene_counts, counters, samples):
+    """Per-sample algorithmic bytes/flops of the closest-hit queries.
+
+    bytes per ray over the flattened fp32 layout: 48 B per sphere / cube / triangle scan
+    record, 16 B per plane, 32 B per BVH node visited, 48 B per BVH triangle tested, 48 B of
+    shade record for the accepted hit; + 16 B/pixel-chunk of framebuffer traffic (negligible).
+    flops per ray follow SURVEY.md section 8d (the reference algorithm's operation counts):
+    56 per affine map, 30 per cube, 25 per sphere, 12 per plane, 75 per triangle, 20 per node.
+    """
+    rays = counters["rays"]
+    per_ray_bytes = 48 * (scene_counts["sph"] + scene_counts["cub"] + scene_counts["tri"]) + 16 * scene_counts["pln"] + 48
+    per_ray_flops = (56 + 25) * scene_counts["sph"] + (56 + 30) * scene_counts["cub"] + 12 * scene_counts["pln"] + \
+        75 * scene_counts["tri"]
+    total_bytes = rays * per_ray_bytes + 32 * counters["bvh_nodes"] + 48 * counters["bvh_tris"]
+    total_flops = rays * per_ray_flops + 20 * counters["bvh_nodes"] + 75 * counters["bvh_tris"] + 300 * counters["vertices"]
+    return total_bytes / samples, total_flops / samples, rays / samples
+
+
+def scene_counts(scene):
+    from rpt_amd.api import Cube, Mesh, Plane, Sphere
+    c = dict(sph=0, cub=0, pln=0, tri=0, bvh_tri=0)
+    for o in scene.objects:
+        b = o.shape.base()
+        if isinstance(b, Sphere):
+            c["sph"] += 1
+        elif isinstance(b, Cube):
+            c["cub"] += 1
+        elif isinstance(b, Plane):
+            c["pln"] += 1
+        elif isinstance(b, Mesh):
+            n = b.tris.shape[0]
+            if n <= 32:
+                c["tri"] += n
+            else:
+                c["bvh_tri"] += n
+    return c
+
+
+def cpu_baseline(scene, cam, cfg, width, height, target_seconds=15.0):
+    """The fp64 oracle (C++ restatement of rpt's CPU algorithm, literal reference semantics,
+    one task per image row like the rayon loop) on all host cores, on a bounded sample."""
+    from oracle.pyoracle import OracleScene
+    osc = OracleScene(scene)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    osc.render(cam, width, height, 1, cfg["max_bounces"], seed=0, threads=cores)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(32, target_seconds / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    osc.render(cam, width, height, spp, cfg["max_bounces"], seed=0, threads=cores)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(width * height * spp / dt / 1e6, 4),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{width}x{height}x{spp}spp of the same scene (fp64 C++ restatement of rpt's CPU algorithm, "
+                  f"{dt:.1f} s, {cores} threads)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # before the HIP library: one shared HIP runtime (rpt_amd/_lib.py)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    import rpt_amd
+    from rpt_amd import Renderer, scenes
+
+    scene, cam, cfg = scenes.CONFIGS[args.workload]()
+    width = args.width or cfg["width"]
+    height = args.height or cfg["height"]
+    spp = args.spp or cfg["spp"]
+    r = Renderer(scene, cam).width(width).height(height).max_bounces(cfg["max_bounces"]).seed(0)
+    r.device(local_rank).shard(rank, world)
+    d_out = torch.zeros(width * height * 3, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    rpt_amd.set_option("timing", 1)
+
+    kernel_ms = []
+
+    def step(record=False):
+        r._sample_offset = 0
+        r.sample_device(spp, d_out.data_ptr(), stream)
+        if dist is not None:
+            dist.reduce(d_out, dst=0, op=dist.ReduceOp.SUM)
+        if record:
+            kernel_ms.append(r.timing()[0])   # waits for this step's events only
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(record=True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    grid_blocks = r.timing()[2]
+
+    # one extra, untimed pass with device counters on (rank-local work) for the roofline figures
+    rpt_amd.set_option("counters", 1)
+    rpt_amd.set_option("timing", 0)
+    r._sample_offset = 0
+    cspp = min(spp, 16)
+    r.sample_device(cspp, d_out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    cnt = r.counters()
+    rpt_amd.set_option("counters", 0)
+
+    if rank == 0:
+        samples_per_step = width * height * spp
+        ms_per_step = elapsed / args.steps * 1e3
+        value = samples_per_step * args.steps / elapsed / 1e6
+        sc = scene_counts(scene)
+        bytes_ps, flops_ps, rays_ps = algorithmic_work(sc, cnt, max(cnt["samples"], 1))
+        k_ms = float(np.mean(kernel_ms))
+        local_samples = samples_per_step / world          # tiles are sharded evenly over ranks
+        ach_gbs = bytes_ps * local_samples / (k_ms * 1e-3) / 1e9
+        ach_tflops = flops_ps * local_samples / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Msamples/sec",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "wall_clock_s": round(ms_per_step / 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload} lampshade-in-fog path trace {width}x{height}x{spp}spp"
+                       if args.workload == "C3" else f"{args.workload} {width}x{height}x{spp}spp",
+                       "scene": "examples/volumetric_pathtrace_lampshade.rs" if args.workload == "C3" else args.workload,
+                       "parallelism": f"tile-shard x{world}", "rays_per_sample": round(rays_ps, 3),
+                       "Mrays_per_s": round(value * rays_ps, 1)},
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(ach_gbs, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(ach_gbs / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "rptg::render_kernel",
+                "kernel_ms": round(k_ms, 3),
+                "grid_blocks": grid_blocks,
+                "algorithmic_bytes_per_sample": round(bytes_ps, 1),
+                "note": "scene records are wave-uniform and served from the scalar cache, not HBM: the binding "
+                        "resource is fp32 VALU issue, see `valu` and DESIGN.md section 5",
+                "valu": {"achieved": round(ach_tflops, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach_tflops / FP32_PEAK_TFLOPS, 4),
+                         "algorithmic_flops_per_sample": round(flops_ps, 1)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, cam, cfg, width, height)
+            out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

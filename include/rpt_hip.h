@@ -127,8 +127,12 @@ int rpt_intersect_batch(rpt_scene*, uint64_t n, const float* origins, const floa
  * [6] BVH triangle tests.  Filled only when the library is built with RPT_COUNTERS or
  * rpt_set_option("counters", 1) was called before the render; otherwise zeros. */
 int rpt_get_counters(rpt_scene*, uint64_t out[8]);
+/* HIP-event timing of the last render on this scene (needs rpt_set_option("timing", 1)):
+ * milliseconds of the megakernel and of the resolve kernel on the stream they ran on, and the
+ * persistent grid size.  Synchronises on the last recorded event. */
+int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* grid_blocks);
 /* Runtime options (all optional): "counters" 0/1, "chunk_spp" (samples per work item),
- * "blocks_per_cu" (persistent grid size), returns RPT_ERR_INVALID for unknown names. */
+ * "blocks_per_cu" (persistent grid size), "timing" 0/1; returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 
 /* ---- device self-test hooks (each runs the device function in a one-block kernel) ---- */

@@ -21,7 +21,13 @@ import numpy as np
 from . import _lib
 from ._lib import RptError
 
+def set_option(name, value):
+    """rpt_set_option: "counters", "timing", "chunk_spp", "blocks_per_cu"."""
+    _lib.check(_lib.load().rpt_set_option(name.encode(), int(value)))
+
+
 __all__ = [
+    "set_option",
     "vec3", "hex_color", "color_bytes", "Sphere", "Cube", "Plane", "Triangle", "Mesh", "Transformed",
     "sphere", "cube", "plane", "polygon", "Material", "Object", "Light", "Medium", "Environment",
     "Scene", "Camera", "Filter", "Buffer", "Renderer", "RptError",
@@ -650,6 +656,12 @@ class Renderer:
             self.sample(steps, buffer)
             iteration += steps
             callback(iteration, buffer)
+
+    def timing(self):
+        """(render_ms, resolve_ms, grid_blocks) of the last call, from HIP events on its stream."""
+        a, b, g = C.c_double(), C.c_double(), C.c_int32()
+        _lib.check(_lib.load().rpt_get_timing(self.scene._handle, C.byref(a), C.byref(b), C.byref(g)))
+        return a.value, b.value, g.value
 
     def counters(self):
         out = (C.c_uint64 * 8)()

@@ -31,6 +31,7 @@ static int fail(int code, const std::string& msg) {
 static int64_t g_opt_counters = 0;
 static int64_t g_opt_chunk_spp = 32;
 static int64_t g_opt_blocks_per_cu = 0;  // 0 = occupancy query
+static int64_t g_opt_timing = 0;
 
 // ---------------------------------------------------------------------------- fp64 helpers
 namespace {
@@ -300,6 +301,9 @@ struct rpt_scene {
     double* d_out = nullptr;
     size_t out_cap = 0;  // bytes
     uint64_t last_counters[8] = {0};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // before render, after render, after resolve
+    bool ev_valid = false;
+    int last_blocks = 0;
     uint64_t prims_per_ray = 0;
     // tile cache key
     uint32_t tk_w = 0, tk_h = 0, tk_rank = 0, tk_count = 0, n_tiles = 0, tiles_x = 0;
@@ -356,6 +360,7 @@ int rpt_set_option(const char* name, int64_t value) {
     if (s == "counters") g_opt_counters = value;
     else if (s == "chunk_spp") { if (value < 1) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 1"); g_opt_chunk_spp = value; }
     else if (s == "blocks_per_cu") g_opt_blocks_per_cu = value;
+    else if (s == "timing") g_opt_timing = value;
     else return fail(RPT_ERR_INVALID, "unknown option " + s);
     return RPT_OK;
 }
@@ -372,6 +377,8 @@ void rpt_scene_destroy(rpt_scene* s) {
         (void)hipFree(s->d_queue);
         (void)hipFree(s->d_counters);
         (void)hipFree(s->d_out);
+        for (auto& e : s->ev)
+            if (e) (void)hipEventDestroy(e);
     }
     delete s;
 }
@@ -797,8 +804,19 @@ static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderAr
         }
         uint64_t want = (uint64_t(a.n_items) + 255) / 256;
         int n_blocks = int(std::min<uint64_t>(uint64_t(s->n_cus) * bpc, want));
+        s->last_blocks = n_blocks;
+        if (g_opt_timing) {
+            for (auto& e : s->ev)
+                if (!e) HIP_TRY(hipEventCreate(&e));
+            HIP_TRY(hipEventRecord(s->ev[0], st));
+        }
         HIP_TRY(launch_render(a, n_blocks, st));
+        if (g_opt_timing) HIP_TRY(hipEventRecord(s->ev[1], st));
         HIP_TRY(launch_resolve(a, std::pow(2.0, prm->exposure_value), d_out, st));
+        if (g_opt_timing) {
+            HIP_TRY(hipEventRecord(s->ev[2], st));
+            s->ev_valid = true;
+        }
     }
     return RPT_OK;
 }
@@ -842,6 +860,19 @@ int rpt_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_para
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out_rgb, s->d_out, bytes, hipMemcpyDeviceToHost));
     return fetch_counters(s, a);
+}
+
+int rpt_get_timing(rpt_scene* s, double* render_ms, double* resolve_ms, int32_t* grid_blocks) {
+    if (!s) return fail(RPT_ERR_INVALID, "null scene");
+    if (!s->ev_valid) return fail(RPT_ERR_STATE, "no timed render: rpt_set_option(\"timing\", 1) first");
+    HIP_TRY(hipEventSynchronize(s->ev[2]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+    if (render_ms) *render_ms = a;
+    if (resolve_ms) *resolve_ms = b;
+    if (grid_blocks) *grid_blocks = s->last_blocks;
+    return RPT_OK;
 }
 
 int rpt_get_counters(rpt_scene* s, uint64_t out[8]) {

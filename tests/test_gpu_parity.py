@@ -37,7 +37,11 @@ def test_closest_hit_matches_oracle(name, center, radius):
     # the oracle is given the fp32-rounded rays so both trace the same input
     te, obje, nrme = _oracle(scene).intersect(o.astype(np.float32), d.astype(np.float32), robust=1)
     same = obj == obje
-    assert same.mean() > 0.9995          # silhouette / edge rays may flip in fp32
+    # Coincident surfaces (the Cornell box stands exactly on the floor) are decided by rounding in
+    # fp64 and fp32 alike: a different object at the same distance is not a mismatch.
+    both = (obj >= 0) & (obje >= 0)
+    coincident = both & ~same & (np.abs(t - te) <= 2e-4 * np.abs(te))
+    assert (same | coincident).mean() > 0.9995          # silhouette / edge rays may flip in fp32
     hit = same & (obje >= 0)
     assert hit.sum() > 5000
     assert np.max(np.abs(t[hit] - te[hit]) / te[hit]) < 2e-4
