@@ -84,6 +84,11 @@ typedef struct rpt_render_params {
 } rpt_render_params;
 
 int rpt_device_count(void);
+/* Tile ownership used by the renderer (pure host function): writes the ids (ty * tiles_x + tx,
+ * tiles_x = ceil(width/32)) of the 32x32 tiles owned by shard_rank, in render order, and returns
+ * their number (or a negative error).  tiles_out may be NULL to query the count. */
+int64_t rpt_shard_tiles(uint32_t width, uint32_t height, uint32_t shard_rank, uint32_t shard_count,
+                        uint32_t* tiles_out, uint64_t capacity);
 const char* rpt_last_error(void);
 
 rpt_scene* rpt_scene_create(void);                 /* Scene::new()            src/scene.rs:26-31 */

@@ -8,7 +8,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librpt_hip.so")
+LIB_PATH = os.environ.get("RPT_LIB", os.path.join(_HERE, "librpt_hip.so"))  # RPT_LIB: A/B builds
 
 
 class RptError(RuntimeError):
@@ -66,6 +66,7 @@ _D3 = C.POINTER(C.c_double)
 SYMBOLS = [
     ("rpt_device_count", C.c_int, []),
     ("rpt_last_error", C.c_char_p, []),
+    ("rpt_shard_tiles", C.c_int64, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_uint64]),
     ("rpt_scene_create", _P, []),
     ("rpt_scene_destroy", None, [_P]),
     ("rpt_scene_add_object", C.c_int, [_P, C.POINTER(ShapeDesc), C.POINTER(MaterialDesc)]),

@@ -21,13 +21,31 @@ import numpy as np
 from . import _lib
 from ._lib import RptError
 
+def shard_pixels(width, height, rank, count):
+    """Pixel indices (y*width + x) owned by `rank` of `count` under the renderer's 32x32-tile
+    sharding (rpt_shard_tiles), in ascending order."""
+    lib = _lib.load()
+    n = _lib.check(lib.rpt_shard_tiles(width, height, rank, count, None, 0))
+    tiles = np.zeros(max(n, 1), dtype=np.uint32)
+    _lib.check(lib.rpt_shard_tiles(width, height, rank, count, tiles.ctypes.data_as(C.c_void_p), n))
+    tiles_x = (width + 31) // 32
+    ys, xs = np.mgrid[0:32, 0:32]
+    out = []
+    for t in tiles[:n]:
+        x = (int(t) % tiles_x) * 32 + xs
+        y = (int(t) // tiles_x) * 32 + ys
+        m = (x < width) & (y < height)
+        out.append((y[m] * width + x[m]).astype(np.uint32))
+    return np.sort(np.concatenate(out)) if out else np.zeros(0, dtype=np.uint32)
+
+
 def set_option(name, value):
     """rpt_set_option: "counters", "timing", "chunk_spp", "blocks_per_cu"."""
     _lib.check(_lib.load().rpt_set_option(name.encode(), int(value)))
 
 
 __all__ = [
-    "set_option",
+    "set_option", "shard_pixels",
     "vec3", "hex_color", "color_bytes", "Sphere", "Cube", "Plane", "Triangle", "Mesh", "Transformed",
     "sphere", "cube", "plane", "polygon", "Material", "Object", "Light", "Medium", "Environment",
     "Scene", "Camera", "Filter", "Buffer", "Renderer", "RptError",

@@ -40,6 +40,24 @@ RPT_DEV float dot3w(const F4& r, V p) { return fmaf(r.x, p.x, fmaf(r.y, p.y, fma
 RPT_DEV float dot3(const F4& r, V p) { return fmaf(r.x, p.x, fmaf(r.y, p.y, r.z * p.z)); }
 RPT_DEV bool is_zero(V a) { return a.x == 0.f && a.y == 0.f && a.z == 0.f; }
 
+// Wave-uniform read of a 16-byte-multiple scene record through the constant address space, so
+// hipcc emits scalar loads (s_load_dwordx4/x8 into SGPRs).  A plain load through the generic
+// pointer is emitted as a per-lane global_load (12 VGPRs per 48-byte record) because the kernel
+// also stores to global memory and the compiler cannot prove the record is never clobbered.
+// Only valid when `p` is the same in every lane.
+template <class T>
+RPT_DEV T uload(const T* p) {
+    static_assert(sizeof(T) % 16 == 0, "scene records are 16-byte multiples");
+    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) u4v* CP;
+    CP q = (CP)(uintptr_t)p;
+    T out;
+    u4v* o = reinterpret_cast<u4v*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) o[i] = q[i];
+    return out;
+}
+
 // ------------------------------------------------------------------ RNG
 // xoshiro128+ seeded through splitmix64 from (seed, pixel, sample); bit-identical to the
 // oracle's Rng.  Replaces StdRng::from_entropy() per row (src/renderer.rs:163).
@@ -203,14 +221,14 @@ template <bool BVH, bool COUNT>
 RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code,
                          uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
     for (uint32_t i = 0; i < sc.n_sph; i++) {
-        const XfScan x = sc.sph[i];
+        const XfScan x = uload(&sc.sph[i]);
         V ol, dl;
         to_local(x, o, d, ol, dl);
         float t = hit_sphere(ol, dl, tmin);
         if (t >= 0.f && t < tbest) { tbest = t; code = (K_SPHERE << 28) | i; }
     }
     for (uint32_t i = 0; i < sc.n_cub; i++) {
-        const XfScan x = sc.cub[i];
+        const XfScan x = uload(&sc.cub[i]);
         V ol, dl;
         to_local(x, o, d, ol, dl);
         uint32_t f;
@@ -218,18 +236,18 @@ RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest
         if (t >= 0.f && t < tbest) { tbest = t; code = (K_CUBE << 28) | i; }
     }
     for (uint32_t i = 0; i < sc.n_pln; i++) {
-        const F4 nv = sc.pln[i].nv;
+        const F4 nv = uload(&sc.pln[i]).nv;
         float t = hit_plane(nv, o, d, tmin);
         if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
     }
     for (uint32_t i = 0; i < sc.n_tri; i++) {
-        const TriScan tr = sc.tri[i];
+        const TriScan tr = uload(&sc.tri[i]);
         float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
         if (t >= 0.f) { tbest = t; code = (K_TRI << 28) | i; }
     }
     if (BVH) {
         for (uint32_t i = 0; i < sc.n_mesh; i++) {
-            const MeshRef m = sc.meshes[i];
+            const MeshRef m = uload(&sc.meshes[i]);
             bvh_traverse<COUNT>(sc, m, o, d, tmin, tbest, code, stk, stride, c_nodes, c_tris);
         }
     }

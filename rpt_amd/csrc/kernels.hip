@@ -46,8 +46,11 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
     y = ty * 32u + (sb >> 2) * 8u + (l >> 3);
 }
 
+#ifndef RPT_MIN_WAVES
+#define RPT_MIN_WAVES 1
+#endif
 template <bool MEDIUM, bool BVH, bool COUNT>
-__global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
     extern __shared__ uint32_t dyn_lds[];
     const SceneView& sc = a.sc;
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a) {
         // ---- next-event estimation: sample_lights / sample_lights_for_media
         //      (src/renderer.rs:362-409 / 325-359); lights in scene order fix the draw order.
         for (uint32_t li = 0; li < sc.n_lights; li++) {
-            const Light L = sc.lights[li];
+            const Light L = uload(&sc.lights[li]);
             if (L.kind == L_AMBIENT) {
                 E = fma3(xyz(L.color), ev_medium ? mcol : mat_color(mat), E);
             } else if (L.kind == L_OBJECT) {

@@ -720,6 +720,22 @@ int rpt_scene_commit(rpt_scene* s, int device) {
 }
 
 // ---------------------------------------------------------------------------- render
+// Tile ownership (host only, no HIP call): 32x32 tiles, tile (tx,ty) belongs to rank (tx+ty) % count.
+extern "C" int64_t rpt_shard_tiles(uint32_t width, uint32_t height, uint32_t shard_rank, uint32_t shard_count,
+                                   uint32_t* tiles_out, uint64_t capacity) {
+    if (shard_count == 0) shard_count = 1;
+    if (width == 0 || height == 0 || shard_rank >= shard_count) return fail(RPT_ERR_INVALID, "bad shard arguments");
+    uint32_t tiles_x = (width + 31) / 32, tiles_y = (height + 31) / 32;
+    int64_t n = 0;
+    for (uint32_t ty = 0; ty < tiles_y; ty++)
+        for (uint32_t tx = 0; tx < tiles_x; tx++)
+            if ((tx + ty) % shard_count == shard_rank) {
+                if (tiles_out && uint64_t(n) < capacity) tiles_out[n] = ty * tiles_x + tx;
+                n++;
+            }
+    return n;
+}
+
 static int prepare_render(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
                           uint64_t seed, uint32_t sample_offset, RenderArgs& a) {
     if (!s || !cam || !prm) return fail(RPT_ERR_INVALID, "null argument");
@@ -755,12 +771,12 @@ static int prepare_render(rpt_scene* s, const rpt_camera* cam, const rpt_render_
 
     // owned tiles
     uint32_t tiles_x = (prm->width + 31) / 32, tiles_y = (prm->height + 31) / 32;
+    (void)tiles_y;
     if (s->tk_w != prm->width || s->tk_h != prm->height || s->tk_rank != prm->shard_rank || s->tk_count != shard_count ||
         !s->d_tiles) {
-        std::vector<uint32_t> tiles;
-        for (uint32_t ty = 0; ty < tiles_y; ty++)
-            for (uint32_t tx = 0; tx < tiles_x; tx++)
-                if ((tx + ty) % shard_count == prm->shard_rank) tiles.push_back(ty * tiles_x + tx);
+        std::vector<uint32_t> tiles(size_t(tiles_x) * tiles_y);
+        tiles.resize(size_t(rpt_shard_tiles(prm->width, prm->height, prm->shard_rank, shard_count, tiles.data(),
+                                            tiles.size())));
         if (tiles.size() > s->tiles_cap) {
             if (s->d_tiles) HIP_TRY(hipFree(s->d_tiles));
             HIP_TRY(hipMalloc((void**)&s->d_tiles, std::max<size_t>(tiles.size(), 1) * 4));
