@@ -1,0 +1,453 @@
+// rpt.hpp — header-only C++17 mirror of rpt's builder API over the C ABI of rpt_hip.h.
+//
+// rpt is a Rust crate; no Rust toolchain exists in this environment, so the host layer above the
+// C ABI is C++ with the reference's names, argument meaning and builder style (methods take the
+// object by value and return it, as `fn width(mut self, ..) -> Self` does).  Reference lines:
+//   Scene/SceneAdd scene.rs:12-81   Object object.rs:10-31   Light light.rs:7-19
+//   Material material.rs:8-97       Medium medium.rs:78-122  Camera camera.rs:9-62
+//   shapes shape.rs:102-314         Renderer renderer.rs:23-156   Buffer/Filter buffer.rs:6-108
+//   hex_color/color_bytes color.rs:10-24
+// Errors: where the reference panics (assert!/expect/unimplemented!), this layer throws rpt::Error.
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rpt_hip.h"
+
+namespace rpt {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+inline void check(int rc) {
+    if (rc < 0) throw Error(std::string("rpt error ") + std::to_string(rc) + ": " + rpt_last_error());
+}
+
+using Vec3 = std::array<double, 3>;
+using Color = Vec3;
+inline Vec3 vec3(double x, double y, double z) { return {x, y, z}; }
+inline Vec3 operator+(Vec3 a, Vec3 b) { return {a[0] + b[0], a[1] + b[1], a[2] + b[2]}; }
+inline Vec3 operator-(Vec3 a, Vec3 b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+inline Vec3 operator*(double s, Vec3 a) { return {s * a[0], s * a[1], s * a[2]}; }
+inline double dot(Vec3 a, Vec3 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline Vec3 cross(Vec3 a, Vec3 b) {
+    return {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+}
+inline Vec3 normalize(Vec3 a) {
+    double l = std::sqrt(dot(a, a));
+    return {a[0] / l, a[1] / l, a[2] / l};
+}
+
+// ---- color.rs
+inline Color hex_color(uint32_t x) {
+    auto ch = [](uint32_t c) { return std::pow(double(c) / 255.0, 2.2); };
+    return {ch((x >> 16) & 0xff), ch((x >> 8) & 0xff), ch(x & 0xff)};
+}
+inline std::array<uint8_t, 3> color_bytes(const Color& c) {
+    std::array<uint8_t, 3> o{};
+    for (int i = 0; i < 3; i++) {
+        double t = std::pow(std::fmin(std::fmax(c[i], 0.0), 1.0), 1.0 / 2.2) * 255.0;
+        o[i] = (t != t || t <= 0.0) ? 0 : (t >= 255.0 ? 255 : uint8_t(t));  // `as u8`: truncating, saturating
+    }
+    return o;
+}
+
+// ---- 4x4 row-major matrices (glm::translate / scale / rotate of the identity)
+struct Mat4 {
+    std::array<double, 16> m{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    Mat4 operator*(const Mat4& o) const {
+        Mat4 r;
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                double s = 0;
+                for (int k = 0; k < 4; k++) s += m[i * 4 + k] * o.m[k * 4 + j];
+                r.m[i * 4 + j] = s;
+            }
+        return r;
+    }
+    static Mat4 translation(Vec3 v) {
+        Mat4 r;
+        r.m[3] = v[0]; r.m[7] = v[1]; r.m[11] = v[2];
+        return r;
+    }
+    static Mat4 scaling(Vec3 v) {
+        Mat4 r;
+        r.m[0] = v[0]; r.m[5] = v[1]; r.m[10] = v[2];
+        return r;
+    }
+    static Mat4 rotation(double angle, Vec3 axis) {
+        Vec3 a = normalize(axis);
+        double c = std::cos(angle), s = std::sin(angle), x = a[0], y = a[1], z = a[2];
+        Mat4 r;
+        r.m = {c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s, 0,
+               y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s, 0,
+               z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c), 0,
+               0, 0, 0, 1};
+        return r;
+    }
+};
+
+// ---- shapes (shape.rs, shape/*.rs).  One value type covers Sphere / Cube / Plane / Mesh and
+//      `Transformed<T>`; chained transforms left-multiply and never nest (shape.rs:232-285).
+struct Triangle {
+    Vec3 v1, v2, v3, n1, n2, n3;
+    static Triangle from_vertices(Vec3 a, Vec3 b, Vec3 c) {
+        Vec3 n = normalize(cross(b - a, c - a));
+        return {a, b, c, n, n, n};
+    }
+};
+class Shape {
+  public:
+    int kind = RPT_SHAPE_SPHERE;
+    bool has_transform = false;
+    Mat4 matrix;
+    Vec3 plane_normal{0, 0, 0};
+    double plane_value = 0;
+    std::vector<double> tris;  // 18 doubles per triangle
+
+    Shape translate(Vec3 v) const { return wrap(Mat4::translation(v)); }
+    Shape scale(Vec3 v) const { return wrap(Mat4::scaling(v)); }
+    Shape rotate(double angle, Vec3 axis) const { return wrap(Mat4::rotation(angle, axis)); }
+    Shape rotate_x(double a) const { return wrap(Mat4::rotation(a, {1, 0, 0})); }
+    Shape rotate_y(double a) const { return wrap(Mat4::rotation(a, {0, 1, 0})); }
+    Shape rotate_z(double a) const { return wrap(Mat4::rotation(a, {0, 0, 1})); }
+    Shape transform(const Mat4& t) const { return wrap(t); }
+
+    rpt_shape_desc desc() const {
+        rpt_shape_desc d{};
+        d.kind = kind;
+        d.has_transform = has_transform ? 1 : 0;
+        for (int i = 0; i < 16; i++) d.transform[i] = matrix.m[i];
+        for (int i = 0; i < 3; i++) d.plane_normal[i] = plane_normal[i];
+        d.plane_value = plane_value;
+        d.tris = tris.empty() ? nullptr : tris.data();
+        d.n_tris = tris.size() / 18;
+        return d;
+    }
+
+  private:
+    Shape wrap(const Mat4& t) const {
+        Shape s = *this;
+        s.matrix = has_transform ? t * matrix : t;
+        s.has_transform = true;
+        return s;
+    }
+};
+using Mesh = Shape;  // `Mesh = KdTree<Triangle>` (shape/mesh.rs:103); the accelerator is built in the library
+inline Shape sphere() { return Shape{}; }
+inline Shape cube() {
+    Shape s;
+    s.kind = RPT_SHAPE_CUBE;
+    return s;
+}
+inline Shape plane(Vec3 normal, double value) {
+    Shape s;
+    s.kind = RPT_SHAPE_PLANE;
+    s.plane_normal = normal;
+    s.plane_value = value;
+    return s;
+}
+inline Shape mesh(const std::vector<Triangle>& ts) {  // Mesh::new
+    Shape s;
+    s.kind = RPT_SHAPE_MESH;
+    for (const Triangle& t : ts)
+        for (const Vec3* v : {&t.v1, &t.v2, &t.v3, &t.n1, &t.n2, &t.n3})
+            for (double c : *v) s.tris.push_back(c);
+    return s;
+}
+inline Shape polygon(const std::vector<Vec3>& verts) {  // shape.rs:308-314
+    std::vector<Triangle> ts;
+    for (size_t i = 1; i + 1 < verts.size(); i++) ts.push_back(Triangle::from_vertices(verts[0], verts[i], verts[i + 1]));
+    return mesh(ts);
+}
+
+// ---- material.rs
+struct Material {
+    int kind = RPT_MAT_LAMBERTIAN;
+    Color albedo{0.5, 0.5, 0.5};
+    double emittance_ = 0, shininess = 0, ior = 1;
+    static Material diffuse(Color c) { return {RPT_MAT_LAMBERTIAN, c, 0, 0, 1}; }
+    static Material specular(Color c, double roughness) { return {RPT_MAT_PHONG, c, 0, roughness, 1}; }
+    static Material metallic(Color c, double roughness) { return {RPT_MAT_PHONG, c, 0, roughness, 1}; }
+    static Material mirror() { return {RPT_MAT_MIRROR, {0, 0, 0}, 0, 0, 1}; }
+    static Material transmissive(double ior) { return {RPT_MAT_TRANSMISSIVE, {0, 0, 0}, 0, 0, ior}; }
+    static Material clear(double index, double /*roughness*/) { return {RPT_MAT_TRANSMISSIVE, {0, 0, 0}, 0, 0, index}; }
+    static Material transparent(Color c, double index, double /*roughness*/) { return {RPT_MAT_TRANSMISSIVE, c, 0, 0, index}; }
+    static Material light(Color c, double emittance) { return {RPT_MAT_LAMBERTIAN, c, emittance, 0, 1}; }
+    double emittance() const { return kind <= RPT_MAT_PHONG ? emittance_ : 0.0; }
+    Color color() const { return kind <= RPT_MAT_PHONG ? albedo : Color{0, 0, 0}; }
+    rpt_material desc() const {
+        rpt_material m{};
+        m.kind = kind;
+        for (int i = 0; i < 3; i++) m.albedo[i] = albedo[i];
+        m.emittance = emittance_;
+        m.shininess = shininess;
+        m.ior = ior;
+        return m;
+    }
+};
+
+// ---- object.rs / light.rs / medium.rs / environment.rs
+struct Object {
+    Shape shape;
+    Material material_;
+    explicit Object(Shape s) : shape(std::move(s)) {}
+    static Object new_(Shape s) { return Object(std::move(s)); }
+    Object material(Material m) && {
+        material_ = m;
+        return std::move(*this);
+    }
+    Object material(Material m) const& {
+        Object o = *this;
+        o.material_ = m;
+        return o;
+    }
+};
+struct Light {
+    enum Kind { POINT, AMBIENT, DIRECTIONAL, OBJECT } kind;
+    Color color{0, 0, 0};
+    Vec3 vec{0, 0, 0};
+    std::vector<rpt::Object> object;  // 0 or 1 element
+    static Light Point(Color c, Vec3 location) { return {POINT, c, location, {}}; }
+    static Light Ambient(Color c) { return {AMBIENT, c, {0, 0, 0}, {}}; }
+    static Light Directional(Color c, Vec3 direction) { return {DIRECTIONAL, c, direction, {}}; }
+    static Light Object(rpt::Object o) { return {OBJECT, {0, 0, 0}, {0, 0, 0}, {std::move(o)}}; }
+};
+struct Medium {
+    int kind;
+    double absorption, scattering;
+    static Medium homogeneous_isotropic(double a, double s) { return {RPT_MEDIUM_HOMOGENEOUS_ISOTROPIC, a, s}; }
+    static Medium colored_glowing_fog(double a, double s) { return {RPT_MEDIUM_COLORED_GLOWING_FOG, a, s}; }
+};
+struct Environment {
+    Color color{0, 0, 0};
+    static Environment Color_(Color c) { return {c}; }
+};
+
+// ---- scene.rs
+class Scene {
+  public:
+    std::vector<Object> objects;
+    std::vector<Light> lights;
+    std::vector<Medium> media;
+    Environment environment;
+    static Scene new_() { return {}; }
+    void add(Object o) { objects.push_back(std::move(o)); }
+    void add(Light l) { lights.push_back(std::move(l)); }
+    void add(Medium m) { media.push_back(m); }
+    // SceneAdd<(Mesh, Material)> / SceneAdd<(Transformed<Cube>, Material)>: object AND light (scene.rs:57-75)
+    void add(const std::pair<Shape, Material>& m) {
+        bool ok = m.first.kind == RPT_SHAPE_MESH || (m.first.kind == RPT_SHAPE_CUBE && m.first.has_transform);
+        if (!ok) throw Error("SceneAdd is implemented for (Mesh, Material) and (Transformed<Cube>, Material)");
+        add(Object(m.first).material(m.second));
+        add(Light::Object(Object(m.first).material(m.second)));
+    }
+};
+
+// ---- camera.rs
+struct Camera {
+    Vec3 eye{0, 0, 10}, direction{0, 0, -1}, up{0, 1, 0};
+    double fov = 0.52359877559829887308, aperture = 0, focal_distance = 0;
+    static Camera look_at(Vec3 eye, Vec3 center, Vec3 up, double fov) {
+        Camera c;
+        c.eye = eye;
+        c.direction = normalize(center - eye);
+        c.up = normalize(up - dot(up, c.direction) * c.direction);
+        c.fov = fov;
+        return c;
+    }
+    Camera focus(Vec3 focal_point, double aperture_) const {
+        Camera c = *this;
+        c.focal_distance = dot(focal_point - eye, direction);
+        c.aperture = aperture_;
+        return c;
+    }
+    rpt_camera desc() const {
+        rpt_camera c{};
+        for (int i = 0; i < 3; i++) {
+            c.eye[i] = eye[i];
+            c.direction[i] = direction[i];
+            c.up[i] = up[i];
+        }
+        c.fov = fov;
+        c.aperture = aperture;
+        c.focal_distance = focal_distance;
+        return c;
+    }
+};
+
+// ---- buffer.rs
+struct Filter {
+    uint32_t radius = 0;
+    static Filter Box(uint32_t r) { return {r}; }
+};
+struct RgbImage {
+    uint32_t width = 0, height = 0;
+    std::vector<uint8_t> data;  // row-major RGB
+};
+class Buffer {
+  public:
+    Buffer(uint32_t w, uint32_t h, Filter f) : width(w), height(h), filter(f) {}
+    void add_samples(const std::vector<double>& s) {
+        if (s.size() != size_t(width) * height * 3) throw Error("Invalid sample dimension");
+        samples.push_back(s);
+    }
+    Color get_filtered_color(uint32_t x, uint32_t y) const {  // buffer.rs:75-93
+        Color c{0, 0, 0};
+        size_t count = 0;
+        uint32_t r = filter.radius;
+        for (uint32_t i = x > r ? x - r : 0; i <= x + r; i++)
+            for (uint32_t j = y > r ? y - r : 0; j <= y + r; j++)
+                if (i < width && j < height) {
+                    size_t idx = (size_t(j) * width + i) * 3;
+                    for (const auto& s : samples)
+                        for (int k = 0; k < 3; k++) c[k] += s[idx + k];
+                    count += samples.size();
+                }
+        if (count == 0) throw Error("Pixel found with no samples");
+        return {c[0] / double(count), c[1] / double(count), c[2] / double(count)};
+    }
+    RgbImage image() const {
+        RgbImage img{width, height, {}};
+        img.data.reserve(size_t(width) * height * 3);
+        for (uint32_t y = 0; y < height; y++)
+            for (uint32_t x = 0; x < width; x++)
+                for (uint8_t b : color_bytes(get_filtered_color(x, y))) img.data.push_back(b);
+        return img;
+    }
+    double variance() const {  // buffer.rs:59-73
+        double variance = 0;
+        size_t n = samples.size(), px = size_t(width) * height;
+        for (size_t p = 0; p < px; p++) {
+            Color mean{0, 0, 0};
+            for (const auto& s : samples)
+                for (int k = 0; k < 3; k++) mean[k] += s[p * 3 + k] / double(n);
+            double ss = 0;
+            for (const auto& s : samples)
+                for (int k = 0; k < 3; k++) ss += (s[p * 3 + k] - mean[k]) * (s[p * 3 + k] - mean[k]);
+            variance += ss / (double(n) - 1.0);
+        }
+        return variance / double(px);
+    }
+    uint32_t width, height;
+    std::vector<std::vector<double>> samples;
+    Filter filter;
+};
+
+// ---- renderer.rs
+class Renderer {
+  public:
+    Renderer(const Scene& scene, Camera camera) : scene_(scene), camera_(camera) {}
+    static Renderer new_(const Scene& scene, Camera camera) { return Renderer(scene, camera); }
+    Renderer(const Renderer&) = delete;
+    Renderer(Renderer&& o) noexcept : scene_(o.scene_), camera_(o.camera_), p_(o.p_), handle_(o.handle_) { o.handle_ = nullptr; }
+    ~Renderer() {
+        if (handle_) rpt_scene_destroy(handle_);
+    }
+    struct Params {
+        uint32_t width = 800, height = 600;
+        double exposure_value = 0, stepsize = 0;
+        Filter filter;
+        uint32_t max_bounces = 0, num_samples = 1;
+        size_t gather_size = 50, gather_size_volume = 50;
+        double watts = 100;
+        uint64_t seed = 0;                   // addition: the reference seeds from entropy (renderer.rs:163)
+        uint32_t shard_rank = 0, shard_count = 1;
+        int device = 0;
+    };
+#define RPT_BUILDER(name, type) \
+    Renderer&& name(type v) && { p_.name = v; return std::move(*this); } \
+    Renderer& name(type v) & { p_.name = v; return *this; }
+    RPT_BUILDER(width, uint32_t)
+    RPT_BUILDER(height, uint32_t)
+    RPT_BUILDER(exposure_value, double)
+    RPT_BUILDER(stepsize, double)
+    RPT_BUILDER(filter, Filter)
+    RPT_BUILDER(max_bounces, uint32_t)
+    RPT_BUILDER(num_samples, uint32_t)
+    RPT_BUILDER(gather_size, size_t)
+    RPT_BUILDER(gather_size_volume, size_t)
+    RPT_BUILDER(watts, double)
+    RPT_BUILDER(seed, uint64_t)
+    RPT_BUILDER(device, int)
+#undef RPT_BUILDER
+    Renderer& shard(uint32_t rank, uint32_t count) {
+        p_.shard_rank = rank;
+        p_.shard_count = count;
+        return *this;
+    }
+    const Params& params() const { return p_; }
+
+    RgbImage render() {  // renderer.rs:137-141
+        Buffer buffer(p_.width, p_.height, p_.filter);
+        sample_offset_ = 0;
+        sample(p_.num_samples, buffer);
+        return buffer.image();
+    }
+    void iterative_render(uint32_t callback_interval, const std::function<void(uint32_t, const Buffer&)>& cb) {
+        Buffer buffer(p_.width, p_.height, p_.filter);  // renderer.rs:144-156
+        sample_offset_ = 0;
+        uint32_t iteration = 0;
+        while (iteration < p_.num_samples) {
+            uint32_t steps = std::min(p_.num_samples - iteration, callback_interval);
+            sample(steps, buffer);
+            iteration += steps;
+            cb(iteration, buffer);
+        }
+    }
+    // Renderer::sample (renderer.rs:158-171): the call that crosses the C ABI.
+    void sample(uint32_t iterations, Buffer& buffer) {
+        commit();
+        std::vector<double> out(size_t(p_.width) * p_.height * 3);
+        rpt_camera cam = camera_.desc();
+        rpt_render_params rp{p_.width, p_.height, p_.exposure_value, p_.max_bounces, p_.shard_rank, p_.shard_count};
+        check(rpt_render_sample(handle_, &cam, &rp, iterations, p_.seed, sample_offset_, out.data()));
+        sample_offset_ += iterations;
+        buffer.add_samples(out);
+    }
+
+  private:
+    void commit() {
+        if (handle_) return;
+        rpt_scene* h = rpt_scene_create();
+        try {
+            for (const Object& o : scene_.objects) {
+                rpt_shape_desc d = o.shape.desc();
+                rpt_material m = o.material_.desc();
+                check(rpt_scene_add_object(h, &d, &m));
+            }
+            for (const Light& l : scene_.lights) {
+                switch (l.kind) {
+                    case Light::POINT: check(rpt_scene_add_light_point(h, l.color.data(), l.vec.data())); break;
+                    case Light::AMBIENT: check(rpt_scene_add_light_ambient(h, l.color.data())); break;
+                    case Light::DIRECTIONAL: check(rpt_scene_add_light_directional(h, l.color.data(), l.vec.data())); break;
+                    default: {
+                        rpt_shape_desc d = l.object.at(0).shape.desc();
+                        rpt_material m = l.object.at(0).material_.desc();
+                        check(rpt_scene_add_light_object(h, &d, &m));
+                    }
+                }
+            }
+            for (const Medium& m : scene_.media) check(rpt_scene_add_medium(h, m.kind, m.absorption, m.scattering));
+            check(rpt_scene_set_environment_color(h, scene_.environment.color.data()));
+            check(rpt_scene_commit(h, p_.device));
+        } catch (...) {
+            rpt_scene_destroy(h);
+            throw;
+        }
+        handle_ = h;
+    }
+    const Scene& scene_;
+    Camera camera_;
+    Params p_;
+    rpt_scene* handle_ = nullptr;
+    uint32_t sample_offset_ = 0;
+};
+
+}  // namespace rpt
