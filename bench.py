@@ -23,42 +23,23 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 
 
-def algorithmic_work(scene_counts, counters, samples):
-    """Per-sample algorithmic bytes/flops of the closest-hit queries.
-
-    bytes per ray over the flattened fp32 layout: 48 B per sphere / cube / triangle scan
-    record, 16 B per plane, 32 B per BVH node visited, 48 B per BVH triangle tested, 48 B of
-    shade record for the accepted hit; + 16 B/pixel-chunk of framebuffer traffic (negligible).
-    flops per ray follow SURVEY.md section 8d (the reference algorithm's operation counts):
-    56 per affine map, 30 per cube, 25 per sphere, 12 per plane, 75 per triangle, 20 per node.
-    """
+def algorithmic_work(stats, n_objects, counters, samples):
+    """Per-sample algorithmic bytes/flops of the closest-hit queries, counted
+    on the REFERENCE's structure so the figure does not move when the device layout is specialised:
+    bytes per ray = 64 B per scene object tested (3x4 inverse affine + type/material words, every
+    object is tested: renderer.rs:419-423) + 48 B per triangle tested (single-leaf meshes test all
+    their triangles) + 48 B for the accepted hit's normals + 32 B per BVH node visited + 48 B per
+    BVH triangle tested (exact device counters).  flops per ray follow SURVEY.md section 8d:
+    56 per affine map, 30 per cube, 25 per sphere, 12 per plane, 75 per triangle, 20 per node,
+    + 300 per path vertex of shading."""
     rays = counters["rays"]
-    per_ray_bytes = 48 * (scene_counts["sph"] + scene_counts["cub"] + scene_counts["tri"]) + 16 * scene_counts["pln"] + 48
-    per_ray_flops = (56 + 25) * scene_counts["sph"] + (56 + 30) * scene_counts["cub"] + 12 * scene_counts["pln"] + \
-        75 * scene_counts["tri"]
+    cubes = stats["cubes"] + stats["aabbs"]
+    tris = stats["tris"] + 2 * stats["rects"]
+    per_ray_bytes = 64 * n_objects + 48 * tris + 48
+    per_ray_flops = (56 + 25) * stats["spheres"] + (56 + 30) * cubes + 12 * stats["planes"] + 75 * tris
     total_bytes = rays * per_ray_bytes + 32 * counters["bvh_nodes"] + 48 * counters["bvh_tris"]
     total_flops = rays * per_ray_flops + 20 * counters["bvh_nodes"] + 75 * counters["bvh_tris"] + 300 * counters["vertices"]
     return total_bytes / samples, total_flops / samples, rays / samples
-
-
-def scene_counts(scene):
-    from rpt_amd.api import Cube, Mesh, Plane, Sphere
-    c = dict(sph=0, cub=0, pln=0, tri=0, bvh_tri=0)
-    for o in scene.objects:
-        b = o.shape.base()
-        if isinstance(b, Sphere):
-            c["sph"] += 1
-        elif isinstance(b, Cube):
-            c["cub"] += 1
-        elif isinstance(b, Plane):
-            c["pln"] += 1
-        elif isinstance(b, Mesh):
-            n = b.tris.shape[0]
-            if n <= 32:
-                c["tri"] += n
-            else:
-                c["bvh_tri"] += n
-    return c
 
 
 def cpu_baseline(scene, cam, cfg, width, height, target_seconds=15.0):
@@ -167,8 +148,8 @@ def main():
         samples_per_step = width * height * spp
         ms_per_step = elapsed / args.steps * 1e3
         value = samples_per_step * args.steps / elapsed / 1e6
-        sc = scene_counts(scene)
-        bytes_ps, flops_ps, rays_ps = algorithmic_work(sc, cnt, max(cnt["samples"], 1))
+        stats = r.scene_stats()
+        bytes_ps, flops_ps, rays_ps = algorithmic_work(stats, len(scene.objects), cnt, max(cnt["samples"], 1))
         k_ms = float(np.mean(kernel_ms))
         local_samples = samples_per_step / world          # tiles are sharded evenly over ranks
         ach_gbs = bytes_ps * local_samples / (k_ms * 1e-3) / 1e9

@@ -126,6 +126,11 @@ int rpt_render_sample_device(rpt_scene*, const rpt_camera*, const rpt_render_par
 int rpt_intersect_batch(rpt_scene*, uint64_t n, const float* origins, const float* dirs, float* t,
                         int32_t* object, float* normal);
 
+/* Flattened-layout statistics of a committed scene: [0] spheres, [1] general (rotated) cubes,
+ * [2] planes, [3] linearly scanned triangles, [4] axis-aligned boxes, [5] axis-aligned
+ * rectangles (pairs of wall triangles), [6] BVH triangles, [7] BVH nodes, [8] bytes of scan
+ * records every closest-hit query walks, [9] bytes of scene data resident in HBM. */
+int rpt_scene_stats(rpt_scene*, uint64_t out[16]);
 /* Counters of the last rpt_render_sample* call on this scene (device-side, exact):
  * [0] camera samples, [1] closest-hit queries (rays), [2] path vertices, [3] kernel loop trips
  * (wave-iterations summed over waves), [4] primitive tests, [5] BVH nodes visited,

@@ -82,6 +82,7 @@ SYMBOLS = [
     ("rpt_render_sample_device", C.c_int,
      [_P, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_uint32, C.c_uint64, C.c_uint32, _P, _P]),
     ("rpt_intersect_batch", C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P]),
+    ("rpt_scene_stats", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("rpt_get_counters", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("rpt_get_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("rpt_set_option", C.c_int, [C.c_char_p, C.c_int64]),

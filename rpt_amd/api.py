@@ -681,6 +681,14 @@ class Renderer:
         _lib.check(_lib.load().rpt_get_timing(self.scene._handle, C.byref(a), C.byref(b), C.byref(g)))
         return a.value, b.value, g.value
 
+    def scene_stats(self):
+        """rpt_scene_stats of the committed scene (flattened-layout record counts and bytes)."""
+        out = (C.c_uint64 * 16)()
+        _lib.check(_lib.load().rpt_scene_stats(self.scene._commit(self.device_), out))
+        names = ["spheres", "cubes", "planes", "tris", "aabbs", "rects", "bvh_tris", "bvh_nodes", "scan_bytes_per_ray",
+                 "scene_bytes"]
+        return dict(zip(names, [int(v) for v in out]))
+
     def counters(self):
         out = (C.c_uint64 * 8)()
         _lib.check(_lib.load().rpt_get_counters(self.scene._handle, out))

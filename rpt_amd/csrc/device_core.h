@@ -172,6 +172,43 @@ RPT_DEV float hit_tri(const F4& pn, const F4& A, const F4& B, V o, V d, float tm
     float u = 1.f - v - w;
     return (u >= 0.f && v >= 0.f && w >= 0.f) ? t : -1.f;
 }
+// Axis-aligned box in world space (a cube under positive scale + translation): the reference's
+// local slab test (src/shape/cube.rs:22-74) evaluated in world coordinates, where it yields the
+// same entry/exit parameters because t is shared between the two spaces.  `inv` = 1/d.
+template <bool WANT_FACE>
+RPT_DEV float hit_aabb(const F4& lo, const F4& hi, V o, V inv, float tmin, uint32_t& face) {
+    float x1 = (lo.x - o.x) * inv.x, x2 = (hi.x - o.x) * inv.x;
+    float y1 = (lo.y - o.y) * inv.y, y2 = (hi.y - o.y) * inv.y;
+    float z1 = (lo.z - o.z) * inv.z, z2 = (hi.z - o.z) * inv.z;
+    bool sx = x1 > x2, sy = y1 > y2, sz = z1 > z2;
+    float xl = sx ? x2 : x1, xh = sx ? x1 : x2;
+    float yl = sy ? y2 : y1, yh = sy ? y1 : y2;
+    float zl = sz ? z2 : z1, zh = sz ? z1 : z2;
+    float start = max3(xl, yl, zl);
+    float end = min3(xh, yh, zh);
+    if (start > end || end < tmin) return -1.f;
+    bool use_end = start < tmin;
+    if (WANT_FACE) {
+        uint32_t as, ae;
+        if (xl > yl && xl > zl) as = 0; else if (yl > zl) as = 1; else as = 2;
+        if (xh < yh && xh < zh) ae = 0; else if (yh < zh) ae = 1; else ae = 2;
+        uint32_t ax = use_end ? ae : as;
+        bool swapped = ax == 0 ? sx : (ax == 1 ? sy : sz);
+        bool positive = use_end ? !swapped : swapped;
+        face = ax | (positive ? 4u : 0u);
+    }
+    return use_end ? end : start;
+}
+// Axis-aligned rectangle = two coplanar triangles of src/shape/mesh.rs:50-83 (u,v,w >= 0 on one
+// of them <=> the point lies in the closed rectangle).  oa/da/ia: origin, direction and 1/direction
+// on the rectangle's axis; (ou,du), (ov,dv) on the two in-plane axes.
+RPT_DEV float hit_rect(const F4& a, float vmax, float oa, float ia, float ou, float du, float ov, float dv,
+                       float tmin, float tmax) {
+    float t = (a.x - oa) * ia;
+    if (!(t >= tmin && t < tmax)) return -1.f;
+    float pu = fmaf(t, du, ou), pv = fmaf(t, dv, ov);
+    return (pu >= a.y && pu <= a.z && pv >= a.w && pv <= vmax) ? t : -1.f;
+}
 RPT_DEV void to_local(const XfScan& x, V o, V d, V& ol, V& dl) {
     ol = mk(dot3w(x.r0, o), dot3w(x.r1, o), dot3w(x.r2, o));
     dl = mk(dot3(x.r0, d), dot3(x.r1, d), dot3(x.r2, d));
@@ -240,6 +277,32 @@ RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest
         float t = hit_plane(nv, o, d, tmin);
         if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
     }
+    const uint32_t n_rect = sc.n_rect_x + sc.n_rect_y + sc.n_rect_z;
+    if (sc.n_aabb + n_rect != 0) {  // wave-uniform: these kinds share one reciprocal direction per ray
+        const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
+        for (uint32_t i = 0; i < sc.n_aabb; i++) {
+            const AabbScan b = uload(&sc.aabb[i]);
+            uint32_t f;
+            float t = hit_aabb<false>(b.lo, b.hi, o, inv, tmin, f);
+            if (t >= 0.f && t < tbest) { tbest = t; code = (K_AABB << 28) | i; }
+        }
+        uint32_t i = 0;
+        for (uint32_t e = sc.n_rect_x; i < e; i++) {
+            const RectScan r = uload(&sc.rect[i]);
+            float t = hit_rect(r.a, r.b.x, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, tbest);
+            if (t >= 0.f) { tbest = t; code = (K_RECT << 28) | i; }
+        }
+        for (uint32_t e = sc.n_rect_x + sc.n_rect_y; i < e; i++) {
+            const RectScan r = uload(&sc.rect[i]);
+            float t = hit_rect(r.a, r.b.x, o.y, inv.y, o.z, d.z, o.x, d.x, tmin, tbest);
+            if (t >= 0.f) { tbest = t; code = (K_RECT << 28) | i; }
+        }
+        for (uint32_t e = n_rect; i < e; i++) {
+            const RectScan r = uload(&sc.rect[i]);
+            float t = hit_rect(r.a, r.b.x, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, tbest);
+            if (t >= 0.f) { tbest = t; code = (K_RECT << 28) | i; }
+        }
+    }
     for (uint32_t i = 0; i < sc.n_tri; i++) {
         const TriScan tr = uload(&sc.tri[i]);
         float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
@@ -277,6 +340,18 @@ RPT_DEV void finalize_hit(const SceneView& sc, V o, V d, float tmin, float t, ui
         V nl = mk(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f);
         n = (s.r1.w != 0.f) ? normalize(mk(dot3(s.r0, nl), dot3(s.r1, nl), dot3(s.r2, nl))) : nl;
         obj = __float_as_uint(s.r0.w);
+    } else if (kind == K_AABB) {
+        const AabbScan b = sc.aabb[idx];
+        uint32_t face = 0;
+        (void)hit_aabb<true>(b.lo, b.hi, o, mk(rcp(d.x), rcp(d.y), rcp(d.z)), tmin, face);
+        float sg = (face & 4u) ? 1.f : -1.f;
+        uint32_t ax = face & 3u;
+        n = mk(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f);
+        obj = __float_as_uint(b.lo.w);
+    } else if (kind == K_RECT) {
+        const F4 s = sc.rect_sh[idx].n_obj;
+        n = xyz(s);
+        obj = __float_as_uint(s.w);
     } else if (kind == K_PLANE) {  // src/shape/plane.rs:27: -normalize(n) * signum(cos)
         const F4 nv = sc.pln[idx].nv;
         const F4 s = sc.pln_sh[idx].unit_n_obj;

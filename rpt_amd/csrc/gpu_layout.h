@@ -17,7 +17,7 @@ struct alignas(16) F4 {
 };
 
 // Primitive code = (kind << 28) | index-within-kind.  0xFFFFFFFF = miss.
-enum : uint32_t { K_SPHERE = 0, K_CUBE = 1, K_PLANE = 2, K_TRI = 3, K_BVHTRI = 4 };
+enum : uint32_t { K_SPHERE = 0, K_CUBE = 1, K_PLANE = 2, K_TRI = 3, K_BVHTRI = 4, K_AABB = 5, K_RECT = 6 };
 static const uint32_t CODE_MISS = 0xFFFFFFFFu;
 
 // Sphere / cube scan record: rows of the inverse affine map (world -> unit primitive).
@@ -46,6 +46,24 @@ struct alignas(16) TriScan {
 // Vertex normals (already multiplied by M^-T for Transformed<Mesh>); n1.w = object id (bits).
 struct alignas(16) TriShade {
     F4 n1, n2, n3;
+};
+// Flatten-time specialisations (same hits, normals and object ids as the generic records):
+//  * AabbScan: a cube whose transform is a positive scale + translation, i.e. an axis-aligned box
+//    in world space; tested with the ray's shared 1/d (no per-box affine map, no per-box rcp).
+//    lo.w = object id (bits).  The face choice follows src/shape/cube.rs:37-55 unchanged.
+//  * RectScan: two coplanar flat triangles of one mesh forming an axis-aligned rectangle
+//    (polygon() of 4 corners, e.g. every Cornell wall): plane coordinate c on `axis`, bounds on
+//    the other two axes in cyclic order (u = axis+1, v = axis+2).  Records are sorted by axis.
+//    b.z = object id (bits), b.w unused; the flat world normal lives in RectShade.
+struct alignas(16) AabbScan {
+    F4 lo, hi;
+};
+struct alignas(16) RectScan {
+    F4 a;  // c, umin, umax, vmin
+    F4 b;  // vmax, -, obj, -
+};
+struct alignas(16) RectShade {
+    F4 n_obj;  // unit normal, object id (bits)
 };
 struct alignas(16) BvhNode {
     float lo[3];
@@ -93,6 +111,8 @@ struct SceneView {
     const XfScan* cub;     const XfShade* cub_sh;   uint32_t n_cub;
     const PlaneScan* pln;  const PlaneShade* pln_sh; uint32_t n_pln;
     const TriScan* tri;    const TriShade* tri_sh;  uint32_t n_tri;
+    const AabbScan* aabb;  uint32_t n_aabb;
+    const RectScan* rect;  const RectShade* rect_sh; uint32_t n_rect_x, n_rect_y, n_rect_z;  // sorted by axis
     const BvhNode* nodes;  const TriScan* btri;     const TriShade* btri_sh;
     const MeshRef* meshes; uint32_t n_mesh;
     const Material* mats;  uint32_t n_obj;   // one material record per scene object

@@ -296,7 +296,7 @@ struct rpt_scene {
     size_t tiles_cap = 0;
     float* d_slab = nullptr;
     size_t slab_cap = 0;  // bytes
-    uint32_t* d_queue = nullptr;
+    unsigned long long* d_queue = nullptr;
     unsigned long long* d_counters = nullptr;
     double* d_out = nullptr;
     size_t out_cap = 0;  // bytes
@@ -305,6 +305,7 @@ struct rpt_scene {
     bool ev_valid = false;
     int last_blocks = 0;
     uint64_t prims_per_ray = 0;
+    uint64_t stats[16] = {0};
     // tile cache key
     uint32_t tk_w = 0, tk_h = 0, tk_rank = 0, tk_count = 0, n_tiles = 0, tiles_x = 0;
 };
@@ -444,6 +445,69 @@ int rpt_scene_set_environment_color(rpt_scene* s, const double rgb[3]) {
 // ---------------------------------------------------------------------------- commit (flatten + upload)
 static const uint64_t kLinearTriMax = 32;  // meshes up to this size are scanned linearly (scalar loads)
 
+static bool axis_aligned_positive(const Xf& x) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            if (i != j && x.M[i][j] != 0.0) return false;
+    return x.M[0][0] > 0.0 && x.M[1][1] > 0.0 && x.M[2][2] > 0.0;
+}
+
+// Two consecutive flat, coplanar triangles of one mesh whose union is an axis-aligned rectangle
+// (what polygon() produces for a wall): returns the axis (0/1/2) and fills the records, or -1.
+static int detect_rect(const double* t0, const double* t1, const Xf& x, uint32_t obj, RectScan& rs, RectShade& rh) {
+    for (int k = 1; k < 6; k++)  // all six vertex normals identical (flat, same plane orientation)
+        if (std::memcmp(t0 + 9, (k < 3 ? t0 + 9 + 3 * k : t1 + 9 + 3 * (k - 3)), 24) != 0) return -1;
+    D3 p[6] = {x.point(d3(t0)), x.point(d3(t0 + 3)), x.point(d3(t0 + 6)), x.point(d3(t1)), x.point(d3(t1 + 3)), x.point(d3(t1 + 6))};
+    auto eq = [](const D3& a, const D3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
+    // the second triangle must share exactly two vertices with the first
+    D3 q[4] = {p[0], p[1], p[2], p[0]};
+    int shared = 0, extra = -1;
+    for (int k = 3; k < 6; k++) {
+        bool s = eq(p[k], p[0]) || eq(p[k], p[1]) || eq(p[k], p[2]);
+        if (s) shared++;
+        else extra = k;
+    }
+    if (shared != 2 || extra < 0) return -1;
+    q[3] = p[extra];
+    int lone = -1;  // vertex of the first triangle that is not on the shared edge
+    for (int k = 0; k < 3; k++) {
+        bool s = false;
+        for (int m = 3; m < 6; m++) s = s || eq(p[k], p[m]);
+        if (!s) lone = k;
+    }
+    if (lone < 0) return -1;
+    for (int axis = 0; axis < 3; axis++) {
+        auto c = [&](const D3& v, int a) { return (&v.x)[a % 3]; };
+        double pc = c(q[0], axis);
+        if (c(q[1], axis) != pc || c(q[2], axis) != pc || c(q[3], axis) != pc) continue;
+        int ua = axis + 1, va = axis + 2;
+        double umin = c(q[0], ua), umax = umin, vmin = c(q[0], va), vmax = vmin;
+        for (int k = 1; k < 4; k++) {
+            umin = std::min(umin, c(q[k], ua)); umax = std::max(umax, c(q[k], ua));
+            vmin = std::min(vmin, c(q[k], va)); vmax = std::max(vmax, c(q[k], va));
+        }
+        if (!(umax > umin && vmax > vmin)) return -1;
+        int seen = 0;
+        for (int k = 0; k < 4; k++) {
+            double u = c(q[k], ua), v = c(q[k], va);
+            if ((u != umin && u != umax) || (v != vmin && v != vmax)) return -1;
+            seen |= 1 << ((u == umax ? 1 : 0) | (v == vmax ? 2 : 0));
+        }
+        if (seen != 15) return -1;
+        // the unshared vertices must be opposite corners (so the shared edge is the other diagonal)
+        const D3 &a = p[lone], &b = q[3];
+        if (c(a, ua) == c(b, ua) || c(a, va) == c(b, va)) return -1;
+        D3 n = x.has ? x.normal(d3(t0 + 9)) : d3(t0 + 9);
+        n = normalize(n);
+        rs.a = F4{float(pc), float(umin), float(umax), float(vmin)};
+        rs.b = F4{float(vmax), 0.f, bits_f(obj), 0.f};
+        rh.n_obj = f4(n, 0);
+        rh.n_obj.w = bits_f(obj);
+        return axis;
+    }
+    return -1;
+}
+
 static void push_tri(const double* t, const Xf& x, uint32_t obj, std::vector<TriScan>& scan,
                      std::vector<TriShade>& shade) {
     D3 v1 = x.point(d3(t)), v2 = x.point(d3(t + 3)), v3 = x.point(d3(t + 6));
@@ -494,6 +558,9 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     std::vector<PlaneShade> pln_sh;
     std::vector<TriScan> tri, btri;
     std::vector<TriShade> tri_sh, btri_sh;
+    std::vector<AabbScan> aabb;
+    std::vector<RectScan> rect_axis[3];
+    std::vector<RectShade> rect_sh_axis[3];
     std::vector<BvhNode> nodes;
     std::vector<MeshRef> meshes;
     std::vector<Material> mats;
@@ -513,6 +580,16 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         switch (o.shape.d.kind) {
             case RPT_SHAPE_SPHERE:
             case RPT_SHAPE_CUBE: {
+                if (o.shape.d.kind == RPT_SHAPE_CUBE && axis_aligned_positive(x)) {
+                    // positive scale + translation only: an axis-aligned box in world space
+                    AabbScan b;
+                    b.lo = F4{float(x.M[0][3] - 0.5 * x.M[0][0]), float(x.M[1][3] - 0.5 * x.M[1][1]),
+                              float(x.M[2][3] - 0.5 * x.M[2][2]), bits_f(obj)};
+                    b.hi = F4{float(x.M[0][3] + 0.5 * x.M[0][0]), float(x.M[1][3] + 0.5 * x.M[1][1]),
+                              float(x.M[2][3] + 0.5 * x.M[2][2]), 0.f};
+                    aabb.push_back(b);
+                    break;
+                }
                 XfScan sc;
                 sc.r0 = F4{float(x.Minv[0][0]), float(x.Minv[0][1]), float(x.Minv[0][2]), float(x.Minv[0][3])};
                 sc.r1 = F4{float(x.Minv[1][0]), float(x.Minv[1][1]), float(x.Minv[1][2]), float(x.Minv[1][3])};
@@ -542,7 +619,19 @@ int rpt_scene_commit(rpt_scene* s, int device) {
             default: {
                 uint64_t nt = o.shape.tris.size() / 18;
                 if (nt <= kLinearTriMax) {
-                    for (uint64_t i = 0; i < nt; i++) push_tri(&o.shape.tris[i * 18], x, obj, tri, tri_sh);
+                    for (uint64_t i = 0; i < nt; i++) {
+                        RectScan rs;
+                        RectShade rh;
+                        int axis = -1;
+                        if (i + 1 < nt) axis = detect_rect(&o.shape.tris[i * 18], &o.shape.tris[(i + 1) * 18], x, obj, rs, rh);
+                        if (axis >= 0) {
+                            rect_axis[axis].push_back(rs);
+                            rect_sh_axis[axis].push_back(rh);
+                            i++;
+                        } else {
+                            push_tri(&o.shape.tris[i * 18], x, obj, tri, tri_sh);
+                        }
+                    }
                 } else {
                     std::vector<TriScan> ms;
                     std::vector<TriShade> mh;
@@ -649,6 +738,14 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     size_t o_cub = reserve(cub.size() * sizeof(XfScan)), o_cubs = reserve(cub_sh.size() * sizeof(XfShade));
     size_t o_pln = reserve(pln.size() * sizeof(PlaneScan)), o_plns = reserve(pln_sh.size() * sizeof(PlaneShade));
     size_t o_tri = reserve(tri.size() * sizeof(TriScan)), o_tris = reserve(tri_sh.size() * sizeof(TriShade));
+    std::vector<RectScan> rect;
+    std::vector<RectShade> rect_sh;
+    for (int a = 0; a < 3; a++) {
+        rect.insert(rect.end(), rect_axis[a].begin(), rect_axis[a].end());
+        rect_sh.insert(rect_sh.end(), rect_sh_axis[a].begin(), rect_sh_axis[a].end());
+    }
+    size_t o_aabb = reserve(aabb.size() * sizeof(AabbScan));
+    size_t o_rect = reserve(rect.size() * sizeof(RectScan)), o_rects = reserve(rect_sh.size() * sizeof(RectShade));
     size_t o_nodes = reserve(nodes.size() * sizeof(BvhNode));
     size_t o_btri = reserve(btri.size() * sizeof(TriScan)), o_btris = reserve(btri_sh.size() * sizeof(TriShade));
     size_t o_mesh = reserve(meshes.size() * sizeof(MeshRef));
@@ -662,6 +759,8 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     put(o_cub, cub.data(), cub.size() * sizeof(XfScan));       put(o_cubs, cub_sh.data(), cub_sh.size() * sizeof(XfShade));
     put(o_pln, pln.data(), pln.size() * sizeof(PlaneScan));    put(o_plns, pln_sh.data(), pln_sh.size() * sizeof(PlaneShade));
     put(o_tri, tri.data(), tri.size() * sizeof(TriScan));      put(o_tris, tri_sh.data(), tri_sh.size() * sizeof(TriShade));
+    put(o_aabb, aabb.data(), aabb.size() * sizeof(AabbScan));
+    put(o_rect, rect.data(), rect.size() * sizeof(RectScan));  put(o_rects, rect_sh.data(), rect_sh.size() * sizeof(RectShade));
     put(o_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
     put(o_btri, btri.data(), btri.size() * sizeof(TriScan));   put(o_btris, btri_sh.data(), btri_sh.size() * sizeof(TriShade));
     put(o_mesh, meshes.data(), meshes.size() * sizeof(MeshRef));
@@ -677,6 +776,9 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     v.cub = (const XfScan*)(base + o_cub);      v.cub_sh = (const XfShade*)(base + o_cubs);    v.n_cub = uint32_t(cub.size());
     v.pln = (const PlaneScan*)(base + o_pln);   v.pln_sh = (const PlaneShade*)(base + o_plns); v.n_pln = uint32_t(pln.size());
     v.tri = (const TriScan*)(base + o_tri);     v.tri_sh = (const TriShade*)(base + o_tris);   v.n_tri = uint32_t(tri.size());
+    v.aabb = (const AabbScan*)(base + o_aabb);  v.n_aabb = uint32_t(aabb.size());
+    v.rect = (const RectScan*)(base + o_rect);  v.rect_sh = (const RectShade*)(base + o_rects);
+    v.n_rect_x = uint32_t(rect_axis[0].size()); v.n_rect_y = uint32_t(rect_axis[1].size()); v.n_rect_z = uint32_t(rect_axis[2].size());
     v.nodes = (const BvhNode*)(base + o_nodes); v.btri = (const TriScan*)(base + o_btri);      v.btri_sh = (const TriShade*)(base + o_btris);
     v.meshes = (const MeshRef*)(base + o_mesh); v.n_mesh = uint32_t(meshes.size());
     v.mats = (const Material*)(base + o_mats);  v.n_obj = uint32_t(mats.size());
@@ -710,7 +812,12 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         }
     }
     for (int i = 0; i < 3; i++) v.env[i] = float(s->env[i]);
-    s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size();
+    s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size() + aabb.size() + rect.size();
+    s->stats[0] = sph.size(); s->stats[1] = cub.size(); s->stats[2] = pln.size(); s->stats[3] = tri.size();
+    s->stats[4] = aabb.size(); s->stats[5] = rect.size(); s->stats[6] = btri.size(); s->stats[7] = nodes.size();
+    // scan-record bytes every closest-hit query walks (the uniform part of the algorithmic bytes)
+    s->stats[8] = 48 * (sph.size() + cub.size() + tri.size()) + 16 * pln.size() + 32 * (aabb.size() + rect.size());
+    s->stats[9] = off;
 
     HIP_TRY(hipMalloc((void**)&s->d_queue, 256));
     HIP_TRY(hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)));
@@ -808,7 +915,7 @@ static int prepare_render(rpt_scene* s, const rpt_camera* cam, const rpt_render_
 }
 
 static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st) {
-    HIP_TRY(hipMemsetAsync(a.queue, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(a.queue, 0, 8, st));
     if (a.counters) HIP_TRY(hipMemsetAsync(a.counters, 0, 64, st));
     uint32_t shard_count = prm->shard_count == 0 ? 1 : prm->shard_count;
     if (shard_count > 1) HIP_TRY(hipMemsetAsync(d_out, 0, size_t(prm->width) * prm->height * 24, st));
@@ -888,6 +995,13 @@ int rpt_get_timing(rpt_scene* s, double* render_ms, double* resolve_ms, int32_t*
     if (render_ms) *render_ms = a;
     if (resolve_ms) *resolve_ms = b;
     if (grid_blocks) *grid_blocks = s->last_blocks;
+    return RPT_OK;
+}
+
+int rpt_scene_stats(rpt_scene* s, uint64_t out[16]) {
+    if (!s || !out) return fail(RPT_ERR_INVALID, "null argument");
+    if (!s->committed) return fail(RPT_ERR_STATE, "rpt_scene_commit must be called first");
+    std::memcpy(out, s->stats, sizeof(s->stats));
     return RPT_OK;
 }
 
