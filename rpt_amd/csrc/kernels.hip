@@ -49,7 +49,7 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 }
 
 #ifndef RPT_MIN_WAVES
-#define RPT_MIN_WAVES 1
+#define RPT_MIN_WAVES 4
 #endif
 template <bool MEDIUM, bool BVH, bool COUNT>
 __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
