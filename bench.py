@@ -28,7 +28,7 @@ def algorithmic_work(stats, n_objects, counters, samples):
     on the REFERENCE's structure so the figure does not move when the device layout is specialised:
     bytes per ray = 64 B per scene object tested (3x4 inverse affine + type/material words, every
     object is tested: renderer.rs:419-423) + 48 B per triangle tested (single-leaf meshes test all
-    their triangles) + 48 B for the accepted hit's normals + 32 B per BVH node visited + 48 B per
+    their triangles) + 48 B for the accepted hit's normals + 64 B per (two-box) BVH node visited + 48 B per
     BVH triangle tested (exact device counters).  flops per ray follow SURVEY.md section 8d:
     56 per affine map, 30 per cube, 25 per sphere, 12 per plane, 75 per triangle, 20 per node,
     + 300 per path vertex of shading."""
@@ -37,7 +37,7 @@ def algorithmic_work(stats, n_objects, counters, samples):
     tris = stats["tris"] + 2 * stats["rects"]
     per_ray_bytes = 64 * n_objects + 48 * tris + 48
     per_ray_flops = (56 + 25) * stats["spheres"] + (56 + 30) * cubes + 12 * stats["planes"] + 75 * tris
-    total_bytes = rays * per_ray_bytes + 32 * counters["bvh_nodes"] + 48 * counters["bvh_tris"]
+    total_bytes = rays * per_ray_bytes + 64 * counters["bvh_nodes"] + 48 * counters["bvh_tris"]
     total_flops = rays * per_ray_flops + 20 * counters["bvh_nodes"] + 75 * counters["bvh_tris"] + 300 * counters["vertices"]
     return total_bytes / samples, total_flops / samples, rays / samples
 

@@ -218,39 +218,61 @@ RPT_DEV void to_local(const XfScan& x, V o, V d, V& ol, V& dl) {
 // Renderer::get_closest_hit, src/renderer.rs:416-425: every object is tested, the closest
 // accepted hit wins, ties keep the earlier object (strict `<`).  The analytic primitives are
 // scanned with a wave-uniform index (scalar loads); BVH meshes are walked per lane.
+// Per-lane BVH walk ("while-while"): descend inner nodes until every lane of the wave holds a
+// leaf (or is done), then test the leaves' triangles together.  Stack = one LDS column per lane.
+RPT_DEV void slab2(const float lo[3], const float hi[3], V o, V inv, float& tn, float& tf) {
+    float x1 = (lo[0] - o.x) * inv.x, x2 = (hi[0] - o.x) * inv.x;
+    float y1 = (lo[1] - o.y) * inv.y, y2 = (hi[1] - o.y) * inv.y;
+    float z1 = (lo[2] - o.z) * inv.z, z2 = (hi[2] - o.z) * inv.z;
+    tn = max3(fminf(x1, x2), fminf(y1, y2), fminf(z1, z2));
+    tf = min3(fmaxf(x1, x2), fmaxf(y1, y2), fmaxf(z1, z2));
+}
 template <bool COUNT>
 RPT_DEV void bvh_traverse(const SceneView& sc, const MeshRef& m, V o, V d, float tmin, float& tbest,
                           uint32_t& code, uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
     const BvhNode* nodes = sc.nodes + m.node_base;
-    float ix = rcp(d.x), iy = rcp(d.y), iz = rcp(d.z);
+    const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
+    const uint32_t kDone = 0xFFFFFFFFu;  // a leaf entry with count 32 at the last triangle never occurs
     uint32_t sp = 0;
-    uint32_t cur = 0;
-    for (;;) {
-        const BvhNode nd = nodes[cur];
-        if (COUNT) c_nodes++;
-        float x1 = (nd.lo[0] - o.x) * ix, x2 = (nd.hi[0] - o.x) * ix;
-        float y1 = (nd.lo[1] - o.y) * iy, y2 = (nd.hi[1] - o.y) * iy;
-        float z1 = (nd.lo[2] - o.z) * iz, z2 = (nd.hi[2] - o.z) * iz;
-        float tn = max3(fminf(x1, x2), fminf(y1, y2), fminf(z1, z2));
-        float tf = min3(fmaxf(x1, x2), fmaxf(y1, y2), fmaxf(z1, z2));
-        bool overlap = fmaxf(tn, tmin) <= fminf(tf, tbest);
-        if (overlap) {
-            if (nd.count == 0) {
-                if (sp < 32) { stk[sp * stride] = nd.left_or_first + 1; sp++; }
-                cur = nd.left_or_first;
-                continue;
-            }
-            for (uint32_t i = 0; i < nd.count; i++) {
-                uint32_t ti = m.tri_base + nd.left_or_first + i;
-                const TriScan tr = sc.btri[ti];
-                if (COUNT) c_tris++;
-                float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
-                if (t >= 0.f) { tbest = t; code = (K_BVHTRI << 28) | ti; }
+    uint32_t cur = 0;  // root is always an inner node
+    while (cur != kDone) {
+        while (!(cur & BVH_LEAF)) {  // kDone has the leaf bit set, so finished lanes fall through
+            const BvhNode nd = nodes[cur];
+            if (COUNT) c_nodes++;
+            float n0, f0, n1, f1;
+            slab2(nd.lo0, nd.hi0, o, inv, n0, f0);
+            slab2(nd.lo1, nd.hi1, o, inv, n1, f1);
+            const bool h0 = fmaxf(n0, tmin) <= fminf(f0, tbest);
+            const bool h1 = fmaxf(n1, tmin) <= fminf(f1, tbest);
+            if (h0 && h1) {
+                const bool first0 = n0 <= n1;
+                if (sp < 32) { stk[sp * stride] = first0 ? nd.e1 : nd.e0; sp++; }
+                cur = first0 ? nd.e0 : nd.e1;
+            } else if (h0 || h1) {
+                cur = h0 ? nd.e0 : nd.e1;
+            } else if (sp) {
+                sp--;
+                cur = stk[sp * stride];
+            } else {
+                cur = kDone;
             }
         }
-        if (sp == 0) break;
-        sp--;
-        cur = stk[sp * stride];
+        if (cur != kDone) {
+            const uint32_t first = m.tri_base + (cur & 0x03FFFFFFu);
+            const uint32_t count = ((cur >> 26) & 31u) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                const TriScan tr = sc.btri[first + i];
+                if (COUNT) c_tris++;
+                float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
+                if (t >= 0.f) { tbest = t; code = (K_BVHTRI << 28) | (first + i); }
+            }
+            if (sp) {
+                sp--;
+                cur = stk[sp * stride];
+            } else {
+                cur = kDone;
+            }
+        }
     }
 }
 

@@ -6,7 +6,7 @@
 //     cube (inverse affine rows), 16 B per plane, 48 B per triangle.
 //   * "shade" arrays are indexed per lane by the winning primitive code after the scan
 //     (normal transform, vertex normals, object -> material).
-//   * large meshes are a BVH2 (32-byte nodes) + the same 48-byte triangle records, walked per lane.
+//   * large meshes are a BVH2 (64-byte two-box nodes) + the same 48-byte triangle records, walked per lane.
 #pragma once
 #include <stdint.h>
 
@@ -65,12 +65,21 @@ struct alignas(16) RectScan {
 struct alignas(16) RectShade {
     F4 n_obj;  // unit normal, object id (bits)
 };
+// BVH2 node holding BOTH children's boxes (64 B): one dependent load per inner node yields two
+// slab tests, the near child is descended first and leaves are referenced directly.
+// Child entry: bit 31 = leaf; leaf: bits 26..30 = triangle count - 1 (1..32), bits 0..25 = first
+// triangle within the mesh; inner: node index within the mesh.
 struct alignas(16) BvhNode {
-    float lo[3];
-    uint32_t left_or_first;  // inner: index of left child (right = left+1); leaf: first triangle
-    float hi[3];
-    uint32_t count;          // 0 = inner node, else number of triangles
+    float lo0[3];
+    uint32_t e0;
+    float hi0[3];
+    uint32_t pad0;
+    float lo1[3];
+    uint32_t e1;
+    float hi1[3];
+    uint32_t pad1;
 };
+static const uint32_t BVH_LEAF = 0x80000000u;
 enum : uint32_t { M_LAMBERTIAN = 0, M_PHONG = 1, M_MIRROR = 2, M_TRANSMISSIVE = 3 };
 struct alignas(16) Material {
     F4 albedo_emit;  // rgb albedo, emittance

@@ -163,9 +163,15 @@ struct BTri {
     float lo[3], hi[3], c[3];
     uint32_t idx;
 };
+struct TmpNode {  // build-time node: own box, children adjacent (left, left+1)
+    float lo[3];
+    uint32_t left_or_first;
+    float hi[3];
+    uint32_t count;  // 0 = inner
+};
 struct BvhBuilder {
     std::vector<BTri>& t;
-    std::vector<BvhNode>& nodes;
+    std::vector<TmpNode>& nodes;
     static constexpr int kBins = 16, kMaxDepth = 28;
     uint32_t leaf_max = 4;
     void bounds(uint32_t first, uint32_t count, float lo[3], float hi[3], float clo[3], float chi[3]) {
@@ -188,7 +194,7 @@ struct BvhBuilder {
     void build(uint32_t node, uint32_t first, uint32_t count, int depth) {
         float lo[3], hi[3], clo[3], chi[3];
         bounds(first, count, lo, hi, clo, chi);
-        BvhNode& n = nodes[node];
+        TmpNode& n = nodes[node];
         for (int a = 0; a < 3; a++) {  // conservative padding for the fp32 slab test
             float pad = 1e-6f * std::max(std::fabs(lo[a]), std::fabs(hi[a])) + 1e-30f;
             n.lo[a] = lo[a] - pad;
@@ -198,7 +204,7 @@ struct BvhBuilder {
             nodes[node].left_or_first = first;
             nodes[node].count = count;
         };
-        if (count <= leaf_max || depth >= kMaxDepth) return make_leaf();
+        if (count <= leaf_max || (depth >= kMaxDepth && count <= 32)) return make_leaf();
         int best_axis = -1, best_bin = -1;
         float best_cost = std::numeric_limits<float>::infinity();
         for (int a = 0; a < 3; a++) {
@@ -246,9 +252,9 @@ struct BvhBuilder {
             }
         }
         uint32_t mid;
-        if (best_axis < 0) {
+        if (best_axis < 0 || depth >= kMaxDepth) {
             if (count <= 16) return make_leaf();
-            mid = first + count / 2;  // all centroids coincide: split by index
+            mid = first + count / 2;  // all centroids coincide (or depth cap): split by index
         } else {
             float parent_cost = area(lo, hi) * float(count);
             if (best_cost >= parent_cost && count <= 8) return make_leaf();
@@ -262,8 +268,8 @@ struct BvhBuilder {
             if (mid == first || mid == first + count) mid = first + count / 2;
         }
         uint32_t left = uint32_t(nodes.size());
-        nodes.push_back(BvhNode{});
-        nodes.push_back(BvhNode{});
+        nodes.push_back(TmpNode{});
+        nodes.push_back(TmpNode{});
         nodes[node].left_or_first = left;
         nodes[node].count = 0;
         build(left, first, mid - first, depth + 1);
@@ -656,11 +662,34 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                     mr.tri_base = uint32_t(btri.size());
                     mr.tri_count = uint32_t(nt);
                     mr.object = obj;
-                    std::vector<BvhNode> local;
-                    local.reserve(nt);
-                    local.push_back(BvhNode{});
-                    BvhBuilder b{bt, local};
+                    std::vector<TmpNode> tmp;
+                    tmp.reserve(nt);
+                    tmp.push_back(TmpNode{});
+                    BvhBuilder b{bt, tmp};
                     b.build(0, 0, uint32_t(nt), 0);
+                    // convert to two-box nodes: inner tmp node k -> wide node remap[k]
+                    std::vector<uint32_t> remap(tmp.size(), 0);
+                    uint32_t n_inner = 0;
+                    for (size_t k = 0; k < tmp.size(); k++)
+                        if (tmp[k].count == 0) remap[k] = n_inner++;
+                    std::vector<BvhNode> local(n_inner);
+                    auto entry = [&](uint32_t k) -> uint32_t {
+                        const TmpNode& c = tmp[k];
+                        if (c.count == 0) return remap[k];
+                        return BVH_LEAF | ((c.count - 1u) << 26) | c.left_or_first;
+                    };
+                    for (size_t k = 0; k < tmp.size(); k++) {
+                        if (tmp[k].count != 0) continue;
+                        BvhNode& w = local[remap[k]];
+                        uint32_t l = tmp[k].left_or_first;
+                        for (int a = 0; a < 3; a++) {
+                            w.lo0[a] = tmp[l].lo[a]; w.hi0[a] = tmp[l].hi[a];
+                            w.lo1[a] = tmp[l + 1].lo[a]; w.hi1[a] = tmp[l + 1].hi[a];
+                        }
+                        w.e0 = entry(l);
+                        w.e1 = entry(l + 1);
+                        w.pad0 = w.pad1 = 0;
+                    }
                     for (uint64_t i = 0; i < nt; i++) {
                         btri.push_back(ms[bt[i].idx]);
                         btri_sh.push_back(mh[bt[i].idx]);
