@@ -145,6 +145,31 @@ int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* g
  * "blocks_per_cu" (persistent grid size), "timing" 0/1; returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 
+/* ---- photon mapping (next tier: src/photon.rs; config C4 = photon_point_query_beam_render) ----
+ * `enum PhotonRenderKind` (src/photon.rs:631-639).  The device builds the point map for the beam
+ * estimate; the other two kinds return RPT_ERR_UNSUPPORTED for now. */
+enum { RPT_PHOTON_MAP = 0, RPT_PHOTON_POINT_BEAM = 1, RPT_PHOTON_BEAM_BEAM = 2 };
+/* Renderer::photon_render, first half (src/photon.rs:655-704): shoot `photon_count` photons of
+ * power watts/photon_count from the first Light::Object (shoot_photon / trace_photon, :724-946),
+ * build the surface and volume point maps and the per-photon gather radii (:204-247).  The map is
+ * stored in the scene handle and replaced by the next build.  Photon i draws from the RNG stream
+ * (seed, i, 0x80000000 + (i >> 32)). */
+int rpt_photon_map_build(rpt_scene*, uint64_t photon_count, int32_t kind, double watts, uint64_t seed);
+/* [0] surface photons, [1] volume photons, [2] photons shot, [3] shooting us, [4] map build us. */
+int rpt_photon_map_stats(rpt_scene*, uint64_t out[8]);
+/* Test hook: which = 0 surface / 1 volume; out = n * 10 floats in shooting order:
+ * position, direction (toward the previous vertex), power, gather radius (volume photons). */
+int rpt_photon_map_download(rpt_scene*, int32_t which, float* out, uint64_t capacity_photons);
+/* Renderer::photon_render, second half = get_color_with_photon_map over the frame
+ * (src/photon.rs:706-716, 950-985; estimate_indirect :316-628) with `num_samples` camera
+ * samples per pixel; same output convention, seed keying and sharding as rpt_render_sample. */
+int rpt_photon_render_sample(rpt_scene*, const rpt_camera*, const rpt_render_params*, uint64_t gather_size,
+                             uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed,
+                             uint32_t sample_offset, double* out_rgb);
+int rpt_photon_render_sample_device(rpt_scene*, const rpt_camera*, const rpt_render_params*, uint64_t gather_size,
+                                    uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed,
+                                    uint32_t sample_offset, void* d_out_rgb, void* hip_stream);
+
 /* ---- device self-test hooks (each runs the device function in a one-block kernel) ---- */
 int rpt_debug_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out);
 int rpt_debug_material_sample_f(const rpt_material*, uint64_t n, const float* normals, const float* wos,

@@ -1000,6 +1000,338 @@ struct Renderer {
     }
 };
 
+
+// ====================================================================== photon.rs (next tier)
+// Photon shooting (src/photon.rs:724-946), the point map for the beam estimate (:204-247), the
+// surface estimate (:327-375), the beam x point volume estimate (:439-502) and the point x point
+// volume estimate (:384-438), combined as in :595-628.  Third-party crates restated from their
+// published semantics: kd-tree 0.4.1 `nearests(q,k)` = the k items of least squared distance;
+// bvh 0.6 `traverse(ray)` = every shape whose AABB the half-infinite ray hits (a superset that the
+// per-photon distance test below filters, so any conservative traversal yields the same sum).
+struct Photon {  // src/photon.rs:24-34
+    V3 position, direction, power, starting_position;
+};
+struct PhotonList {  // src/photon.rs:141-147
+    std::vector<Photon> surface, volume;
+};
+enum PhotonKind { PK_PHOTON_MAP = 0, PK_POINT_BEAM = 1, PK_BEAM_BEAM = 2 };  // src/photon.rs:631-639
+
+// trace_photon, src/photon.rs:803-946.  The recursion is a tail call (nothing but list
+// concatenation follows it), so it is a loop here; photons are stored in path order.
+static void trace_photon(const Renderer& r, Ray ray, V3 power, Rng& rng, PhotonList& out) {
+    const Scene& scene = r.scene;
+    for (;;) {
+        V3 wo = -normalize(ray.dir);
+        HitRecord h;
+        int oi;
+        bool hit = r.get_closest_hit(ray, h, oi);
+        bool in_volume = false;
+        double d = 0.0;
+        const Medium* medium = scene.media.empty() ? nullptr : &scene.media[0];
+        if (medium) {  // :918-944
+            double pdf_d, cdf_d;
+            medium->sample_d(ray, rng, d, pdf_d, cdf_d);
+            in_volume = !hit || d < h.time;
+        } else if (!hit) {
+            return;
+        }
+        if (in_volume) {  // trace_in_volume :879-914
+            V3 collision = ray.at(d);
+            V3 medium_color = medium->color(collision);
+            double scat = medium->scattering(collision), extinction = medium->absorption(collision) + scat;
+            V3 attenuated = cmul(power, medium_color) * scat / extinction;
+            double rr_prob = scat / extinction;
+            out.volume.push_back(Photon{collision, wo, power, ray.origin});
+            if (rng.uniform() < rr_prob) {
+                V3 wi;
+                double ph_p;
+                medium->sample_ph(wo, rng, wi, ph_p);
+                power = attenuated * medium->phase(wo, wi) / ph_p;
+                ray = Ray{collision, wi};
+                continue;
+            }
+            return;
+        }
+        // trace_on_surface :811-875: p_d = 0.7 (diffuse (0.7,0.7,0.7), no specular)
+        V3 world_pos = ray.at(h.time);
+        const Material& material = scene.objects[oi].material;
+        const double p_d = (0.7 + 0.7 + 0.7) / (0.7 + 0.7 + 0.7 + 0.0) * 0.7;
+        if (!(rng.uniform() < p_d)) return;  // absorbed: no photon is stored
+        V3 wi;
+        double pdf;
+        if (!sample_f(material, h.normal, wo, rng, wi, pdf)) return;  // total internal reflection: no photons
+        V3 f = bsdf(material, h.normal, wo, wi);
+        double cosine_term = dot(wi, h.normal) > 0.0 ? dot(wi, h.normal) : 1.0;
+        V3 attenuated = cmul(power, f) * cosine_term / pdf / p_d;
+        bool is_mirror = material.kind == MIRROR || material.kind == TRANSMISSIVE;  // material.rs:135-141
+        if (!is_mirror) out.surface.push_back(Photon{world_pos, wo, power, world_pos});  // `ray` is shadowed by the new ray at :842-846
+        power = attenuated;
+        ray = Ray{world_pos, wi};
+    }
+}
+// shoot_photon, src/photon.rs:724-799 (first Light::Object only, as written)
+static bool shoot_photon(const Renderer& r, double power, Rng& rng, int kind, PhotonList& out) {
+    for (const Light& light : r.scene.lights) {
+        if (light.kind != L_OBJECT) continue;
+        SurfSample s = light.object.shape->sample(V3(0, 0, 0), rng);
+        double phi = 2.0 * PI * rng.uniform();
+        double theta = std::acos(1.0 - rng.uniform());
+        V3 dir(std::sin(theta) * std::cos(phi), std::cos(theta), std::sin(theta) * std::sin(phi));
+        bool ok;
+        V3 direction = rotation_between_apply(V3(0, 1, 0), s.n, dir, ok);
+        if (!ok) direction = rotation_between_apply(V3(0, 1, 0.00000001), s.n, dir, ok);
+        PhotonList mine;
+        trace_photon(r, Ray{s.v, direction}, power * light.object.material.color(), rng, mine);
+        for (const Photon& p : mine.surface) out.surface.push_back(p);
+        for (Photon p : mine.volume) {
+            if (kind == PK_BEAM_BEAM) {  // :779-787 thinning
+                const double thresh = 0.001;
+                if (rng.uniform() < thresh) {
+                    p.power = p.power / thresh;
+                    out.volume.push_back(p);
+                }
+            } else {
+                out.volume.push_back(p);
+            }
+        }
+        return true;
+    }
+    return false;  // panic!("Only found non-object lights while photon mapping")
+}
+
+// kd-tree over points: only nearests(q, k) is needed.
+struct PointKd {
+    std::vector<V3> pts;
+    std::vector<uint32_t> idx;   // permutation: tree order -> original index
+    void build(const std::vector<Photon>& ph) {
+        pts.resize(ph.size());
+        idx.resize(ph.size());
+        for (size_t i = 0; i < ph.size(); i++) { pts[i] = ph[i].position; idx[i] = uint32_t(i); }
+        if (!ph.empty()) rec(0, ph.size(), 0);
+    }
+    void rec(size_t lo, size_t hi, int axis) {
+        if (hi - lo <= 1) return;
+        size_t mid = (lo + hi) / 2;
+        std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi,
+                         [&](uint32_t a, uint32_t b) { return pts[a][axis] < pts[b][axis]; });
+        rec(lo, mid, (axis + 1) % 3);
+        rec(mid + 1, hi, (axis + 1) % 3);
+    }
+    // max-heap of (dist2, index) of size <= k
+    void nearests(const V3& q, size_t k, std::vector<std::pair<double, uint32_t>>& heap) const {
+        heap.clear();
+        if (!idx.empty() && k) search(0, idx.size(), 0, q, k, heap);
+        std::sort_heap(heap.begin(), heap.end());
+    }
+    void search(size_t lo, size_t hi, int axis, const V3& q, size_t k,
+                std::vector<std::pair<double, uint32_t>>& heap) const {
+        if (lo >= hi) return;
+        size_t mid = (lo + hi) / 2;
+        uint32_t id = idx[mid];
+        V3 dv = pts[id] - q;
+        double d2 = dot(dv, dv);
+        if (heap.size() < k) { heap.emplace_back(d2, id); std::push_heap(heap.begin(), heap.end()); }
+        else if (d2 < heap.front().first) { std::pop_heap(heap.begin(), heap.end()); heap.back() = {d2, id}; std::push_heap(heap.begin(), heap.end()); }
+        double delta = q[axis] - pts[id][axis];
+        int na = (axis + 1) % 3;
+        if (delta < 0) {
+            search(lo, mid, na, q, k, heap);
+            if (heap.size() < k || delta * delta <= heap.front().first) search(mid + 1, hi, na, q, k, heap);
+        } else {
+            search(mid + 1, hi, na, q, k, heap);
+            if (heap.size() < k || delta * delta <= heap.front().first) search(lo, mid, na, q, k, heap);
+        }
+    }
+};
+// Median-split BVH over photon spheres; visit() is called for every sphere whose box the ray hits.
+struct SphereBvh {
+    struct Node { V3 lo, hi; uint32_t left, right, first, count; };
+    std::vector<Node> nodes;
+    std::vector<uint32_t> order;
+    const std::vector<V3>* pos = nullptr;
+    const std::vector<double>* rad = nullptr;
+    void build(const std::vector<V3>& p, const std::vector<double>& r) {
+        pos = &p; rad = &r;
+        order.resize(p.size());
+        for (size_t i = 0; i < p.size(); i++) order[i] = uint32_t(i);
+        nodes.clear();
+        if (!p.empty()) rec(0, uint32_t(p.size()));
+    }
+    uint32_t rec(uint32_t first, uint32_t count) {
+        uint32_t me = uint32_t(nodes.size());
+        nodes.push_back(Node{});
+        V3 lo(INF, INF, INF), hi(-INF, -INF, -INF), clo(INF, INF, INF), chi(-INF, -INF, -INF);
+        for (uint32_t i = first; i < first + count; i++) {
+            const V3& c = (*pos)[order[i]];
+            double r = (*rad)[order[i]];
+            lo = vmin(lo, c - V3(r, r, r)); hi = vmax(hi, c + V3(r, r, r));
+            clo = vmin(clo, c); chi = vmax(chi, c);
+        }
+        nodes[me].lo = lo; nodes[me].hi = hi; nodes[me].first = first; nodes[me].count = count;
+        nodes[me].left = nodes[me].right = 0;
+        if (count > 8) {
+            V3 e = chi - clo;
+            int ax = (e.x > e.y && e.x > e.z) ? 0 : (e.y > e.z ? 1 : 2);
+            uint32_t mid = first + count / 2;
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) { return (*pos)[a][ax] < (*pos)[b][ax]; });
+            uint32_t l = rec(first, mid - first), rr = rec(mid, first + count - mid);
+            nodes[me].left = l; nodes[me].right = rr; nodes[me].count = 0;
+        }
+        return me;
+    }
+    template <class F>
+    void traverse(const Ray& ray, F&& visit) const {
+        if (nodes.empty()) return;
+        uint32_t stack[64];
+        int sp = 0;
+        stack[sp++] = 0;
+        while (sp) {
+            const Node& n = nodes[stack[--sp]];
+            BBox b; b.p_min = n.lo; b.p_max = n.hi;
+            double t0, t1;
+            b.intersect(ray, t0, t1);
+            if (!(t1 >= std::fmax(t0, 0.0))) continue;
+            if (n.count) { for (uint32_t i = n.first; i < n.first + n.count; i++) visit(order[i]); }
+            else { stack[sp++] = n.left; stack[sp++] = n.right; }
+        }
+    }
+};
+
+struct PhotonMap {  // src/photon.rs:181-311
+    int kind = PK_POINT_BEAM;
+    PhotonList list;
+    PointKd surface_kd, volume_kd;
+    std::vector<V3> sphere_pos;
+    std::vector<double> sphere_radius;  // PointMapForBeamEstimate: distance to the 10th nearest volume photon
+    SphereBvh bvh;
+    void build() {
+        surface_kd.build(list.surface);
+        volume_kd.build(list.volume);
+        if (kind == PK_POINT_BEAM) {  // :204-247
+            size_t n = list.volume.size();
+            sphere_pos.resize(n);
+            sphere_radius.resize(n);
+            std::vector<std::pair<double, uint32_t>> heap;
+            for (size_t i = 0; i < n; i++) {
+                volume_kd.nearests(list.volume[i].position, 10, heap);
+                double m = -1.0;
+                for (auto& e : heap) m = std::fmax(m, e.first);
+                sphere_pos[i] = list.volume[i].position;
+                sphere_radius[i] = std::sqrt(m);
+            }
+            bvh.build(sphere_pos, sphere_radius);
+        }
+    }
+};
+
+struct PhotonParams {
+    uint64_t photon_count;
+    int kind;
+    double watts;
+    uint64_t gather_size, gather_size_volume;
+};
+
+// surface_estimate closure, src/photon.rs:327-375
+static V3 photon_surface_estimate(const Renderer& r, const PhotonMap& pm, const PhotonParams& pp, const Ray& ray,
+                                  const HitRecord& h, const Material& material, const V3& wo) {
+    V3 world_pos = ray.at(h.time);
+    std::vector<std::pair<double, uint32_t>> near;
+    pm.surface_kd.nearests(world_pos, pp.gather_size, near);
+    double max_dist_squared = 0.0;
+    for (auto& e : near) max_dist_squared = std::fmax(max_dist_squared, e.first);
+    V3 color = material.emittance() * material.color();
+    for (auto& e : near) {
+        const Photon& photon = pm.list.surface[e.second];
+        V3 disp = world_pos - photon.position;
+        Ray pr{photon.position, normalize(disp)};
+        HitRecord ph;
+        int oi;
+        if (r.get_closest_hit(pr, ph, oi)) {
+            double len = length(disp);
+            bool blocked;
+            if (r.p.robust) {  // policy of the fp32 path: own-tangent-plane hits are not occluders
+                V3 hp = pr.at(ph.time) - world_pos;
+                bool own_plane = std::fabs(dot(hp, h.normal)) <= 1e-4 * len;
+                blocked = !own_plane && ph.time < len * (1.0 - 1e-3);
+            } else {
+                blocked = len > ph.time;  // :357-361
+            }
+            if (blocked) continue;
+        }
+        double c = std::fmin(std::fmax(dot(photon.direction, h.normal), 0.0), 1.0);
+        color = color + cmul(bsdf(material, h.normal, wo, photon.direction), photon.power) * c;
+    }
+    return color * (1.0 / (PI * max_dist_squared));
+}
+// PhotonMap::estimate_indirect, src/photon.rs:316-628
+static V3 photon_estimate_indirect(const Renderer& r, const PhotonMap& pm, const PhotonParams& pp, const Ray& ray,
+                                   Rng& rng) {
+    const Scene& scene = r.scene;
+    V3 wo = -normalize(ray.dir);
+    const Medium* medium = scene.media.empty() ? nullptr : &scene.media[0];
+    HitRecord h;
+    int oi;
+    bool hit = r.get_closest_hit(ray, h, oi);
+    auto volume_beam = [&](const HitRecord* hp) {  // :439-502
+        V3 dummy(0, 0, 0);
+        V3 medium_color = medium->color(dummy);
+        double extinction = medium->absorption(dummy) + medium->scattering(dummy);
+        V3 volume_color(0, 0, 0);
+        pm.bvh.traverse(ray, [&](uint32_t i) {
+            const Photon& photon = pm.list.volume[i];
+            double radius = pm.sphere_radius[i];
+            V3 otc = photon.position - ray.origin;
+            if (hp && length(otc) > hp->time) return;
+            double radius_squared = radius * radius;
+            double disk_distance = dot(otc, ray.dir);
+            V3 dv = ray.at(disk_distance) - photon.position;
+            double distance_squared = dot(dv, dv);
+            if (disk_distance > 0.0 && distance_squared < radius_squared) {
+                double tmp = 1.0 - distance_squared / radius_squared;
+                double weight = (3.0 / PI) * tmp * tmp / radius_squared;
+                V3 wi = -photon.direction;
+                double transmittance = std::exp(-extinction * disk_distance);
+                volume_color = volume_color + transmittance * cmul(photon.power, medium_color) * medium->phase(wi, -ray.dir) * weight;
+            }
+        });
+        return volume_color;
+    };
+    auto volume_point = [&](const HitRecord* hp, const Material* material) {  // :384-438
+        double d, d_pdf, d_cdf;
+        medium->sample_d(ray, rng, d, d_pdf, d_cdf);
+        if (!hp || d < hp->time) {
+            V3 collision = ray.at(d);
+            V3 medium_color = medium->color(collision);
+            double extinction = medium->absorption(collision) + medium->scattering(collision);
+            V3 color(0, 0, 0);
+            std::vector<std::pair<double, uint32_t>> near;
+            pm.volume_kd.nearests(collision, pp.gather_size_volume, near);
+            double max_dist_squared = 0.0;
+            for (auto& e : near) max_dist_squared = std::fmax(max_dist_squared, e.first);
+            for (auto& e : near)
+                color = color + cmul(pm.list.volume[e.second].power, medium_color) * medium->phase(wo, pm.list.volume[e.second].direction);
+            color = color / ((4.0 / 3.0) * PI * std::pow(max_dist_squared, 1.5));
+            color = color / extinction;
+            color = color * medium->transmittence(ray, d);
+            color = color / d_pdf;
+            return color;
+        }
+        return photon_surface_estimate(r, pm, pp, ray, *hp, *material, wo) * medium->transmittence(ray, hp->time) / (1.0 - d_cdf);
+    };
+    if (!hit) {
+        if (!medium) return scene.environment;
+        return pm.kind == PK_PHOTON_MAP ? volume_point(nullptr, nullptr) : volume_beam(nullptr);
+    }
+    const Material& material = scene.objects[oi].material;
+    if (!medium) return photon_surface_estimate(r, pm, pp, ray, h, material, wo);
+    if (pm.kind == PK_PHOTON_MAP) return volume_point(&h, &material);
+    V3 volume_color = volume_beam(&h);
+    V3 surface_color = photon_surface_estimate(r, pm, pp, ray, h, material, wo) * medium->transmittence(ray, h.time);
+    (void)rng.uniform();  // the debug print's draw, src/photon.rs:619
+    return surface_color + volume_color;
+}
+
 }  // namespace orc
 
 // ====================================================================== C API (ctypes)
@@ -1289,6 +1621,83 @@ void orc_light_illuminate(orc_scene* s, int light_index, const double* pos, uint
     s->scene.lights[light_index].illuminate(v3(pos), rng, I, w, *dist);
     intensity[0] = I.x; intensity[1] = I.y; intensity[2] = I.z;
     wi[0] = w.x; wi[1] = w.y; wi[2] = w.z;
+}
+
+// ---------------------------------------------------------------------------- photon mapping (next tier)
+struct orc_photon_map {
+    PhotonMap pm;
+    PhotonParams pp;
+};
+// Renderer::photon_render, shooting + map build (src/photon.rs:655-704).  Photon i draws from
+// the stream (seed, pixel = i, sample = 0x80000000).  Returns null when no Light::Object exists.
+orc_photon_map* orc_photon_map_build(orc_scene* s, uint64_t photon_count, int kind, double watts, uint64_t gather_size,
+                                     uint64_t gather_size_volume, uint64_t seed, int robust) {
+    RenderParams rp{1, 1, 0.0, 0, robust};
+    Renderer r{s->scene, Camera{}, rp};
+    auto* m = new orc_photon_map();
+    m->pp = PhotonParams{photon_count, kind, watts, gather_size, gather_size_volume};
+    m->pm.kind = kind;
+    double power = watts / double(photon_count);
+    for (uint64_t i = 0; i < photon_count; i++) {
+        Rng rng(seed, uint32_t(i), 0x80000000u + uint32_t(i >> 32));
+        if (!shoot_photon(r, power, rng, kind, m->pm.list)) {
+            delete m;
+            return nullptr;
+        }
+    }
+    m->pm.build();
+    return m;
+}
+void orc_photon_map_free(orc_photon_map* m) { delete m; }
+// which: 0 surface, 1 volume.  out (may be null): n * 10 doubles: position, direction, power, radius (volume, point-beam)
+uint64_t orc_photon_map_get(orc_photon_map* m, int which, double* out) {
+    const std::vector<Photon>& v = which == 0 ? m->pm.list.surface : m->pm.list.volume;
+    if (out)
+        for (size_t i = 0; i < v.size(); i++) {
+            double* o = out + i * 10;
+            o[0] = v[i].position.x; o[1] = v[i].position.y; o[2] = v[i].position.z;
+            o[3] = v[i].direction.x; o[4] = v[i].direction.y; o[5] = v[i].direction.z;
+            o[6] = v[i].power.x; o[7] = v[i].power.y; o[8] = v[i].power.z;
+            o[9] = (which == 1 && i < m->pm.sphere_radius.size()) ? m->pm.sphere_radius[i] : 0.0;
+        }
+    return v.size();
+}
+// get_color_with_photon_map over the frame (src/photon.rs:950-985), one task per row.
+int orc_photon_render(orc_scene* s, orc_photon_map* m, const orc_camera* cam, const orc_params* prm, uint32_t num_samples,
+                      uint64_t seed, uint32_t sample_offset, double* out_rgb, int threads, const uint32_t* pixel_list,
+                      uint64_t n_pixels) {
+    RenderParams rp{prm->width, prm->height, prm->exposure_value, prm->max_bounces, prm->robust};
+    Renderer r{s->scene, make_camera(cam), rp};
+    if (threads < 1) threads = 1;
+    std::atomic<uint64_t> next(0);
+    const uint64_t total = pixel_list ? n_pixels : uint64_t(prm->width) * prm->height;
+    auto work = [&]() {
+        for (;;) {
+            uint64_t b = next.fetch_add(64);
+            if (b >= total) break;
+            for (uint64_t i = b; i < std::min(total, b + 64); i++) {
+                uint32_t pix = pixel_list ? pixel_list[i] : uint32_t(i);
+                uint32_t x = pix % prm->width, y = pix / prm->width;
+                double dim = double(std::max(prm->width, prm->height));
+                double xn = (double(2 * x + 1) - double(prm->width)) / dim;
+                double yn = (double(2 * (prm->height - y) - 1) - double(prm->height)) / dim;
+                V3 color(0, 0, 0);
+                for (uint32_t k = 0; k < num_samples; k++) {
+                    Rng rng(seed, pix, sample_offset + k);
+                    double dx = rng.range(-1.0 / dim, 1.0 / dim), dy = rng.range(-1.0 / dim, 1.0 / dim);
+                    Ray ray = r.camera.cast_ray(xn + dx, yn + dy, rng);
+                    color = color + photon_estimate_indirect(r, m->pm, m->pp, ray, rng);
+                }
+                color = color / double(num_samples) * std::pow(2.0, rp.exposure_value);
+                out_rgb[size_t(pix) * 3] = color.x; out_rgb[size_t(pix) * 3 + 1] = color.y; out_rgb[size_t(pix) * 3 + 2] = color.z;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    return 0;
 }
 
 }  // extern "C"

@@ -86,6 +86,13 @@ SYMBOLS = [
     ("rpt_get_counters", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("rpt_get_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("rpt_set_option", C.c_int, [C.c_char_p, C.c_int64]),
+    ("rpt_photon_map_build", C.c_int, [_P, C.c_uint64, C.c_int32, C.c_double, C.c_uint64]),
+    ("rpt_photon_map_stats", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("rpt_photon_map_download", C.c_int, [_P, C.c_int32, _P, C.c_uint64]),
+    ("rpt_photon_render_sample", C.c_int,
+     [_P, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, _P]),
+    ("rpt_photon_render_sample_device", C.c_int,
+     [_P, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, _P, _P]),
     ("rpt_debug_rng_u32", C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("rpt_debug_material_sample_f", C.c_int,
      [C.POINTER(MaterialDesc), C.c_uint64, _P, _P, C.c_uint64, _P, _P, _P]),

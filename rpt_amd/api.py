@@ -689,6 +689,68 @@ class Renderer:
                  "scene_bytes"]
         return dict(zip(names, [int(v) for v in out]))
 
+    # ---- photon mapping (src/photon.rs:631-720)
+    PHOTON_MAP, PHOTON_POINT_BEAM, PHOTON_BEAM_BEAM = 0, 1, 2   # enum PhotonRenderKind
+
+    def photon_map_build(self, photon_count, kind=1):
+        """Shooting + map build of Renderer::photon_render (photon.rs:655-704) on the device."""
+        lib = _lib.load()
+        h = self.scene._commit(self.device_)
+        _lib.check(lib.rpt_photon_map_build(h, int(photon_count), int(kind), self.watts_, C.c_uint64(self.seed_)))
+        out = (C.c_uint64 * 8)()
+        _lib.check(lib.rpt_photon_map_stats(h, out))
+        return {"surface": int(out[0]), "volume": int(out[1]), "shot": int(out[2]), "shoot_us": int(out[3]),
+                "build_us": int(out[4])}
+
+    def photon_map_download(self, which):
+        """Test hook: (n, 10) float32 photons in shooting order (position, direction, power, radius)."""
+        lib = _lib.load()
+        h = self.scene._handle
+        out = (C.c_uint64 * 8)()
+        _lib.check(lib.rpt_photon_map_stats(h, out))
+        n = int(out[which])
+        arr = np.zeros((n, 10), dtype=np.float32)
+        _lib.check(lib.rpt_photon_map_download(h, which, arr.ctypes.data_as(C.c_void_p), n))
+        return arr
+
+    def photon_sample_array(self, num_samples):
+        """get_color_with_photon_map over the frame (photon.rs:706-716): (h*w, 3) fp64 means."""
+        lib = _lib.load()
+        h = self.scene._commit(self.device_)
+        out = np.empty((self.width_ * self.height_, 3), dtype=np.float64)
+        _lib.check(lib.rpt_photon_render_sample(
+            h, C.byref(camera_desc(self.camera, _lib.CameraDesc)), C.byref(self._params()), self.gather_size_,
+            self.gather_size_volume_, int(num_samples), C.c_uint64(self.seed_), self._sample_offset,
+            out.ctypes.data_as(C.c_void_p)))
+        self._sample_offset += int(num_samples)
+        return out
+
+    def photon_sample_device(self, num_samples, d_out_ptr, stream_ptr=0):
+        lib = _lib.load()
+        h = self.scene._commit(self.device_)
+        _lib.check(lib.rpt_photon_render_sample_device(
+            h, C.byref(camera_desc(self.camera, _lib.CameraDesc)), C.byref(self._params()), self.gather_size_,
+            self.gather_size_volume_, int(num_samples), C.c_uint64(self.seed_), self._sample_offset,
+            C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr)))
+        self._sample_offset += int(num_samples)
+
+    def photon_render(self, photon_count, kind):
+        """Renderer::photon_render (photon.rs:655-720) -> (h, w, 3) uint8 image."""
+        self.photon_map_build(photon_count, kind)
+        buffer = Buffer(self.width_, self.height_, self.filter_)
+        self._sample_offset = 0
+        buffer.add_samples(self.photon_sample_array(self.num_samples_))
+        return buffer.image()
+
+    def photon_point_query_beam_render(self, photon_count):   # photon.rs:642-644
+        return self.photon_render(photon_count, Renderer.PHOTON_POINT_BEAM)
+
+    def photon_beam_query_beam_render(self, photon_count):    # photon.rs:646-648
+        return self.photon_render(photon_count, Renderer.PHOTON_BEAM_BEAM)
+
+    def photon_map_render(self, photon_count):                # photon.rs:650-652
+        return self.photon_render(photon_count, Renderer.PHOTON_MAP)
+
     def counters(self):
         out = (C.c_uint64 * 8)()
         _lib.check(_lib.load().rpt_get_counters(self.scene._handle, out))

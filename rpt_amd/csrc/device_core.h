@@ -499,10 +499,9 @@ RPT_DEV V bsdf(const Mat& m, V n, V wo, V wi) {
 // Light::illuminate for Light::Object, src/light.rs:34-45, over the shape samplers
 // (src/kdtree.rs:141-146 + src/shape/mesh.rs:85-99, sphere.rs:53-65, cube.rs:76-89,
 //  Transformed::sample src/shape.rs:140-151).
-RPT_DEV void illuminate_object(const SceneView& sc, const Light& L, V pos, Rng& rng, V& intensity, V& wi,
-                               float& dist) {
-    V v, n, vl, nl;
-    float p;
+// Shape::sample of the light's shape: point v, normal n, pdf p (per world area).
+RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng& rng, V& v, V& n, float& p) {
+    V vl, nl;
     const LightXf x = sc.lxf[L.xf];
     const bool xf = x.nrm[1].w != 0.f;
     const bool mesh = L.shape == LS_MESH;
@@ -554,6 +553,12 @@ RPT_DEV void illuminate_object(const SceneView& sc, const Light& L, V pos, Rng& 
         v = vl;
         n = nl;
     }
+}
+RPT_DEV void illuminate_object(const SceneView& sc, const Light& L, V pos, Rng& rng, V& intensity, V& wi,
+                               float& dist) {
+    V v, n;
+    float p;
+    sample_light_shape(sc, L, pos, rng, v, n, p);
     V disp = v - pos;
     float len2 = dot(disp, disp);
     float ilen = rsq(len2);

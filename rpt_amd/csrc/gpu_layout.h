@@ -97,6 +97,7 @@ struct alignas(16) Light {
     uint32_t xf;          // index into lxf (every object light has one)
     uint32_t _pad[2];
     F4 color;             // Ambient: colour;  Object: material.color() * material.emittance()
+    F4 albedo;            // Object: material.color() (photon power, src/photon.rs:757)
 };
 // Light-mesh triangle: world-space vertices, LOCAL vertex normals and 1/(local area): the
 // pdf / normal mapping of Transformed::sample (src/shape.rs:140-151) is applied per sample.

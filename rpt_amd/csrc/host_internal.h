@@ -1,0 +1,38 @@
+// host_internal.h — internals of rpt_capi.cpp shared with the photon-mapping translation unit.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <functional>
+#include <string>
+
+#include "../../include/rpt_hip.h"
+#include "kernels.h"
+
+namespace rpti {
+int fail(int code, const std::string& msg);
+uint64_t seed_mix(uint64_t seed);
+struct SceneDev {
+    bool committed;
+    int device, n_cus;
+    rptg::SceneView view;
+    int first_object_light;  // index into scene.lights of the first Light::Object, or -1
+};
+SceneDev scene_dev(rpt_scene* s);
+void*& photon_slot(rpt_scene* s);  // owned by photon.hip (PhotonMapDev*), released through photon_release
+void photon_release(void* p);      // defined in photon.hip
+// Fills camera, tiles, slab, queue, chunking exactly as for the path tracer.
+int prepare_render(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations, uint64_t seed,
+                   uint32_t sample_offset, rptg::RenderArgs& a);
+// Zeroes the queue / sharded frame, calls `launch(args, n_blocks, stream)` with a persistent grid of
+// blocks_per_cu blocks per CU, then resolves the slab into d_out.
+int run_persistent(rpt_scene* s, const rpt_render_params* prm, const rptg::RenderArgs& a, double* d_out, hipStream_t st,
+                   int blocks_per_cu, const std::function<hipError_t(const rptg::RenderArgs&, int, hipStream_t)>& launch);
+double* scratch_out(rpt_scene* s, size_t bytes);  // cached device frame for the host-buffer entry points
+}  // namespace rpti
+
+#define RPTI_HIP_TRY(expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return rpti::fail(RPT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));  \
+    } while (0)

@@ -1,0 +1,873 @@
+// photon.hip — photon mapping on gfx950 (reference src/photon.rs):
+//   * photon shooting (shoot_photon / trace_photon, :724-946) as a two-pass kernel (count, then
+//     write at prefix-summed offsets, so the photon arrays are deterministic);
+//   * point maps as LBVHs built on the device: 63-bit Morton codes, hipCUB radix sort, Karras'
+//     parallel construction, bottom-up refit, packed into the same two-box 64-byte nodes the mesh
+//     BVH uses.  They replace the kd-tree 0.4.1 / bvh 0.6 crates: `nearests(q, k)` -> k nearest by
+//     squared distance; `traverse(ray)` -> every sphere whose box the ray hits (filtered below);
+//   * the per-photon gather radius = distance to the 10th nearest volume photon (:214-232);
+//   * the camera pass (get_color_with_photon_map / estimate_indirect, :316-628, :950-985) as a
+//     persistent kernel sharing the path tracer's work queue, slab and resolve.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "device_core.h"
+#include "host_internal.h"
+#include "kernels.h"
+
+namespace rptg {
+
+struct alignas(16) PhotonRec {
+    F4 pos_r;  // position, gather radius (volume photons of the beam map)
+    F4 dir;    // direction toward where the photon came from (wo); w = original index (bits)
+    F4 pow;    // power
+};
+
+RPT_DEV float ray_tmin_p(V o) { return 2e-5f * (1.f + max3(fabsf(o.x), fabsf(o.y), fabsf(o.z))); }
+
+struct ShootArgs {
+    SceneView sc;
+    uint64_t n_photons, seed_mixed;
+    float power;  // watts / photon_count
+    uint32_t light_index;
+    uint32_t* cnt_s;
+    uint32_t* cnt_v;
+    const uint64_t* off_s;
+    const uint64_t* off_v;
+    PhotonRec* surf;
+    PhotonRec* vol;
+};
+
+// shoot_photon + trace_photon, src/photon.rs:724-946.  WRITE = false: count only.
+template <bool MEDIUM, bool BVH, bool WRITE>
+__global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
+    extern __shared__ uint32_t dyn_lds[];
+    const SceneView& sc = a.sc;
+    uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
+    const float sigma_t = sc.sigma_a + sc.sigma_s;
+    const float inv_sigma_t = MEDIUM ? 1.f / sigma_t : 0.f;
+    const float albedo_med = MEDIUM ? sc.sigma_s / sigma_t : 0.f;
+    const Light L = uload(&sc.lights[a.light_index]);
+    for (uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x; i < a.n_photons; i += uint64_t(gridDim.x) * 256u) {
+        Rng rng;
+        rng.seed(a.seed_mixed, uint32_t(i), 0x80000000u + uint32_t(i >> 32));
+        V ro, n0;
+        float p0;
+        sample_light_shape(sc, L, mk(0.f, 0.f, 0.f), rng, ro, n0, p0);  // :733-734 (target is a dummy)
+        float u1 = rng.uniform(), u2 = rng.uniform();
+        float ct = 1.f - u2;                                           // theta = acos(1 - u), :738
+        float st = __builtin_sqrtf(fmaxf(1.f - ct * ct, 0.f));
+        V rd = rotate_from_y(n0, mk(st * __builtin_amdgcn_cosf(u1), ct, st * __builtin_amdgcn_sinf(u1)), true);
+        V power = a.power * xyz(L.albedo);
+        uint32_t ns = 0, nv = 0, c0 = 0, c1 = 0;
+        uint64_t os = WRITE ? a.off_s[i] : 0, ov = WRITE ? a.off_v[i] : 0;
+        for (;;) {
+            const V wo = -normalize(rd);
+            const float tmin = ray_tmin_p(ro);
+            float t = kInf;
+            uint32_t code = CODE_MISS;
+            closest_hit<BVH, false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
+            const bool hit = code != CODE_MISS;
+            bool in_volume = false;
+            float d = 0.f;
+            if (MEDIUM) {
+                float xi = rng.range(0.f, 1.f);
+                d = -__logf(xi) * inv_sigma_t;
+                in_volume = !hit || d < t;
+            } else if (!hit) {
+                break;
+            }
+            if (in_volume) {  // trace_in_volume :879-914
+                V x = fma3(d, rd, ro);
+                bool hi = sc.medium_kind == 1u && x.y > 250.f;
+                V mcol = hi ? mk(sc.medium_color_hi[0], sc.medium_color_hi[1], sc.medium_color_hi[2])
+                            : mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);
+                if (WRITE) {
+                    PhotonRec r;
+                    r.pos_r = F4{x.x, x.y, x.z, 0.f};
+                    r.dir = F4{wo.x, wo.y, wo.z, 0.f};
+                    r.pow = F4{power.x, power.y, power.z, 0.f};
+                    a.vol[ov + nv] = r;
+                }
+                nv++;
+                if (!(rng.uniform() < albedo_med)) break;
+                float ax = rng.range(-1.f, 1.f), ay = rng.range(-1.f, 1.f), az = rng.range(-1.f, 1.f);
+                power = albedo_med * (power * mcol);  // phase / ph_p == 1
+                ro = x;
+                rd = normalize(mk(ax, ay, az));
+                continue;
+            }
+            // trace_on_surface :811-875, p_d = 0.7
+            V n;
+            uint32_t obj;
+            finalize_hit(sc, ro, rd, tmin, t, code, n, obj);
+            const Mat mat = load_mat(sc, obj);
+            V x = fma3(t, rd, ro);
+            if (!(rng.uniform() < 0.7f)) break;
+            V wi;
+            float pdf;
+            if (!sample_f(mat, n, wo, rng, wi, pdf)) break;
+            V f = bsdf(mat, n, wo, wi);
+            float cw = dot(wi, n);
+            float cosine_term = cw > 0.f ? cw : 1.f;
+            if (mat.kind <= M_PHONG) {  // !is_mirror()
+                if (WRITE) {
+                    PhotonRec r;
+                    r.pos_r = F4{x.x, x.y, x.z, 0.f};
+                    r.dir = F4{wo.x, wo.y, wo.z, 0.f};
+                    r.pow = F4{power.x, power.y, power.z, 0.f};
+                    a.surf[os + ns] = r;
+                }
+                ns++;
+            }
+            power = (cosine_term * rcp(pdf * 0.7f)) * (power * f);
+            ro = x;
+            rd = wi;
+            // zero-power photons (back-face hits, bsdf == 0) are still traced and stored: they occupy
+            // slots of the k-nearest gathers exactly as in the reference
+        }
+        if (!WRITE) {
+            a.cnt_s[i] = ns;
+            a.cnt_v[i] = nv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LBVH over points
+struct Lbvh {
+    BvhNode* nodes = nullptr;   // n-1 two-box nodes; leaf entry = BVH_LEAF | sorted index
+    uint32_t n = 0;
+};
+RPT_DEV uint64_t expand21(uint32_t v) {  // spread 21 bits to every third bit
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void bounds_kernel(const PhotonRec* p, uint32_t n, float* lohi /*6, pre-set to +inf/-inf*/) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+    for (; i < n; i += gridDim.x * blockDim.x) {
+        F4 q = p[i].pos_r;
+        lo[0] = fminf(lo[0], q.x); lo[1] = fminf(lo[1], q.y); lo[2] = fminf(lo[2], q.z);
+        hi[0] = fmaxf(hi[0], q.x); hi[1] = fmaxf(hi[1], q.y); hi[2] = fmaxf(hi[2], q.z);
+    }
+    for (int k = 0; k < 3; k++) {
+        for (int off = 32; off; off >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; k++) {  // float atomics through the ordered-int trick
+            int il = __float_as_int(lo[k]), ih = __float_as_int(hi[k]);
+            if (il >= 0) atomicMin((int*)&lohi[k], il); else atomicMax((unsigned*)&lohi[k], (unsigned)il);
+            if (ih >= 0) atomicMax((int*)&lohi[3 + k], ih); else atomicMin((unsigned*)&lohi[3 + k], (unsigned)ih);
+        }
+    }
+}
+__global__ void morton_kernel(const PhotonRec* p, uint32_t n, const float* lohi, uint64_t* keys, uint32_t* vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F4 q = p[i].pos_r;
+    float ex = fmaxf(lohi[3] - lohi[0], 1e-30f), ey = fmaxf(lohi[4] - lohi[1], 1e-30f), ez = fmaxf(lohi[5] - lohi[2], 1e-30f);
+    const float s = 2097151.f;
+    uint32_t x = uint32_t(fminf(fmaxf((q.x - lohi[0]) / ex * s, 0.f), s));
+    uint32_t y = uint32_t(fminf(fmaxf((q.y - lohi[1]) / ey * s, 0.f), s));
+    uint32_t z = uint32_t(fminf(fmaxf((q.z - lohi[2]) / ez * s, 0.f), s));
+    keys[i] = (expand21(x) << 2) | (expand21(y) << 1) | expand21(z);
+    vals[i] = i;
+}
+__global__ void gather_kernel(const PhotonRec* in, const uint32_t* perm, uint32_t n, PhotonRec* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PhotonRec r = in[perm[i]];
+    r.dir.w = __uint_as_float(perm[i]);
+    out[i] = r;
+}
+RPT_DEV int lcp(const uint64_t* keys, int n, int i, int j) {  // Karras' delta with index tie-break
+    if (j < 0 || j >= n) return -1;
+    uint64_t a = keys[i], b = keys[j];
+    if (a != b) return __clzll(a ^ b);
+    return 64 + __clz(uint32_t(i) ^ uint32_t(j));
+}
+// One thread per internal node (Karras 2012).  child < 0x80000000: internal index; else leaf | index.
+__global__ void karras_kernel(const uint64_t* keys, int n, uint32_t* left, uint32_t* right, uint32_t* parent_int,
+                              uint32_t* parent_leaf) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (lcp(keys, n, i, i + 1) - lcp(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = lcp(keys, n, i, i - d);
+    int lmax = 2;
+    while (lcp(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (lcp(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = lcp(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (lcp(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    int gamma = i + s * d + min(d, 0);
+    uint32_t lc, rc;
+    if (min(i, j) == gamma) { lc = BVH_LEAF | uint32_t(gamma); parent_leaf[gamma] = uint32_t(i); }
+    else { lc = uint32_t(gamma); parent_int[gamma] = uint32_t(i); }
+    if (max(i, j) == gamma + 1) { rc = BVH_LEAF | uint32_t(gamma + 1); parent_leaf[gamma + 1] = uint32_t(i); }
+    else { rc = uint32_t(gamma + 1); parent_int[gamma + 1] = uint32_t(i); }
+    left[i] = lc;
+    right[i] = rc;
+    if (i == 0) parent_int[0] = 0xFFFFFFFFu;
+}
+// Bottom-up boxes: the second thread to reach a node computes it.  box = 6 floats per internal node.
+__global__ void refit_kernel(const PhotonRec* p, int n, const uint32_t* left, const uint32_t* right,
+                             const uint32_t* parent_int, const uint32_t* parent_leaf, uint32_t* flags, float* box,
+                             int use_radius) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t node = parent_leaf[i];
+    for (;;) {
+        __threadfence();
+        if (atomicAdd(&flags[node], 1u) == 0u) return;  // first arrival: the sibling will continue
+        float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
+        uint32_t ch[2] = {left[node], right[node]};
+        for (int c = 0; c < 2; c++) {
+            if (ch[c] & BVH_LEAF) {
+                F4 q = p[ch[c] & 0x7FFFFFFFu].pos_r;
+                float r = use_radius ? q.w : 0.f;
+                lo[0] = fminf(lo[0], q.x - r); lo[1] = fminf(lo[1], q.y - r); lo[2] = fminf(lo[2], q.z - r);
+                hi[0] = fmaxf(hi[0], q.x + r); hi[1] = fmaxf(hi[1], q.y + r); hi[2] = fmaxf(hi[2], q.z + r);
+            } else {
+                const volatile float* b = box + size_t(ch[c]) * 6;
+                for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[k]); hi[k] = fmaxf(hi[k], b[3 + k]); }
+            }
+        }
+        float* b = box + size_t(node) * 6;
+        for (int k = 0; k < 3; k++) { b[k] = lo[k]; b[3 + k] = hi[k]; }
+        __threadfence();
+        uint32_t par = parent_int[node];
+        if (par == 0xFFFFFFFFu) return;
+        node = par;
+    }
+}
+__global__ void pack_kernel(const PhotonRec* p, int n, const uint32_t* left, const uint32_t* right, const float* box,
+                            BvhNode* nodes, int use_radius) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    BvhNode w;
+    uint32_t ch[2] = {left[i], right[i]};
+    float lo[2][3], hi[2][3];
+    for (int c = 0; c < 2; c++) {
+        if (ch[c] & BVH_LEAF) {
+            F4 q = p[ch[c] & 0x7FFFFFFFu].pos_r;
+            float r = use_radius ? q.w * (1.f + 1e-6f) : 0.f;
+            lo[c][0] = q.x - r; lo[c][1] = q.y - r; lo[c][2] = q.z - r;
+            hi[c][0] = q.x + r; hi[c][1] = q.y + r; hi[c][2] = q.z + r;
+        } else {
+            const float* b = box + size_t(ch[c]) * 6;
+            for (int k = 0; k < 3; k++) { lo[c][k] = b[k]; hi[c][k] = b[3 + k]; }
+        }
+    }
+    for (int k = 0; k < 3; k++) { w.lo0[k] = lo[0][k]; w.hi0[k] = hi[0][k]; w.lo1[k] = lo[1][k]; w.hi1[k] = hi[1][k]; }
+    w.e0 = ch[0];
+    w.e1 = ch[1];
+    w.pad0 = w.pad1 = 0;
+    nodes[i] = w;
+}
+
+RPT_DEV float box_dist2(const float lo[3], const float hi[3], V q) {
+    float dx = fmaxf(fmaxf(lo[0] - q.x, q.x - hi[0]), 0.f);
+    float dy = fmaxf(fmaxf(lo[1] - q.y, q.y - hi[1]), 0.f);
+    float dz = fmaxf(fmaxf(lo[2] - q.z, q.z - hi[2]), 0.f);
+    return fmaf(dx, dx, fmaf(dy, dy, dz * dz));
+}
+// k-nearest walk.  visit(index, d2) returns the current pruning bound (d2 of the k-th best, or +inf).
+template <class F>
+RPT_DEV void knn_walk(const BvhNode* nodes, const PhotonRec* p, uint32_t n, V q, float& bound, F&& visit) {
+    if (n == 0) return;
+    if (n == 1) {
+        V d = xyz(p[0].pos_r) - q;
+        bound = visit(0u, dot(d, d));
+        return;
+    }
+    uint32_t stack[64];
+    int sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        if (cur & BVH_LEAF) {
+            uint32_t idx = cur & 0x7FFFFFFFu;
+            V d = xyz(p[idx].pos_r) - q;
+            bound = visit(idx, dot(d, d));
+        } else {
+            const BvhNode nd = nodes[cur];
+            float d0 = box_dist2(nd.lo0, nd.hi0, q), d1 = box_dist2(nd.lo1, nd.hi1, q);
+            bool h0 = d0 <= bound, h1 = d1 <= bound;
+            if (h0 && h1) {
+                bool first0 = d0 <= d1;
+                if (sp < 64) stack[sp++] = first0 ? nd.e1 : nd.e0;
+                cur = first0 ? nd.e0 : nd.e1;
+                continue;
+            }
+            if (h0 || h1) {
+                cur = h0 ? nd.e0 : nd.e1;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+}
+// radius = distance to the k-th (k = 10, self included) nearest photon: src/photon.rs:214-232
+__global__ __launch_bounds__(256) void knn_radius_kernel(const BvhNode* nodes, PhotonRec* p, uint32_t n, float* radius_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V q = xyz(p[i].pos_r);
+    float best[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) best[k] = kInf;
+    float bound = kInf;
+    uint32_t found = 0;
+    knn_walk(nodes, p, n, q, bound, [&](uint32_t, float d2) {
+        float v = d2;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {  // sorted insertion, ascending
+            float lo = fminf(best[k], v);
+            v = fmaxf(best[k], v);
+            best[k] = lo;
+        }
+        found++;
+        return best[9];
+    });
+    float m = 0.f;  // max over the (up to 10) found; +inf slots are unfilled
+#pragma unroll
+    for (int k = 0; k < 10; k++) m = (best[k] < kInf) ? fmaxf(m, best[k]) : m;
+    radius_out[i] = __builtin_sqrtf(m);
+}
+__global__ void set_radius_kernel(PhotonRec* p, uint32_t n, const float* radius) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i].pos_r.w = radius[i];
+}
+
+// ------------------------------------------------------------------ camera pass
+struct QueryArgs {
+    RenderArgs r;
+    const BvhNode* s_nodes; const PhotonRec* s_ph; uint32_t n_s;   // surface photons (points)
+    const BvhNode* v_nodes; const PhotonRec* v_ph; uint32_t n_v;   // volume photons (spheres for the beam query)
+    uint32_t kind, gather_size, gather_size_volume;
+};
+
+// Ray vs. sphere-box LBVH: visit every leaf whose padded box the half-infinite ray hits.
+template <class F>
+RPT_DEV void beam_walk(const BvhNode* nodes, uint32_t n, V o, V d, F&& visit) {
+    if (n == 0) return;
+    if (n == 1) { visit(0u); return; }
+    const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
+    uint32_t stack[64];
+    int sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        if (cur & BVH_LEAF) {
+            visit(cur & 0x7FFFFFFFu);
+        } else {
+            const BvhNode nd = nodes[cur];
+            float n0, f0, n1, f1;
+            slab2(nd.lo0, nd.hi0, o, inv, n0, f0);
+            slab2(nd.lo1, nd.hi1, o, inv, n1, f1);
+            bool h0 = fmaxf(n0, 0.f) <= f0, h1 = fmaxf(n1, 0.f) <= f1;
+            if (h0 && h1) {
+                if (sp < 64) stack[sp++] = nd.e1;
+                cur = nd.e0;
+                continue;
+            }
+            if (h0 || h1) {
+                cur = h0 ? nd.e0 : nd.e1;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+}
+
+// get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
+// (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
+template <bool MEDIUM, bool BVH>
+__global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
+    extern __shared__ uint32_t dyn_lds[];
+    const RenderArgs& a = q.r;
+    const SceneView& sc = a.sc;
+    uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
+    const uint32_t K = q.gather_size;
+    // gather list: [K][256] floats then [K][256] indices, after the BVH stack region
+    float* gd = reinterpret_cast<float*>(dyn_lds + (BVH ? 32u * 256u : 0u)) + threadIdx.x;
+    uint32_t* gi = reinterpret_cast<uint32_t*>(gd - threadIdx.x + K * 256u) + threadIdx.x;
+    const float sigma_t = sc.sigma_a + sc.sigma_s;
+    const V mcol0 = mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);  // medium.color(dummy_pos = 0)
+    const V env = mk(sc.env[0], sc.env[1], sc.env[2]);
+
+    V acc = mk(0, 0, 0);
+    uint32_t slab_idx = 0, s = 0, s_end = 0, pix = 0;
+    float xn = 0.f, yn = 0.f;
+    bool alive = true, have_item = false;
+    uint32_t pool_next = 0, pool_end = 0;
+    uint32_t c0 = 0, c1 = 0;
+    for (;;) {
+        bool want = alive && s >= s_end;
+        if (__any(want)) {
+            if (want && have_item) {
+                reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+                have_item = false;
+            }
+            for (;;) {
+                const uint64_t m = __ballot(want);
+                if (m == 0) break;
+                if (pool_next == pool_end) {
+                    unsigned long long base = 0;
+                    if ((threadIdx.x & 63u) == 0) base = atomicAdd(a.queue, 64ull);
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(base));
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(base >> 32));
+                    if (hi != 0 || lo >= a.n_items) {
+                        if (want) alive = false;
+                        break;
+                    }
+                    pool_next = lo;
+                    pool_end = min(lo + 64u, a.n_items);
+                }
+                const uint32_t take = min(uint32_t(__popcll(m)), pool_end - pool_next);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+                const uint32_t item = pool_next + rank;
+                const bool got = want && rank < take;
+                pool_next += take;
+                if (got) {
+                    uint32_t chunk = item / a.n_owned, p = item - chunk * a.n_owned;
+                    uint32_t tl = p >> 10, within = p & 1023u, sb = within >> 6, l = within & 63u;
+                    uint32_t tile = a.tiles[tl];
+                    uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+                    uint32_t x = tx * 32u + (sb & 3u) * 8u + (l & 7u), y = ty * 32u + (sb >> 2) * 8u + (l >> 3);
+                    if (x < a.width && y < a.height) {
+                        want = false;
+                        have_item = true;
+                        slab_idx = item;
+                        acc = mk(0, 0, 0);
+                        s = chunk * a.chunk_spp;
+                        s_end = min(s + a.chunk_spp, a.iterations);
+                        pix = y * a.width + x;
+                        xn = (float(2u * x + 1u) - float(a.width)) * a.inv_dim;
+                        yn = (float(2u * (a.height - y) - 1u) - float(a.height)) * a.inv_dim;
+                    }
+                }
+            }
+        }
+        if (!__any(alive)) break;
+        if (!alive) continue;
+
+        // ---- one camera sample
+        Rng rng;
+        rng.seed(a.seed_mixed, pix, a.sample_offset + s);
+        s++;
+        float dx = rng.range(-a.inv_dim, a.inv_dim), dy = rng.range(-a.inv_dim, a.inv_dim);
+        V ro, rd;
+        cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
+        const V wo = -normalize(rd);
+        const float tmin = ray_tmin_p(ro);
+        float t = kInf;
+        uint32_t code = CODE_MISS;
+        closest_hit<BVH, false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
+        const bool hit = code != CODE_MISS;
+        if (!hit && !MEDIUM) {
+            acc = acc + env;  // src/photon.rs:597
+            continue;
+        }
+        V color = mk(0, 0, 0);
+        if (MEDIUM) {  // beam x point volume estimate, src/photon.rs:439-502
+            V vc = mk(0, 0, 0);
+            const float phase = sc.medium_phase;
+            beam_walk(q.v_nodes, q.n_v, ro, rd, [&](uint32_t idx) {
+                const PhotonRec ph = q.v_ph[idx];
+                V otc = xyz(ph.pos_r) - ro;
+                float r2 = ph.pos_r.w * ph.pos_r.w;
+                float disk = dot(otc, rd);
+                V dv = fma3(disk, rd, ro) - xyz(ph.pos_r);
+                float dist2 = dot(dv, dv);
+                bool ok = disk > 0.f && dist2 < r2 && !(hit && dot(otc, otc) > t * t);
+                if (ok) {
+                    float tmp = 1.f - dist2 * rcp(r2);
+                    float w = (3.f * kInvPi) * tmp * tmp * rcp(r2) * __expf(-sigma_t * disk) * phase;
+                    vc = fma3(w, xyz(ph.pow), vc);
+                }
+            });
+            color = vc * mcol0;
+        }
+        if (hit) {  // surface estimate, src/photon.rs:327-375
+            V n;
+            uint32_t obj;
+            finalize_hit(sc, ro, rd, tmin, t, code, n, obj);
+            const Mat mat = load_mat(sc, obj);
+            const V x = fma3(t, rd, ro);
+            uint32_t found = 0;
+            float bound = kInf, worst = 0.f;
+            uint32_t worst_slot = 0;
+            if (K > 0) {
+                knn_walk(q.s_nodes, q.s_ph, q.n_s, x, bound, [&](uint32_t idx, float d2) {
+                    if (found < K) {
+                        gd[found * 256u] = d2;
+                        gi[found * 256u] = idx;
+                        found++;
+                        if (found == K) {  // locate the current worst
+                            worst = -1.f;
+                            for (uint32_t k = 0; k < K; k++) {
+                                float v = gd[k * 256u];
+                                if (v > worst) { worst = v; worst_slot = k; }
+                            }
+                            return worst;
+                        }
+                        return kInf;
+                    }
+                    if (d2 < worst) {
+                        gd[worst_slot * 256u] = d2;
+                        gi[worst_slot * 256u] = idx;
+                        worst = -1.f;
+                        for (uint32_t k = 0; k < K; k++) {
+                            float v = gd[k * 256u];
+                            if (v > worst) { worst = v; worst_slot = k; }
+                        }
+                    }
+                    return worst;
+                });
+            }
+            float max_d2 = 0.f;
+            for (uint32_t k = 0; k < found; k++) max_d2 = fmaxf(max_d2, gd[k * 256u]);
+            V sc_col = mat_emit(mat) * mat_color(mat);
+            for (uint32_t k = 0; k < found; k++) {
+                const PhotonRec ph = q.s_ph[gi[k * 256u]];
+                V disp = x - xyz(ph.pos_r);
+                float len2 = dot(disp, disp);
+                float ilen = rsq(len2);
+                V pd = ilen * disp;
+                V po = xyz(ph.pos_r);
+                float len = len2 * ilen;
+                float ts = kInf;
+                uint32_t cs = CODE_MISS;
+                closest_hit<BVH, false>(sc, po, pd, ray_tmin_p(po), ts, cs, stk, 256, c0, c1);
+                // :357-361 "something lies between the photon and the query point".  A hit inside the
+                // query point's own tangent plane is the grazing ray meeting its own surface: fp64 rejects
+                // it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
+                V hp = fma3(ts, pd, po) - x;
+                bool own_plane = fabsf(dot(hp, n)) <= 1e-4f * len;
+                bool blocked = cs != CODE_MISS && !own_plane && ts < len * (1.f - 1e-3f);
+                if (!blocked && len2 > 0.f) {
+                    V pdir = xyz(ph.dir);
+                    float c = fminf(fmaxf(dot(pdir, n), 0.f), 1.f);
+                    sc_col = fma3(c, bsdf(mat, n, wo, pdir) * xyz(ph.pow), sc_col);
+                } else if (!(len2 > 0.f)) {  // query point coincides with the photon: no ray to trace
+                    V pdir = xyz(ph.dir);
+                    float c = fminf(fmaxf(dot(pdir, n), 0.f), 1.f);
+                    sc_col = fma3(c, bsdf(mat, n, wo, pdir) * xyz(ph.pow), sc_col);
+                }
+            }
+            sc_col = (kInvPi * rcp(max_d2)) * sc_col;
+            if (MEDIUM) sc_col = __expf(-sigma_t * t) * sc_col;  // :610-611
+            color = color + sc_col;
+        }
+        acc = acc + color;
+    }
+}
+
+}  // namespace rptg
+
+// ============================================================================ host side
+using namespace rptg;
+
+namespace {
+struct DevLbvh {
+    BvhNode* nodes = nullptr;
+    PhotonRec* sorted = nullptr;
+    uint32_t n = 0;
+};
+struct PhotonMapDev {
+    int device = 0;
+    int kind = RPT_PHOTON_POINT_BEAM;
+    uint64_t photon_count = 0;
+    DevLbvh surf, vol;
+    double build_ms[4] = {0, 0, 0, 0};  // shoot, sort+build, radii, total
+    void release() {
+        (void)hipSetDevice(device);
+        (void)hipFree(surf.nodes); (void)hipFree(surf.sorted);
+        (void)hipFree(vol.nodes); (void)hipFree(vol.sorted);
+        surf = DevLbvh{};
+        vol = DevLbvh{};
+    }
+};
+struct Tmp {
+    std::vector<void*> ptrs;
+    ~Tmp() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T** p, size_t n) {
+        hipError_t e = hipMalloc((void**)p, std::max<size_t>(n * sizeof(T), 64));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+
+// Build the LBVH of `n` photons in `raw` (consumed: the sorted copy is kept).  radius_k > 0: also
+// compute the k-NN radii and refit the boxes with them (sphere map for the beam query).
+int build_lbvh(PhotonRec* raw, uint32_t n, bool with_radius, DevLbvh& out, hipStream_t st) {
+    out = DevLbvh{};
+    out.n = n;
+    if (n == 0) return RPT_OK;
+    Tmp tmp;
+    float* lohi;
+    uint64_t *keys, *keys2;
+    uint32_t *vals, *vals2, *left, *right, *par_i, *par_l, *flags;
+    float* box;
+    RPTI_HIP_TRY(tmp.alloc(&lohi, 6));
+    RPTI_HIP_TRY(tmp.alloc(&keys, n));
+    RPTI_HIP_TRY(tmp.alloc(&keys2, n));
+    RPTI_HIP_TRY(tmp.alloc(&vals, n));
+    RPTI_HIP_TRY(tmp.alloc(&vals2, n));
+    RPTI_HIP_TRY(tmp.alloc(&left, n));
+    RPTI_HIP_TRY(tmp.alloc(&right, n));
+    RPTI_HIP_TRY(tmp.alloc(&par_i, n));
+    RPTI_HIP_TRY(tmp.alloc(&par_l, n));
+    RPTI_HIP_TRY(tmp.alloc(&flags, n));
+    RPTI_HIP_TRY(tmp.alloc(&box, size_t(n) * 6));
+    const float inf = std::numeric_limits<float>::infinity();
+    float init[6] = {inf, inf, inf, -inf, -inf, -inf};
+    RPTI_HIP_TRY(hipMemcpyAsync(lohi, init, sizeof(init), hipMemcpyHostToDevice, st));
+    uint32_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(bounds_kernel, dim3(std::min(blocks, 1024u)), dim3(256), 0, st, raw, n, lohi);
+    hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(256), 0, st, raw, n, lohi, keys, vals);
+    size_t temp_bytes = 0;
+    RPTI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys2, vals, vals2, int(n), 0, 63, st));
+    void* temp;
+    RPTI_HIP_TRY(tmp.alloc((char**)&temp, temp_bytes));
+    RPTI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, int(n), 0, 63, st));
+    RPTI_HIP_TRY(hipMalloc((void**)&out.sorted, size_t(n) * sizeof(PhotonRec)));
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, raw, vals2, n, out.sorted);
+    if (n >= 2) {
+        RPTI_HIP_TRY(hipMalloc((void**)&out.nodes, size_t(n - 1) * sizeof(BvhNode)));
+        hipLaunchKernelGGL(karras_kernel, dim3(blocks), dim3(256), 0, st, keys2, int(n), left, right, par_i, par_l);
+        RPTI_HIP_TRY(hipMemsetAsync(flags, 0, size_t(n) * 4, st));
+        hipLaunchKernelGGL(refit_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, par_i, par_l, flags, box, 0);
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, out.nodes, 0);
+    }
+    if (with_radius) {
+        float* radius;
+        RPTI_HIP_TRY(tmp.alloc(&radius, n));
+        hipLaunchKernelGGL(knn_radius_kernel, dim3(blocks), dim3(256), 0, st, out.nodes, out.sorted, n, radius);
+        hipLaunchKernelGGL(set_radius_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, n, radius);
+        if (n >= 2) {
+            RPTI_HIP_TRY(hipMemsetAsync(flags, 0, size_t(n) * 4, st));
+            hipLaunchKernelGGL(refit_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, par_i, par_l, flags, box, 1);
+            hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, out.nodes, 1);
+        }
+    }
+    RPTI_HIP_TRY(hipGetLastError());
+    RPTI_HIP_TRY(hipStreamSynchronize(st));
+    return RPT_OK;
+}
+
+template <bool W>
+hipError_t launch_shoot(const ShootArgs& a, bool medium, bool bvh, int blocks, hipStream_t st) {
+    size_t lds = bvh ? 32u * 256u * 4u : 0;
+    if (medium) {
+        if (bvh) hipLaunchKernelGGL((photon_shoot_kernel<true, true, W>), dim3(blocks), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((photon_shoot_kernel<true, false, W>), dim3(blocks), dim3(256), lds, st, a);
+    } else {
+        if (bvh) hipLaunchKernelGGL((photon_shoot_kernel<false, true, W>), dim3(blocks), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((photon_shoot_kernel<false, false, W>), dim3(blocks), dim3(256), lds, st, a);
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
+void rpti::photon_release(void* p) {
+    auto* m = static_cast<PhotonMapDev*>(p);
+    if (m) {
+        m->release();
+        delete m;
+    }
+}
+
+extern "C" {
+
+int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, double watts, uint64_t seed) {
+    if (!s) return rpti::fail(RPT_ERR_INVALID, "null scene");
+    rpti::SceneDev sd = rpti::scene_dev(s);
+    if (!sd.committed) return rpti::fail(RPT_ERR_STATE, "rpt_scene_commit must be called first");
+    if (photon_count == 0) return rpti::fail(RPT_ERR_INVALID, "photon_count must be > 0");
+    if (kind != RPT_PHOTON_POINT_BEAM)
+        return rpti::fail(RPT_ERR_UNSUPPORTED, "only the point-beam photon map (photon_point_query_beam_render) is built on the device");
+    if (sd.first_object_light < 0)
+        return rpti::fail(RPT_ERR_INVALID, "Only found non-object lights while photon mapping");  // the reference's panic
+    RPTI_HIP_TRY(hipSetDevice(sd.device));
+    void*& slot = rpti::photon_slot(s);
+    if (slot) {
+        rpti::photon_release(slot);
+        slot = nullptr;
+    }
+    auto* pm = new PhotonMapDev();
+    pm->device = sd.device;
+    pm->kind = kind;
+    pm->photon_count = photon_count;
+    hipStream_t st = nullptr;
+    hipEvent_t e0, e1, e2;
+    RPTI_HIP_TRY(hipEventCreate(&e0));
+    RPTI_HIP_TRY(hipEventCreate(&e1));
+    RPTI_HIP_TRY(hipEventCreate(&e2));
+    Tmp tmp;
+    ShootArgs a{};
+    a.sc = sd.view;
+    a.n_photons = photon_count;
+    a.seed_mixed = rpti::seed_mix(seed);
+    a.power = float(watts / double(photon_count));
+    a.light_index = uint32_t(sd.first_object_light);
+    RPTI_HIP_TRY(tmp.alloc(&a.cnt_s, photon_count));
+    RPTI_HIP_TRY(tmp.alloc(&a.cnt_v, photon_count));
+    const bool medium = sd.view.has_medium != 0, bvh = sd.view.n_mesh != 0;
+    int blocks = int(std::min<uint64_t>((photon_count + 255) / 256, uint64_t(sd.n_cus) * 8));
+    RPTI_HIP_TRY(hipEventRecord(e0, st));
+    RPTI_HIP_TRY(launch_shoot<false>(a, medium, bvh, blocks, st));
+    std::vector<uint32_t> cs(photon_count), cv(photon_count);
+    RPTI_HIP_TRY(hipMemcpy(cs.data(), a.cnt_s, photon_count * 4, hipMemcpyDeviceToHost));
+    RPTI_HIP_TRY(hipMemcpy(cv.data(), a.cnt_v, photon_count * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> os(photon_count), ov(photon_count);
+    uint64_t ts = 0, tv = 0;
+    for (uint64_t i = 0; i < photon_count; i++) {
+        os[i] = ts; ts += cs[i];
+        ov[i] = tv; tv += cv[i];
+    }
+    if (ts >= (1ull << 31) || tv >= (1ull << 31)) { delete pm; return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons"); }
+    uint64_t *d_os, *d_ov;
+    PhotonRec *raw_s, *raw_v;
+    RPTI_HIP_TRY(tmp.alloc(&d_os, photon_count));
+    RPTI_HIP_TRY(tmp.alloc(&d_ov, photon_count));
+    RPTI_HIP_TRY(tmp.alloc(&raw_s, ts));
+    RPTI_HIP_TRY(tmp.alloc(&raw_v, tv));
+    RPTI_HIP_TRY(hipMemcpy(d_os, os.data(), photon_count * 8, hipMemcpyHostToDevice));
+    RPTI_HIP_TRY(hipMemcpy(d_ov, ov.data(), photon_count * 8, hipMemcpyHostToDevice));
+    a.off_s = d_os;
+    a.off_v = d_ov;
+    a.surf = raw_s;
+    a.vol = raw_v;
+    RPTI_HIP_TRY(launch_shoot<true>(a, medium, bvh, blocks, st));
+    RPTI_HIP_TRY(hipEventRecord(e1, st));
+    int rc = build_lbvh(raw_s, uint32_t(ts), false, pm->surf, st);
+    if (rc == RPT_OK) rc = build_lbvh(raw_v, uint32_t(tv), true, pm->vol, st);
+    if (rc != RPT_OK) {
+        pm->release();
+        delete pm;
+        return rc;
+    }
+    RPTI_HIP_TRY(hipEventRecord(e2, st));
+    RPTI_HIP_TRY(hipEventSynchronize(e2));
+    float m0 = 0, m1 = 0;
+    (void)hipEventElapsedTime(&m0, e0, e1);
+    (void)hipEventElapsedTime(&m1, e1, e2);
+    pm->build_ms[0] = m0;
+    pm->build_ms[1] = m1;
+    pm->build_ms[3] = m0 + m1;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    slot = pm;
+    return RPT_OK;
+}
+
+int rpt_photon_map_stats(rpt_scene* s, uint64_t out[8]) {
+    if (!s || !out) return rpti::fail(RPT_ERR_INVALID, "null argument");
+    auto* pm = static_cast<PhotonMapDev*>(rpti::photon_slot(s));
+    if (!pm) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
+    out[0] = pm->surf.n;
+    out[1] = pm->vol.n;
+    out[2] = pm->photon_count;
+    out[3] = uint64_t(pm->build_ms[0] * 1000.0);  // microseconds: shooting (both passes)
+    out[4] = uint64_t(pm->build_ms[1] * 1000.0);  // microseconds: sort + LBVH + radii
+    out[5] = out[6] = out[7] = 0;
+    return RPT_OK;
+}
+
+// which: 0 surface, 1 volume.  out: n * 10 floats in ORIGINAL (shooting) order: position, direction,
+// power, radius.
+int rpt_photon_map_download(rpt_scene* s, int32_t which, float* out, uint64_t capacity) {
+    if (!s || !out) return rpti::fail(RPT_ERR_INVALID, "null argument");
+    auto* pm = static_cast<PhotonMapDev*>(rpti::photon_slot(s));
+    if (!pm) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
+    const DevLbvh& l = which == 0 ? pm->surf : pm->vol;
+    if (capacity < l.n) return rpti::fail(RPT_ERR_INVALID, "output buffer too small");
+    std::vector<PhotonRec> h(l.n);
+    if (l.n) RPTI_HIP_TRY(hipMemcpy(h.data(), l.sorted, size_t(l.n) * sizeof(PhotonRec), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < l.n; i++) {
+        uint32_t orig;
+        std::memcpy(&orig, &h[i].dir.w, 4);
+        float* o = out + size_t(orig) * 10;
+        o[0] = h[i].pos_r.x; o[1] = h[i].pos_r.y; o[2] = h[i].pos_r.z;
+        o[3] = h[i].dir.x; o[4] = h[i].dir.y; o[5] = h[i].dir.z;
+        o[6] = h[i].pow.x; o[7] = h[i].pow.y; o[8] = h[i].pow.z;
+        o[9] = h[i].pos_r.w;
+    }
+    return RPT_OK;
+}
+
+static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint64_t gather_size,
+                              uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed, uint32_t sample_offset,
+                              double* d_out, hipStream_t st) {
+    auto* pm = s ? static_cast<PhotonMapDev*>(rpti::photon_slot(s)) : nullptr;
+    if (!pm) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
+    if (gather_size > 56) return rpti::fail(RPT_ERR_UNSUPPORTED, "gather_size > 56 does not fit the LDS gather list");
+    QueryArgs q{};
+    int rc = rpti::prepare_render(s, cam, prm, num_samples, seed, sample_offset, q.r);
+    if (rc) return rc;
+    q.s_nodes = pm->surf.nodes; q.s_ph = pm->surf.sorted; q.n_s = pm->surf.n;
+    q.v_nodes = pm->vol.nodes; q.v_ph = pm->vol.sorted; q.n_v = pm->vol.n;
+    q.kind = uint32_t(pm->kind);
+    q.gather_size = uint32_t(gather_size);
+    q.gather_size_volume = uint32_t(gather_size_volume);
+    const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_mesh != 0;
+    const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + size_t(gather_size) * 256u * 8u;
+    auto launch = [&](const RenderArgs& ra, int nb, hipStream_t stream) -> hipError_t {
+        QueryArgs qq = q;
+        qq.r = ra;
+        if (medium) {
+            if (bvh) hipLaunchKernelGGL((photon_query_kernel<true, true>), dim3(nb), dim3(256), lds, stream, qq);
+            else hipLaunchKernelGGL((photon_query_kernel<true, false>), dim3(nb), dim3(256), lds, stream, qq);
+        } else {
+            if (bvh) hipLaunchKernelGGL((photon_query_kernel<false, true>), dim3(nb), dim3(256), lds, stream, qq);
+            else hipLaunchKernelGGL((photon_query_kernel<false, false>), dim3(nb), dim3(256), lds, stream, qq);
+        }
+        return hipGetLastError();
+    };
+    int bpc = int(std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / std::max<size_t>(lds, 1))));
+    return rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch);
+}
+
+int rpt_photon_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint64_t gather_size,
+                             uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed, uint32_t sample_offset,
+                             double* out_rgb) {
+    if (!s || !cam || !prm || !out_rgb) return rpti::fail(RPT_ERR_INVALID, "null argument");
+    size_t bytes = size_t(prm->width) * prm->height * 24;
+    double* d_out = rpti::scratch_out(s, bytes);
+    if (!d_out) return rpti::fail(RPT_ERR_DEVICE, "out of device memory");
+    int rc = photon_render_impl(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset, d_out, nullptr);
+    if (rc) return rc;
+    RPTI_HIP_TRY(hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+
+int rpt_photon_render_sample_device(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm,
+                                    uint64_t gather_size, uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed,
+                                    uint32_t sample_offset, void* d_out_rgb, void* hip_stream) {
+    if (!s || !cam || !prm || !d_out_rgb) return rpti::fail(RPT_ERR_INVALID, "null argument");
+    return photon_render_impl(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset,
+                              static_cast<double*>(d_out_rgb), static_cast<hipStream_t>(hip_stream));
+}
+
+}  // extern "C"

@@ -11,16 +11,31 @@
 #include <vector>
 
 #include "../../include/rpt_hip.h"
+#include "host_internal.h"
 #include "kernels.h"
 
 using namespace rptg;
 
 // ---------------------------------------------------------------------------- errors / options
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
+namespace rpti {
+int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+}  // namespace rpti
+using rpti::fail;
+namespace rpti {
+uint64_t seed_mix(uint64_t seed) {
+    uint64_t x = seed + 0x9E3779B97F4A7C15ULL;
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return x;
+}
+}  // namespace rpti
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e__ = (expr);                                                                   \
@@ -119,7 +134,7 @@ D3 hex_color(uint32_t v) {  // src/color.rs:10-15
     auto ch = [](uint32_t c) { return std::pow(double(c) / 255.0, 2.2); };
     return {ch((v >> 16) & 0xff), ch((v >> 8) & 0xff), ch(v & 0xff)};
 }
-uint64_t mix64(uint64_t x) {
+uint64_t mix64_(uint64_t x) {
     x ^= x >> 30;
     x *= 0xBF58476D1CE4E5B9ULL;
     x ^= x >> 27;
@@ -127,7 +142,7 @@ uint64_t mix64(uint64_t x) {
     x ^= x >> 31;
     return x;
 }
-uint64_t seed_mix(uint64_t seed) { return mix64(seed + 0x9E3779B97F4A7C15ULL); }
+uint64_t seed_mix(uint64_t seed) { return rpti::seed_mix(seed); }
 
 // ---------------------------------------------------------------------------- host scene
 struct HShape {
@@ -312,6 +327,7 @@ struct rpt_scene {
     int last_blocks = 0;
     uint64_t prims_per_ray = 0;
     uint64_t stats[16] = {0};
+    void* photon = nullptr;  // PhotonMapDev*, owned by photon.hip
     // tile cache key
     uint32_t tk_w = 0, tk_h = 0, tk_rank = 0, tk_count = 0, n_tiles = 0, tiles_x = 0;
 };
@@ -386,6 +402,7 @@ void rpt_scene_destroy(rpt_scene* s) {
         (void)hipFree(s->d_out);
         for (auto& e : s->ev)
             if (e) (void)hipEventDestroy(e);
+        if (s->photon) rpti::photon_release(s->photon);
     }
     delete s;
 }
@@ -716,6 +733,8 @@ int rpt_scene_commit(rpt_scene* s, int device) {
             double e = has ? o.mat.emittance : 0.0;
             L.color = F4{float(has ? o.mat.albedo[0] * e : 0.0), float(has ? o.mat.albedo[1] * e : 0.0),
                          float(has ? o.mat.albedo[2] * e : 0.0), 0.f};
+            L.albedo = F4{float(has ? o.mat.albedo[0] : 0.0), float(has ? o.mat.albedo[1] : 0.0),
+                          float(has ? o.mat.albedo[2] : 0.0), 0.f};
             Xf x;
             make_xf(o.shape.d, x);
             LightXf gx;
@@ -872,8 +891,8 @@ extern "C" int64_t rpt_shard_tiles(uint32_t width, uint32_t height, uint32_t sha
     return n;
 }
 
-static int prepare_render(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
-                          uint64_t seed, uint32_t sample_offset, RenderArgs& a) {
+extern "C++" int rpti::prepare_render(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
+                         uint64_t seed, uint32_t sample_offset, RenderArgs& a) {
     if (!s || !cam || !prm) return fail(RPT_ERR_INVALID, "null argument");
     if (!s->committed) return fail(RPT_ERR_STATE, "rpt_scene_commit must be called before rendering");
     if (prm->width == 0 || prm->height == 0 || iterations == 0) return fail(RPT_ERR_INVALID, "empty render");
@@ -943,26 +962,22 @@ static int prepare_render(rpt_scene* s, const rpt_camera* cam, const rpt_render_
     return RPT_OK;
 }
 
-static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st) {
+extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st,
+                         int blocks_per_cu, const std::function<hipError_t(const RenderArgs&, int, hipStream_t)>& launch) {
     HIP_TRY(hipMemsetAsync(a.queue, 0, 8, st));
     if (a.counters) HIP_TRY(hipMemsetAsync(a.counters, 0, 64, st));
     uint32_t shard_count = prm->shard_count == 0 ? 1 : prm->shard_count;
     if (shard_count > 1) HIP_TRY(hipMemsetAsync(d_out, 0, size_t(prm->width) * prm->height * 24, st));
     if (a.n_items) {
-        int bpc = int(g_opt_blocks_per_cu);
-        if (bpc <= 0) {
-            HIP_TRY(render_occupancy(a.sc.has_medium != 0, a.sc.n_mesh != 0, &bpc));
-            if (bpc < 1) bpc = 1;
-        }
         uint64_t want = (uint64_t(a.n_items) + 255) / 256;
-        int n_blocks = int(std::min<uint64_t>(uint64_t(s->n_cus) * bpc, want));
+        int n_blocks = int(std::min<uint64_t>(uint64_t(s->n_cus) * std::max(blocks_per_cu, 1), want));
         s->last_blocks = n_blocks;
         if (g_opt_timing) {
             for (auto& e : s->ev)
                 if (!e) HIP_TRY(hipEventCreate(&e));
             HIP_TRY(hipEventRecord(s->ev[0], st));
         }
-        HIP_TRY(launch_render(a, n_blocks, st));
+        HIP_TRY(launch(a, n_blocks, st));
         if (g_opt_timing) HIP_TRY(hipEventRecord(s->ev[1], st));
         HIP_TRY(launch_resolve(a, std::pow(2.0, prm->exposure_value), d_out, st));
         if (g_opt_timing) {
@@ -971,6 +986,32 @@ static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderAr
         }
     }
     return RPT_OK;
+}
+static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st) {
+    int bpc = int(g_opt_blocks_per_cu);
+    if (bpc <= 0) {
+        HIP_TRY(render_occupancy(a.sc.has_medium != 0, a.sc.n_mesh != 0, &bpc));
+        if (bpc < 1) bpc = 1;
+    }
+    return rpti::run_persistent(s, prm, a, d_out, st, bpc,
+                                [](const RenderArgs& ra, int nb, hipStream_t stream) { return launch_render(ra, nb, stream); });
+}
+extern "C++" rpti::SceneDev rpti::scene_dev(rpt_scene* s) {
+    int first = -1;
+    for (size_t i = 0; i < s->lights.size(); i++)
+        if (s->lights[i].kind == L_OBJECT) { first = int(i); break; }
+    return SceneDev{s->committed, s->device, s->n_cus, s->view, first};
+}
+extern "C++" void*& rpti::photon_slot(rpt_scene* s) { return s->photon; }
+extern "C++" double* rpti::scratch_out(rpt_scene* s, size_t bytes) {
+    if (bytes > s->out_cap) {
+        if (s->d_out) (void)hipFree(s->d_out);
+        s->d_out = nullptr;
+        s->out_cap = 0;
+        if (hipMalloc((void**)&s->d_out, bytes) != hipSuccess) return nullptr;
+        s->out_cap = bytes;
+    }
+    return s->d_out;
 }
 static int fetch_counters(rpt_scene* s, const RenderArgs& a) {
     std::memset(s->last_counters, 0, sizeof(s->last_counters));
@@ -985,7 +1026,7 @@ int rpt_render_sample_device(rpt_scene* s, const rpt_camera* cam, const rpt_rend
                              uint64_t seed, uint32_t sample_offset, void* d_out_rgb, void* hip_stream) {
     if (!d_out_rgb) return fail(RPT_ERR_INVALID, "null output");
     RenderArgs a{};
-    int rc = prepare_render(s, cam, prm, iterations, seed, sample_offset, a);
+    int rc = rpti::prepare_render(s, cam, prm, iterations, seed, sample_offset, a);
     if (rc) return rc;
     rc = run_render(s, prm, a, static_cast<double*>(d_out_rgb), static_cast<hipStream_t>(hip_stream));
     if (rc) return rc;
@@ -1000,7 +1041,7 @@ int rpt_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_para
                       uint64_t seed, uint32_t sample_offset, double* out_rgb) {
     if (!out_rgb) return fail(RPT_ERR_INVALID, "null output");
     RenderArgs a{};
-    int rc = prepare_render(s, cam, prm, iterations, seed, sample_offset, a);
+    int rc = rpti::prepare_render(s, cam, prm, iterations, seed, sample_offset, a);
     if (rc) return rc;
     size_t bytes = size_t(prm->width) * prm->height * 24;
     if (bytes > s->out_cap) {
