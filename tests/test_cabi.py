@@ -36,7 +36,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_is_built_for_gfx950_only():
     data = open(_lib.LIB_PATH, "rb").read()
-    assert b"gfx950" in data and b"gfx942" not in data and b"gfx90a" not in data
+    # code objects in the fat binary are tagged hipv4-amdgcn-amd-amdhsa--<arch> (bare arch names also
+    # occur in rocPRIM's host-side dispatch tables and mean nothing)
+    targets = set(re.findall(rb"hipv4-amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", data))
+    assert targets == {b"gfx950"}
 
 
 def test_argument_validation_needs_no_gpu():

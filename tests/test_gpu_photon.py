@@ -1,0 +1,112 @@
+"""GPU photon mapping (config C4: photon_point_query_beam_render) against the oracle's
+restatement of src/photon.rs on the same seeds."""
+import numpy as np
+import pytest
+
+from rpt_amd import Light, Material, Object, Renderer, RptError, Scene, polygon, scenes, vec3
+from tests.util import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(scene):
+    from oracle.pyoracle import OracleScene
+    return OracleScene(scene)
+
+
+def _match(g, e):
+    from scipy.spatial import cKDTree
+    tree = cKDTree(g[:, :3].astype(np.float64))
+    d, j = tree.query(e[:, :3])
+    ok = d < 1e-4 * (1 + np.abs(e[:, :3]).max(axis=1))
+    return ok, j
+
+
+@pytest.mark.parametrize("name", ["C4", "C2"])
+def test_photon_shooting_and_radii_match_oracle(name):
+    scene, cam, cfg = scenes.CONFIGS[name]()
+    n = 20000
+    watts = 14.65 * n
+    r = Renderer(scene, cam).watts(watts).seed(7)
+    st = r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    pm = _oracle(scene).photon_map(n, 1, watts, 20, 3, seed=7, robust=1)
+    for which in (0, 1):
+        g, e = r.photon_map_download(which), pm.photons(which)
+        assert len(g) == st["surface" if which == 0 else "volume"]
+        if name == "C2" and which == 1:
+            assert len(g) == 0 and len(e) == 0             # no medium, no volume photons
+            continue
+        assert abs(len(g) - len(e)) < 0.01 * len(e)         # a few chains flip a decision in fp32
+        ok, j = _match(g, e)
+        assert ok.mean() > 0.998
+        gp, ep = g[j[ok]], e[ok]
+        # (two different photons can share a position: a matched pair is not always the same photon)
+        assert np.quantile(np.abs(gp[:, 3:6] - ep[:, 3:6]).max(axis=1), 0.999) < 1e-5          # incoming direction
+        assert np.quantile((np.abs(gp[:, 6:9] - ep[:, 6:9]) / (np.abs(ep[:, 6:9]) + 1e-12)).max(axis=1), 0.999) < 1e-4
+        if which == 1:
+            rr = np.abs(gp[:, 9] - ep[:, 9]) / ep[:, 9]
+            assert np.median(rr) < 1e-5 and (rr > 1e-2).mean() < 0.03                    # 10-NN gather radius
+
+
+def test_photon_map_is_deterministic_and_seeded():
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    r = Renderer(scene, cam).watts(1000.0).seed(3)
+    r.photon_map_build(5000, 1)
+    a0, a1 = r.photon_map_download(0), r.photon_map_download(1)
+    r.photon_map_build(5000, 1)
+    assert np.array_equal(a0, r.photon_map_download(0)) and np.array_equal(a1, r.photon_map_download(1))
+    r.seed(4).photon_map_build(5000, 1)
+    assert not np.array_equal(a0[:100], r.photon_map_download(0)[:100])
+
+
+@pytest.mark.parametrize("name,tol", [("C4", 5e-3), ("C2", 3e-2)])
+def test_photon_camera_pass_matches_oracle(name, tol):
+    scene, cam, cfg = scenes.CONFIGS[name]()
+    n, size, spp = 20000, 64, 4
+    watts = 14.65 * n
+    r = Renderer(scene, cam).width(size).height(size).watts(watts).gather_size(20).gather_size_volume(3).seed(0)
+    r.photon_map_build(n, 1)
+    got = r.photon_sample_array(spp)
+    pm = _oracle(scene).photon_map(n, 1, watts, 20, 3, seed=0, robust=1)
+    exp = pm.render(cam, size, size, spp, seed=0)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert rel_rms(got, exp) < tol                           # a handful of fp32-flipped photon chains move k-NN sets
+    assert abs(got.mean() - exp.mean()) / exp.mean() < 2e-3
+    d = np.abs(got - exp).sum(axis=1) / (np.abs(exp).sum(axis=1) + 1e-9)
+    assert (d > 0.01).mean() < 0.03
+
+
+def test_photon_render_builder_entry_point_and_sharding():
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    size = 64
+    def make(rank=0, count=1):
+        s2, c2, _ = scenes.CONFIGS["C4"]()
+        return Renderer(s2, c2).width(size).height(size).num_samples(2).gather_size(20).gather_size_volume(3) \
+            .watts(14.65 * 4000).seed(1).shard(rank, count)
+    img = make().photon_point_query_beam_render(4000)        # src/photon.rs:642-644
+    assert img.shape == (size, size, 3) and img.dtype == np.uint8 and img.max() > 0
+    full = make()
+    full.photon_map_build(4000, 1)
+    whole = full.photon_sample_array(2)
+    parts = []
+    for rk in range(2):
+        r = make(rk, 2)
+        r.photon_map_build(4000, 1)
+        parts.append(r.photon_sample_array(2))
+    assert np.array_equal(parts[0] + parts[1], whole)         # tile shards are bit-exact, as for path tracing
+
+
+def test_photon_mapping_errors():
+    scene = Scene()
+    scene.add(Object(polygon([vec3(0, 0, 0), vec3(1, 0, 0), vec3(0, 1, 0)])).material(Material.diffuse(vec3(1, 1, 1))))
+    scene.add(Light.Ambient(vec3(1, 1, 1)))
+    from rpt_amd import Camera
+    r = Renderer(scene, Camera())
+    with pytest.raises(RptError, match="non-object lights"):   # the reference panics here (photon.rs:798)
+        r.photon_map_build(100, 1)
+    scene2, cam2, _ = scenes.CONFIGS["C4"]()
+    r2 = Renderer(scene2, cam2)
+    with pytest.raises(RptError):
+        r2.photon_sample_array(1)                              # no map built yet
+    with pytest.raises(RptError):
+        r2.photon_map_build(100, Renderer.PHOTON_BEAM_BEAM)    # not on the device yet

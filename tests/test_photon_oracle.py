@@ -1,0 +1,161 @@
+"""Known-answer and brute-force checks of the oracle's photon-mapping restatement
+(src/photon.rs).  CPU only."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from oracle.pyoracle import CameraDesc, OracleScene
+from rpt_amd import Camera, Light, Material, Medium, Object, Scene, hex_color, polygon, scenes, vec3
+from rpt_amd.api import camera_desc
+from tests.test_oracle_kat import furnace_scene
+
+
+def closed_box_with_light(rho=0.5):
+    scene, cam = furnace_scene(rho, 0.0)
+    scene.lights.clear()
+    quad = polygon([vec3(2, 9.5, -2), vec3(2, 9.5, 2), vec3(-2, 9.5, 2), vec3(-2, 9.5, -2)])   # faces down
+    scene.add((quad, Material.light(vec3(1.0, 0.5, 0.25), 5.0)))
+    return scene, cam
+
+
+def test_surface_photon_chain_follows_the_russian_roulette():
+    """Closed Lambertian box, no medium: every bounce survives with p_d = 0.7 and a survivor stores
+    one photon, so photons per emission ~ 0.7 / 0.3; powers follow power * albedo / 0.7 exactly
+    (f cos / pdf == albedo for the cosine-weighted sampler), src/photon.rs:811-875."""
+    rho = 0.5
+    scene, cam = closed_box_with_light(rho)
+    n = 20000
+    pm = OracleScene(scene).photon_map(n, 1, 100.0, seed=3, robust=1)
+    s, v = pm.photons(0), pm.photons(1)
+    assert len(v) == 0
+    # the light quad itself is an object too (one-sided, faces down): photons start on it and leave downward
+    assert abs(len(s) / n - 0.7 / 0.3) < 0.05
+    p0 = 100.0 / n * np.array([1.0, 0.5, 0.25])
+    # photons that met the back of the one-sided light quad (bsdf == 0) carry zero power from then on,
+    # but are still traced and stored (they fill k-nearest slots): keep them out of the power check
+    lit = s[:, 6] > 0
+    assert 0.9 < lit.mean() < 1.0
+    s = s[lit]
+    levels = np.round(np.log(s[:, 6] / p0[0]) / math.log(rho / 0.7)).astype(int)
+    assert levels.min() == 0 and levels.max() > 5
+    expect = p0[None, :] * (rho / 0.7) ** levels[:, None]
+    # chains that bounced off the emissive quad's front face picked up ITS albedo instead of rho
+    exact = np.all(np.abs(s[:, 6:9] - expect) <= 1e-9 * expect, axis=1)
+    assert exact.mean() > 0.95
+    # chain-length distribution: P(level >= k) = 0.7^k among stored photons' chains
+    frac0 = (levels == 0).mean()
+    assert abs(frac0 - 0.3) < 0.03          # stored photons at level k are 0.3 * 0.7^k of all stored
+    assert np.all(np.abs(np.linalg.norm(s[:, 3:6], axis=1) - 1) < 1e-12)
+
+
+def test_volume_photons_in_open_fog():
+    """Only the light quad (as object + light) in an infinite medium: every vertex off the quad is a
+    volume photon and the chain continues with probability sigma_s / sigma_t (src/photon.rs:879-914)."""
+    scene = Scene()
+    quad = polygon([vec3(1, 0, -1), vec3(1, 0, 1), vec3(-1, 0, 1), vec3(-1, 0, -1)])
+    scene.add((quad, Material.light(vec3(1, 1, 1), 1.0)))
+    sa, ss = 0.02, 0.08
+    scene.add(Medium.homogeneous_isotropic(sa, ss))
+    n = 20000
+    pm = OracleScene(scene).photon_map(n, 1, float(n), seed=1, robust=1)
+    s, v = pm.photons(0), pm.photons(1)
+    albedo = ss / (sa + ss)
+    assert abs(len(v) / n - 1.0 / (1.0 - albedo)) < 0.25      # ~5 per chain (a few chains re-hit the quad)
+    assert len(s) < 0.05 * len(v)
+    # first photon of every chain carries the emitted power; later ones power * albedo * colour each
+    col = hex_color(0xD2B48C)
+    lit = v[:, 6] > 0                       # chains that bounced off the quad's dark back carry zero power
+    assert lit.mean() > 0.9
+    v = v[lit]
+    lev = np.round(np.log(v[:, 6] / 1.0) / math.log(albedo * col[0])).astype(int)
+    expect = (albedo * col[None, :]) ** lev[:, None]
+    exact = np.all(np.abs(v[:, 6:9] - expect) <= 1e-9 * expect, axis=1)
+    assert exact.mean() > 0.95              # the rest bounced off the quad's front (its own albedo / 0.7)
+
+
+def test_gather_radius_is_the_tenth_nearest_distance():
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    pm = OracleScene(scene).photon_map(1500, 1, 1500.0, 20, 3, seed=2, robust=1)
+    v = pm.photons(1)
+    assert len(v) > 1000
+    p = v[:, :3]
+    d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+    tenth = np.sqrt(np.sort(d2, axis=1)[:, 9])                 # self (0) included, src/photon.rs:217-226
+    assert np.allclose(v[:, 9], tenth, rtol=1e-12)
+
+
+def _camera_ray(cam, w, h, pix, seed, sample):
+    L = pyoracle.lib()
+    x, y = pix % w, pix // w
+    xn, yn = C.c_double(), C.c_double()
+    L.orc_pixel_ndc(x, y, w, h, C.byref(xn), C.byref(yn))
+    u = np.zeros(2)
+    L.orc_rng_uniform(C.c_uint64(seed), pix, sample, 2, u.ctypes.data_as(C.c_void_p))
+    dim = float(max(w, h))
+    dx, dy = -1 / dim + (2 / dim) * u[0], -1 / dim + (2 / dim) * u[1]
+    o, d = (C.c_double * 3)(), (C.c_double * 3)()
+    L.orc_camera_cast_ray(C.byref(camera_desc(cam, CameraDesc)), xn.value + dx, yn.value + dy, C.c_uint64(seed), pix,
+                          sample, o, d)                       # pinhole: no lens draws
+    return np.array(list(o)), np.array(list(d))
+
+
+def test_beam_and_surface_estimates_match_brute_force():
+    """estimate_indirect (src/photon.rs:316-628) for single camera samples, recomputed in numpy by
+    summing over ALL photons: validates the oracle's kd-tree k-nearest and sphere-BVH traversal."""
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    osc = OracleScene(scene)
+    K = 20
+    pm = osc.photon_map(3000, 1, 3000.0 * 14.65, K, 3, seed=5, robust=1)
+    s, v = pm.photons(0), pm.photons(1)
+    w = h = 16
+    pixels = np.array([3 * 16 + 5, 8 * 16 + 8, 13 * 16 + 2, 15 * 16 + 15], dtype=np.uint32)
+    got = pm.render(cam, w, h, 1, seed=9, threads=1, pixels=pixels)[pixels]
+    sa, ss = 0.0001, 0.001
+    ext = sa + ss
+    mcol = hex_color(0xD2B48C)
+    white = {0: hex_color(0xAAAAAA), 1: hex_color(0xAAAAAA), 2: hex_color(0xAAAAAA), 3: hex_color(0xBC0000),
+             4: hex_color(0x00BC00), 5: hex_color(0xAAAAAA), 6: hex_color(0xAAAAAA)}
+    for k, pix in enumerate(pixels):
+        o, d = _camera_ray(cam, w, h, int(pix), 9, 0)
+        t, obj, nrm = osc.intersect(o[None], d[None], robust=1)
+        t, obj, nrm = float(t[0]), int(obj[0]), nrm[0]
+        # volume: every photon with disk_distance > 0, inside its radius, centre not beyond the hit
+        otc = v[:, :3] - o
+        disk = otc @ d
+        dist2 = (((o + disk[:, None] * d) - v[:, :3]) ** 2).sum(1)
+        r2 = v[:, 9] ** 2
+        ok = (disk > 0) & (dist2 < r2)
+        if obj >= 0:
+            ok &= ~(np.linalg.norm(otc, axis=1) > t)
+        wgt = (3 / math.pi) * (1 - dist2[ok] / r2[ok]) ** 2 / r2[ok] * np.exp(-ext * disk[ok]) / (4 * math.pi)
+        vol = (wgt[:, None] * v[ok, 6:9]).sum(0) * mcol
+        total = vol
+        if obj >= 0:
+            x = o + t * d
+            d2 = ((s[:, :3] - x) ** 2).sum(1)
+            near = np.argsort(d2)[:K]
+            albedo = white.get(obj, hex_color(0xBCBC00) if obj < 11 else hex_color(0xFFFEFA))
+            emit = 14.65 * albedo if obj == 11 else 0.0
+            col = np.zeros(3) + emit
+            wo = -d
+            for j in near:
+                # visibility of the photon from the query point is not re-derived here: pick pixels whose
+                # neighbourhood is unoccluded (floor / walls away from the boxes)
+                pd = s[j, 3:6]
+                if np.dot(nrm, pd) < 0 or np.dot(nrm, wo) < 0:
+                    continue
+                col += (albedo / math.pi) * s[j, 6:9] * min(max(np.dot(pd, nrm), 0.0), 1.0)
+            col = col / (math.pi * d2[near].max()) * math.exp(-ext * t)
+            total = vol + col
+        assert np.allclose(got[k], total, rtol=2e-6, atol=1e-12), (pix, got[k], total)
+
+
+def test_photon_render_needs_an_object_light():
+    scene = Scene()
+    scene.add(Object(polygon([vec3(0, 0, 0), vec3(1, 0, 0), vec3(0, 1, 0)])))
+    scene.add(Light.Ambient(vec3(1, 1, 1)))
+    with pytest.raises(ValueError):                          # panic!("Only found non-object lights ...")
+        OracleScene(scene).photon_map(10, 1, 1.0)
