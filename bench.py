@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--photons", type=int, default=0, help="C4 only: photons shot per step (default: the config's 1,000,000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -108,9 +109,19 @@ def main():
 
     kernel_ms = []
 
+    photon = "photons" in cfg   # C4: Renderer::photon_render = shoot + build the map + camera pass, every step
+    if photon:
+        n_photons = args.photons or cfg["photons"]
+        r.gather_size(cfg["gather_size"]).gather_size_volume(cfg["gather_size_volume"])
+        r.watts(cfg["renderer_watts"] / cfg["photons"] * n_photons)
+
     def step(record=False):
         r._sample_offset = 0
-        r.sample_device(spp, d_out.data_ptr(), stream)
+        if photon:
+            r.photon_map_build(n_photons, Renderer.PHOTON_POINT_BEAM)
+            r.photon_sample_device(spp, d_out.data_ptr(), stream)
+        else:
+            r.sample_device(spp, d_out.data_ptr(), stream)
         if dist is not None:
             dist.reduce(d_out, dst=0, op=dist.ReduceOp.SUM)
         if record:
@@ -133,6 +144,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     grid_blocks = r.timing()[2]
+
+    if photon:
+        if rank == 0:
+            samples_per_step = width * height * spp
+            ms_per_step = elapsed / args.steps * 1e3
+            print(json.dumps({
+                "metric": "Msamples/sec", "value": round(samples_per_step * args.steps / elapsed / 1e6, 3),
+                "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"C4 lampshade beam x point photon map {width}x{height}x{spp}spp, "
+                                       f"{n_photons} photons shot + map build + camera pass per step",
+                           "scene": "examples/volumetric_beamphoton_lampshade.rs", "parallelism": f"tile-shard x{world}",
+                           "camera_pass_kernel_ms": round(float(np.mean(kernel_ms)), 3)},
+                "roofline": None}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # one extra, untimed pass with device counters on (rank-local work) for the roofline figures
     rpt_amd.set_option("counters", 1)

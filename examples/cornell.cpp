@@ -60,6 +60,15 @@ int main(int argc, char** argv) {
                 if (buffer.samples.size() > 1) variance = buffer.variance();
                 std::fprintf(stderr, "Finished iteration %u\n", iteration);
             });
+        if (argc > 4) {  // optional: photon-mapped render of the same scene (photon.rs:650-652 style entry point)
+            Renderer pr(scene, camera);
+            pr.width(size).height(size).num_samples(2).gather_size(20).gather_size_volume(3).watts(14.65 * 5000.0).seed(1);
+            RgbImage pimg = pr.photon_point_query_beam_render(5000);
+            size_t lit = 0;
+            for (uint8_t b : pimg.data) lit += b > 0;
+            std::fprintf(stderr, "photon render: %zu non-zero bytes\n", lit);
+            if (lit == 0) return 3;
+        }
         uint64_t h = 1469598103934665603ull;
         for (uint8_t b : last.data) {
             h ^= b;

@@ -401,6 +401,24 @@ class Renderer {
             cb(iteration, buffer);
         }
     }
+    // ---- photon mapping (photon.rs:631-720)
+    enum PhotonRenderKind { PhotonMap = RPT_PHOTON_MAP, PhotonPointBeam = RPT_PHOTON_POINT_BEAM, PhotonBeamBeam = RPT_PHOTON_BEAM_BEAM };
+    RgbImage photon_render(size_t photon_count, PhotonRenderKind kind) {  // photon.rs:655-720
+        commit();
+        check(rpt_photon_map_build(handle_, photon_count, int32_t(kind), p_.watts, p_.seed));
+        Buffer buffer(p_.width, p_.height, p_.filter);
+        std::vector<double> out(size_t(p_.width) * p_.height * 3);
+        rpt_camera cam = camera_.desc();
+        rpt_render_params rp{p_.width, p_.height, p_.exposure_value, p_.max_bounces, p_.shard_rank, p_.shard_count};
+        check(rpt_photon_render_sample(handle_, &cam, &rp, p_.gather_size, p_.gather_size_volume, p_.num_samples, p_.seed, 0,
+                                       out.data()));
+        buffer.add_samples(out);
+        return buffer.image();
+    }
+    RgbImage photon_point_query_beam_render(size_t n) { return photon_render(n, PhotonPointBeam); }  // :642-644
+    RgbImage photon_beam_query_beam_render(size_t n) { return photon_render(n, PhotonBeamBeam); }   // :646-648
+    RgbImage photon_map_render(size_t n) { return photon_render(n, PhotonMap); }                     // :650-652
+
     // Renderer::sample (renderer.rs:158-171): the call that crosses the C ABI.
     void sample(uint32_t iterations, Buffer& buffer) {
         commit();

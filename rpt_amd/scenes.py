@@ -177,10 +177,19 @@ def mesh_in_fog(nu=224, nv=224, absorb=0.005, scat=0.045):
     return scene, camera, dict(width=2048, height=2048, spp=1024, max_bounces=2, filter=0)
 
 
+def lampshade_beamphoton():
+    """C4: examples/volumetric_beamphoton_lampshade.rs:139-164 (photon_point_query_beam_render)."""
+    watts = 200_000.0 / (130.0 * 105.0)
+    scene, cam, cfg = lampshade(absorb=0.0001, scat=0.001, watts=watts)
+    photons = 1_000_000
+    cfg = dict(cfg, photons=photons, gather_size=20, gather_size_volume=3, renderer_watts=watts * photons)
+    return scene, cam, cfg
+
+
 CONFIGS = {
     "C1": spheres,
     "C2": cornell,
     "C3": lampshade,
-    "C4": lambda: lampshade(absorb=0.0001, scat=0.001, watts=150.0),
+    "C4": lampshade_beamphoton,
     "C5": mesh_in_fog,
 }

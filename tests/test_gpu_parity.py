@@ -308,6 +308,11 @@ def test_cpp_mirror_example_renders_the_same_bytes_as_the_python_mirror():
         h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert line[3] == f"{h:016x}"
     assert abs(float(line[4]) - seen["var"]) <= 1e-9 * seen["var"]
+    # the same binary with a 4th argument also runs photon_point_query_beam_render through rpt.hpp
+    ppm = os.path.join(root, "gpurun_out", "cornell_cpp.ppm")
+    os.makedirs(os.path.dirname(ppm), exist_ok=True)
+    subprocess.check_call([exe, "32", "2", ppm, "photon"])
+    assert open(ppm, "rb").read(2) == b"P6"
 
 
 # ------------------------------------------------------------------ BASELINE.json full sizes
