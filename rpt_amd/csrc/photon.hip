@@ -397,6 +397,51 @@ RPT_DEV void beam_walk(const BvhNode* nodes, uint32_t n, V o, V d, F&& visit) {
     }
 }
 
+// Wave-cooperative variant: the 64 camera rays of a wave come from one 8x8 pixel tile, so the
+// wave walks the tree ONCE.  The node index is wave-uniform (scalar loads of the 64-byte node and the
+// 48-byte photon record), a child is entered when ANY lane's ray hits its box (ballot), and the stack
+// lives in the 64 lanes of one VGPR (lane-select write / v_readlane with a uniform stack pointer).
+// Must be called by every lane of the wave; lanes with active == false only take part in the votes.
+template <class F>
+RPT_DEV void beam_walk_wave(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
+                            F&& visit) {
+    if (n == 0) return;
+    const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t stackreg = 0;
+    uint32_t sp = 0;
+    uint32_t cur = (n == 1) ? BVH_LEAF : 0u;
+    for (;;) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        if (cur & BVH_LEAF) {
+            const PhotonRec ph = uload(&photons[cur & 0x7FFFFFFFu]);
+            if (active) visit(ph);
+        } else {
+            const BvhNode nd = uload(&nodes[cur]);
+            float n0, f0, n1, f1;
+            slab2(nd.lo0, nd.hi0, o, inv, n0, f0);
+            slab2(nd.lo1, nd.hi1, o, inv, n1, f1);
+            const bool a0 = __ballot(active && fmaxf(n0, 0.f) <= f0) != 0;
+            const bool a1 = __ballot(active && fmaxf(n1, 0.f) <= f1) != 0;
+            if (a0 && a1) {
+                if (sp < 64) {
+                    stackreg = (lane == sp) ? nd.e1 : stackreg;  // lane `sp` of the VGPR holds entry `sp`
+                    sp++;
+                }
+                cur = nd.e0;
+                continue;
+            }
+            if (a0 || a1) {
+                cur = a0 ? nd.e0 : nd.e1;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = __builtin_amdgcn_readlane(stackreg, sp);
+    }
+}
+
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
 template <bool MEDIUM, bool BVH>
@@ -419,6 +464,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
     bool alive = true, have_item = false;
     uint32_t pool_next = 0, pool_end = 0;
     uint32_t c0 = 0, c1 = 0;
+    unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
     for (;;) {
         bool want = alive && s >= s_end;
         if (__any(want)) {
@@ -467,31 +513,30 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
             }
         }
         if (!__any(alive)) break;
-        if (!alive) continue;
 
-        // ---- one camera sample
-        Rng rng;
-        rng.seed(a.seed_mixed, pix, a.sample_offset + s);
-        s++;
-        float dx = rng.range(-a.inv_dim, a.inv_dim), dy = rng.range(-a.inv_dim, a.inv_dim);
-        V ro, rd;
-        cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
-        const V wo = -normalize(rd);
-        const float tmin = ray_tmin_p(ro);
-        float t = kInf;
+        // ---- one camera sample per live lane (dead lanes idle but stay in the wave-level votes)
+        const bool active = alive;
+        V ro = mk(0, 0, 0), rd = mk(0, 0, 1), wo = mk(0, 0, -1);
+        float tmin = 0.f, t = kInf;
         uint32_t code = CODE_MISS;
-        closest_hit<BVH, false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
-        const bool hit = code != CODE_MISS;
-        if (!hit && !MEDIUM) {
-            acc = acc + env;  // src/photon.rs:597
-            continue;
+        if (active) {
+            Rng rng;
+            rng.seed(a.seed_mixed, pix, a.sample_offset + s);
+            s++;
+            c_samp++;
+            float dx = rng.range(-a.inv_dim, a.inv_dim), dy = rng.range(-a.inv_dim, a.inv_dim);
+            cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
+            wo = -normalize(rd);
+            tmin = ray_tmin_p(ro);
+            closest_hit<BVH, false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
         }
+        const bool hit = code != CODE_MISS;
         V color = mk(0, 0, 0);
         if (MEDIUM) {  // beam x point volume estimate, src/photon.rs:439-502
             V vc = mk(0, 0, 0);
             const float phase = sc.medium_phase;
-            beam_walk(q.v_nodes, q.n_v, ro, rd, [&](uint32_t idx) {
-                const PhotonRec ph = q.v_ph[idx];
+            beam_walk_wave(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, [&](const PhotonRec& ph) {
+                c_leaf++;
                 V otc = xyz(ph.pos_r) - ro;
                 float r2 = ph.pos_r.w * ph.pos_r.w;
                 float disk = dot(otc, rd);
@@ -499,12 +544,18 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                 float dist2 = dot(dv, dv);
                 bool ok = disk > 0.f && dist2 < r2 && !(hit && dot(otc, otc) > t * t);
                 if (ok) {
+                    c_acc++;
                     float tmp = 1.f - dist2 * rcp(r2);
                     float w = (3.f * kInvPi) * tmp * tmp * rcp(r2) * __expf(-sigma_t * disk) * phase;
                     vc = fma3(w, xyz(ph.pow), vc);
                 }
             });
             color = vc * mcol0;
+        }
+        if (!active) continue;
+        if (!hit && !MEDIUM) {
+            acc = acc + env;  // src/photon.rs:597
+            continue;
         }
         if (hit) {  // surface estimate, src/photon.rs:327-375
             V n;
@@ -578,6 +629,11 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
             color = color + sc_col;
         }
         acc = acc + color;
+    }
+    if (a.counters) {  // diagnostic: [0] camera samples, [5] photon spheres visited, [6] photon spheres accepted
+        atomicAdd(&a.counters[0], c_samp);
+        atomicAdd(&a.counters[5], c_leaf);
+        atomicAdd(&a.counters[6], c_acc);
     }
 }
 
@@ -819,7 +875,7 @@ int rpt_photon_map_download(rpt_scene* s, int32_t which, float* out, uint64_t ca
 
 static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint64_t gather_size,
                               uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed, uint32_t sample_offset,
-                              double* d_out, hipStream_t st) {
+                              double* d_out, hipStream_t st, bool sync_counters) {
     auto* pm = s ? static_cast<PhotonMapDev*>(rpti::photon_slot(s)) : nullptr;
     if (!pm) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
     if (gather_size > 56) return rpti::fail(RPT_ERR_UNSUPPORTED, "gather_size > 56 does not fit the LDS gather list");
@@ -846,7 +902,12 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         return hipGetLastError();
     };
     int bpc = int(std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / std::max<size_t>(lds, 1))));
-    return rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch);
+    rc = rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch);
+    if (rc == RPT_OK && sync_counters && q.r.counters) {
+        RPTI_HIP_TRY(hipStreamSynchronize(st));
+        rc = rpti::fetch_counters(s, q.r);
+    }
+    return rc;
 }
 
 int rpt_photon_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint64_t gather_size,
@@ -856,7 +917,7 @@ int rpt_photon_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_rend
     size_t bytes = size_t(prm->width) * prm->height * 24;
     double* d_out = rpti::scratch_out(s, bytes);
     if (!d_out) return rpti::fail(RPT_ERR_DEVICE, "out of device memory");
-    int rc = photon_render_impl(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset, d_out, nullptr);
+    int rc = photon_render_impl(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset, d_out, nullptr, true);
     if (rc) return rc;
     RPTI_HIP_TRY(hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost));
     return RPT_OK;
@@ -867,7 +928,7 @@ int rpt_photon_render_sample_device(rpt_scene* s, const rpt_camera* cam, const r
                                     uint32_t sample_offset, void* d_out_rgb, void* hip_stream) {
     if (!s || !cam || !prm || !d_out_rgb) return rpti::fail(RPT_ERR_INVALID, "null argument");
     return photon_render_impl(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset,
-                              static_cast<double*>(d_out_rgb), static_cast<hipStream_t>(hip_stream));
+                              static_cast<double*>(d_out_rgb), static_cast<hipStream_t>(hip_stream), true);
 }
 
 }  // extern "C"

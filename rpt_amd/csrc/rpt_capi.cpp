@@ -1013,7 +1013,7 @@ extern "C++" double* rpti::scratch_out(rpt_scene* s, size_t bytes) {
     }
     return s->d_out;
 }
-static int fetch_counters(rpt_scene* s, const RenderArgs& a) {
+extern "C++" int rpti::fetch_counters(rpt_scene* s, const RenderArgs& a) {
     std::memset(s->last_counters, 0, sizeof(s->last_counters));
     if (a.counters) {
         HIP_TRY(hipMemcpy(s->last_counters, a.counters, 64, hipMemcpyDeviceToHost));
@@ -1032,7 +1032,7 @@ int rpt_render_sample_device(rpt_scene* s, const rpt_camera* cam, const rpt_rend
     if (rc) return rc;
     if (a.counters) {
         HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
-        return fetch_counters(s, a);
+        return rpti::fetch_counters(s, a);
     }
     return RPT_OK;
 }
@@ -1052,7 +1052,7 @@ int rpt_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_para
     rc = run_render(s, prm, a, s->d_out, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out_rgb, s->d_out, bytes, hipMemcpyDeviceToHost));
-    return fetch_counters(s, a);
+    return rpti::fetch_counters(s, a);
 }
 
 int rpt_get_timing(rpt_scene* s, double* render_ms, double* resolve_ms, int32_t* grid_blocks) {
