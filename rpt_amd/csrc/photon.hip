@@ -362,6 +362,7 @@ struct QueryArgs {
     const BvhNode* s_nodes; const PhotonRec* s_ph; uint32_t n_s;   // surface photons (points)
     const BvhNode* v_nodes; const PhotonRec* v_ph; uint32_t n_v;   // volume photons (spheres for the beam query)
     uint32_t kind, gather_size, gather_size_volume;
+    uint32_t* overflow;  // set to 1 if a beam-walk stack overflowed (the render is then rejected)
 };
 
 // Ray vs. sphere-box LBVH: visit every leaf whose padded box the half-infinite ray hits.
@@ -442,6 +443,74 @@ RPT_DEV void beam_walk_wave(const BvhNode* nodes, const PhotonRec* photons, uint
     }
 }
 
+// Batched wave-cooperative walk.  The single-node walk above is one dependent memory round trip per
+// node (~3,400 cycles each with 220 MB of nodes + photons far beyond L2).  Here the wave pops up to
+// 64 pending entries at once, lane i fetches entry i's node / photon record (64 loads in flight),
+// stages it in LDS, and then all lanes test their own ray against each staged record in turn
+// (broadcast LDS reads, ballot to decide which children to push).  Pending entries live on a
+// wave-private LDS stack of kBeamCap entries; near the cap the walk degrades to depth-first (batch
+// of 1), whose extra footprint is bounded by the tree depth.  *overflow is set if even that fails.
+static constexpr uint32_t kBeamCap = 1024;
+template <class F>
+RPT_DEV void beam_walk_batch(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
+                             uint32_t* wstack, F4* stage, uint32_t* overflow, F&& visit) {
+    if (n == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
+    uint32_t count = 1;  // wave-uniform
+    if (lane == 0) wstack[0] = (n == 1) ? BVH_LEAF : 0u;
+    while (count != 0) {
+        const uint32_t b = (count > kBeamCap - 160u) ? 1u : min(count, 64u);
+        uint32_t e = 0u;
+        if (lane < b) {
+            e = wstack[count - b + lane];
+            if (e & BVH_LEAF) {
+                const PhotonRec ph = photons[e & 0x7FFFFFFFu];
+                stage[lane * 4u + 0u] = ph.pos_r;
+                stage[lane * 4u + 1u] = ph.dir;
+                stage[lane * 4u + 2u] = ph.pow;
+            } else {
+                const F4* src = reinterpret_cast<const F4*>(nodes + e);
+                const F4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+                stage[lane * 4u + 0u] = a0;
+                stage[lane * 4u + 1u] = a1;
+                stage[lane * 4u + 2u] = a2;
+                stage[lane * 4u + 3u] = a3;
+            }
+        }
+        count -= b;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = 0; j < b; j++) {
+            const uint32_t ej = __builtin_amdgcn_readlane(e, j);
+            if (ej & BVH_LEAF) {
+                PhotonRec ph;
+                ph.pos_r = stage[j * 4u + 0u];
+                ph.dir = stage[j * 4u + 1u];
+                ph.pow = stage[j * 4u + 2u];
+                if (active) visit(ph);
+            } else {
+                const F4 q0 = stage[j * 4u + 0u], q1 = stage[j * 4u + 1u], q2 = stage[j * 4u + 2u], q3 = stage[j * 4u + 3u];
+                const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q1.x, q1.y, q1.z};
+                const float lo1[3] = {q2.x, q2.y, q2.z}, hi1[3] = {q3.x, q3.y, q3.z};
+                float n0, f0, n1, f1;
+                slab2(lo0, hi0, o, inv, n0, f0);
+                slab2(lo1, hi1, o, inv, n1, f1);
+                const bool a0 = __ballot(active && fmaxf(n0, 0.f) <= f0) != 0;
+                const bool a1 = __ballot(active && fmaxf(n1, 0.f) <= f1) != 0;
+                if (a0) {
+                    if (count < kBeamCap) { if (lane == 0) wstack[count] = __float_as_uint(q0.w); count++; }
+                    else if (lane == 0) *overflow = 1u;
+                }
+                if (a1) {
+                    if (count < kBeamCap) { if (lane == 0) wstack[count] = __float_as_uint(q2.w); count++; }
+                    else if (lane == 0) *overflow = 1u;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
 template <bool MEDIUM, bool BVH>
@@ -454,6 +523,9 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
     // gather list: [K][256] floats then [K][256] indices, after the BVH stack region
     float* gd = reinterpret_cast<float*>(dyn_lds + (BVH ? 32u * 256u : 0u)) + threadIdx.x;
     uint32_t* gi = reinterpret_cast<uint32_t*>(gd - threadIdx.x + K * 256u) + threadIdx.x;
+    // per-wave beam-walk stack and staging area (after the gather lists)
+    uint32_t* wstack = reinterpret_cast<uint32_t*>(gi - threadIdx.x + K * 256u) + (threadIdx.x >> 6) * kBeamCap;
+    F4* stage = reinterpret_cast<F4*>(reinterpret_cast<uint32_t*>(gi - threadIdx.x + K * 256u) + 4u * kBeamCap) + (threadIdx.x >> 6) * 256u;
     const float sigma_t = sc.sigma_a + sc.sigma_s;
     const V mcol0 = mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);  // medium.color(dummy_pos = 0)
     const V env = mk(sc.env[0], sc.env[1], sc.env[2]);
@@ -535,7 +607,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
         if (MEDIUM) {  // beam x point volume estimate, src/photon.rs:439-502
             V vc = mk(0, 0, 0);
             const float phase = sc.medium_phase;
-            beam_walk_wave(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, [&](const PhotonRec& ph) {
+            beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, [&](const PhotonRec& ph) {
                 c_leaf++;
                 V otc = xyz(ph.pos_r) - ro;
                 float r2 = ph.pos_r.w * ph.pos_r.w;
@@ -654,10 +726,13 @@ struct PhotonMapDev {
     uint64_t photon_count = 0;
     DevLbvh surf, vol;
     double build_ms[4] = {0, 0, 0, 0};  // shoot, sort+build, radii, total
+    uint32_t* d_overflow = nullptr;
     void release() {
         (void)hipSetDevice(device);
         (void)hipFree(surf.nodes); (void)hipFree(surf.sorted);
         (void)hipFree(vol.nodes); (void)hipFree(vol.sorted);
+        (void)hipFree(d_overflow);
+        d_overflow = nullptr;
         surf = DevLbvh{};
         vol = DevLbvh{};
     }
@@ -888,7 +963,10 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     q.gather_size = uint32_t(gather_size);
     q.gather_size_volume = uint32_t(gather_size_volume);
     const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_mesh != 0;
-    const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + size_t(gather_size) * 256u * 8u;
+    const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + size_t(gather_size) * 256u * 8u + 4u * kBeamCap * 4u + 4u * 256u * 16u;
+    if (!pm->d_overflow) RPTI_HIP_TRY(hipMalloc((void**)&pm->d_overflow, 64));
+    RPTI_HIP_TRY(hipMemsetAsync(pm->d_overflow, 0, 4, st));
+    q.overflow = pm->d_overflow;
     auto launch = [&](const RenderArgs& ra, int nb, hipStream_t stream) -> hipError_t {
         QueryArgs qq = q;
         qq.r = ra;
@@ -903,9 +981,12 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     };
     int bpc = int(std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / std::max<size_t>(lds, 1))));
     rc = rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch);
-    if (rc == RPT_OK && sync_counters && q.r.counters) {
+    if (rc == RPT_OK && sync_counters) {
+        uint32_t ov = 0;
+        RPTI_HIP_TRY(hipMemcpyAsync(&ov, pm->d_overflow, 4, hipMemcpyDeviceToHost, st));
         RPTI_HIP_TRY(hipStreamSynchronize(st));
-        rc = rpti::fetch_counters(s, q.r);
+        if (ov) return rpti::fail(RPT_ERR_UNSUPPORTED, "photon beam walk: traversal stack overflow (photon tree too deep)");
+        if (q.r.counters) rc = rpti::fetch_counters(s, q.r);
     }
     return rc;
 }
