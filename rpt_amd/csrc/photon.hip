@@ -511,6 +511,108 @@ RPT_DEV void beam_walk_batch(const BvhNode* nodes, const PhotonRec* photons, uin
     }
 }
 
+// Packet walk: when the live lanes' rays share one origin (pinhole camera, one pixel tile per wave)
+// the inner nodes are not tested per ray at all.  The wave bounds its 64 directions by a four-plane
+// frustum through the common origin; each lane then culls a DIFFERENT pending node's two child boxes
+// against that frustum (64 nodes per instruction stream instead of one), survivors are pushed with a
+// ballot/mbcnt prefix, and only photon records reach the per-ray test (staged in LDS, broadcast to
+// all lanes).  Culling is conservative, the per-photon test is the exact one, so the sum equals the
+// brute-force sum over all photons.  Returns false (nothing done) if the rays do not form a packet.
+RPT_DEV float wave_min(float v) {
+    for (int off = 32; off; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+RPT_DEV float wave_max(float v) {
+    for (int off = 32; off; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+RPT_DEV bool box_outside(const float lo[3], const float hi[3], V o, V nrm) {
+    // true if the whole box lies on the negative side of the plane through o with inward normal nrm
+    V c = mk(0.5f * (lo[0] + hi[0]) - o.x, 0.5f * (lo[1] + hi[1]) - o.y, 0.5f * (lo[2] + hi[2]) - o.z);
+    V h = mk(0.5f * (hi[0] - lo[0]), 0.5f * (hi[1] - lo[1]), 0.5f * (hi[2] - lo[2]));
+    float reach = fabsf(nrm.x) * h.x + fabsf(nrm.y) * h.y + fabsf(nrm.z) * h.z;
+    return dot(nrm, c) + reach < 0.f;
+}
+template <class F>
+RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
+                              uint32_t* wstack, F4* stage, uint32_t* overflow, F&& visit) {
+    if (n == 0) return true;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t act = __ballot(active);
+    if (act == 0) return true;
+    // common origin?
+    const uint32_t first = uint32_t(__ffsll((unsigned long long)act)) - 1u;
+    auto bcast = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), first)); };
+    const V o0 = mk(bcast(o.x), bcast(o.y), bcast(o.z));
+    const V m = normalize(mk(bcast(d.x), bcast(d.y), bcast(d.z)));
+    const float dm = dot(d, m);
+    const bool fits = !active || (o.x == o0.x && o.y == o0.y && o.z == o0.z && dm > 0.5f);
+    if (__ballot(!fits) != 0) return false;
+    // orthonormal basis around m (Duff et al.), perspective coordinates of every live direction
+    const float sg = __builtin_copysignf(1.f, m.z);
+    const float aa = -1.f / (sg + m.z), bb = m.x * m.y * aa;
+    const V u = mk(1.f + sg * m.x * m.x * aa, sg * bb, -sg * m.x), v = mk(bb, sg + m.y * m.y * aa, -m.y);
+    const float idm = rcp(dm);
+    const float pu = active ? dot(d, u) * idm : 0.f, pv = active ? dot(d, v) * idm : 0.f;
+    const float pad = 1e-5f;
+    const float umin = wave_min(active ? pu : kInf) - pad, umax = wave_max(active ? pu : -kInf) + pad;
+    const float vmin = wave_min(active ? pv : kInf) - pad, vmax = wave_max(active ? pv : -kInf) + pad;
+    const V nl = fma3(-umin, m, u), nr = fma3(umax, m, -u), nb = fma3(-vmin, m, v), nt = fma3(vmax, m, -v);
+
+    uint32_t count = 1;  // wave-uniform
+    if (lane == 0) wstack[0] = (n == 1) ? BVH_LEAF : 0u;
+    while (count != 0) {
+        const uint32_t b = (count > kBeamCap - 160u) ? 1u : min(count, 64u);
+        const bool mine = lane < b;
+        uint32_t e = 0u;
+        bool s0 = false, s1 = false, leaf = false;
+        uint32_t c0 = 0u, c1 = 0u;
+        if (mine) {
+            e = wstack[count - b + lane];
+            leaf = (e & BVH_LEAF) != 0u;
+            if (leaf) {
+                const PhotonRec ph = photons[e & 0x7FFFFFFFu];
+                stage[lane * 4u + 0u] = ph.pos_r;
+                stage[lane * 4u + 1u] = ph.dir;
+                stage[lane * 4u + 2u] = ph.pow;
+            } else {
+                const BvhNode nd = nodes[e];
+                c0 = nd.e0;
+                c1 = nd.e1;
+                s0 = !(box_outside(nd.lo0, nd.hi0, o0, m) || box_outside(nd.lo0, nd.hi0, o0, nl) || box_outside(nd.lo0, nd.hi0, o0, nr) ||
+                       box_outside(nd.lo0, nd.hi0, o0, nb) || box_outside(nd.lo0, nd.hi0, o0, nt));
+                s1 = !(box_outside(nd.lo1, nd.hi1, o0, m) || box_outside(nd.lo1, nd.hi1, o0, nl) || box_outside(nd.lo1, nd.hi1, o0, nr) ||
+                       box_outside(nd.lo1, nd.hi1, o0, nb) || box_outside(nd.lo1, nd.hi1, o0, nt));
+            }
+        }
+        count -= b;
+        // wave-aggregated push of the surviving children
+        const uint64_t m0 = __ballot(s0), m1 = __ballot(s1);
+        const uint32_t n0 = uint32_t(__popcll(m0)), n1 = uint32_t(__popcll(m1));
+        if (count + n0 + n1 > kBeamCap) {
+            if (lane == 0) *overflow = 1u;
+        } else {
+            if (s0) wstack[count + __builtin_amdgcn_mbcnt_hi(uint32_t(m0 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m0), 0u))] = c0;
+            if (s1) wstack[count + n0 + __builtin_amdgcn_mbcnt_hi(uint32_t(m1 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m1), 0u))] = c1;
+            count += n0 + n1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // exact per-ray test of the staged photons
+        uint64_t lm = __ballot(leaf);
+        while (lm) {
+            const uint32_t j = uint32_t(__ffsll((unsigned long long)lm)) - 1u;
+            lm &= lm - 1;
+            PhotonRec ph;
+            ph.pos_r = stage[j * 4u + 0u];
+            ph.dir = stage[j * 4u + 1u];
+            ph.pow = stage[j * 4u + 2u];
+            if (active) visit(ph);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return true;
+}
+
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
 template <bool MEDIUM, bool BVH>
@@ -607,7 +709,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
         if (MEDIUM) {  // beam x point volume estimate, src/photon.rs:439-502
             V vc = mk(0, 0, 0);
             const float phase = sc.medium_phase;
-            beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, [&](const PhotonRec& ph) {
+            auto visit = [&](const PhotonRec& ph) {
                 c_leaf++;
                 V otc = xyz(ph.pos_r) - ro;
                 float r2 = ph.pos_r.w * ph.pos_r.w;
@@ -621,7 +723,9 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                     float w = (3.f * kInvPi) * tmp * tmp * rcp(r2) * __expf(-sigma_t * disk) * phase;
                     vc = fma3(w, xyz(ph.pow), vc);
                 }
-            });
+            };
+            if (!beam_walk_packet(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit))
+                beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit);
             color = vc * mcol0;
         }
         if (!active) continue;
