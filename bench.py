@@ -42,6 +42,20 @@ def algorithmic_work(stats, n_objects, counters, samples):
     return total_bytes / samples, total_flops / samples, rays / samples
 
 
+def hbm_traffic_from_profile(workload, width, height, spp, world):
+    """HBM bytes per render_kernel launch from the committed rocprofv3 PMC passes
+    (profiles/r01/final_c3_pmc_render_kernel.json: FETCH_SIZE and WRITE_SIZE in KB, collected in
+    separate --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM).  Only valid for the
+    configuration that was profiled (C3 at full size on one GPU); null otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01", "final_c3_pmc_render_kernel.json")
+    if (workload, width, height, spp, world) != ("C3", 1024, 1024, 256, 1) or not os.path.exists(path):
+        return None
+    pmc = json.load(open(path))
+    if "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
+        return None
+    return int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
+
+
 def cpu_baseline(scene, cam, cfg, width, height, target_seconds=15.0):
     """The fp64 oracle (C++ restatement of rpt's CPU algorithm, literal reference semantics,
     one task per image row like the rayon loop) on all host cores, on a bounded sample."""
@@ -209,7 +223,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(ach_gbs / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": hbm_traffic_from_profile(args.workload, width, height, spp, world),
                 "kernel": "rptg::render_kernel",
                 "kernel_ms": round(k_ms, 3),
                 "grid_blocks": grid_blocks,
