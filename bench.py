@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--photons", type=int, default=0, help="C4 only: photons shot per step (default: the config's 1,000,000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl) even with one rank, to rehearse the N > 1 code path")
     args = ap.parse_args()
 
     import torch  # before the HIP library: one shared HIP runtime (rpt_amd/_lib.py)
@@ -102,8 +104,11 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 

@@ -132,3 +132,39 @@ def test_config_scenes_have_the_documented_shape():
     gn = np.cross(e0, e1)
     assert np.all(np.linalg.norm(gn, axis=1) > 0)
     assert np.all(np.einsum("ij,ij->i", gn, tris[:, 3]) > 0)      # winding agrees with the vertex normals
+
+
+def test_load_obj_follows_the_reference_parser(tmp_path):
+    import io
+    import struct
+    from rpt_amd import load_obj, load_stl
+    text = """# a quad, a triangle with normals, relative indices
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vt 0.5 0.5
+vn 0 0 1
+vn 0 1 0
+usemtl ignored
+f 1 2 3 4
+f 1//1 2//1 3//2
+f -4/1 -3/1 -2
+"""
+    m = load_obj(io.StringIO(text))
+    assert m.tris.shape == (4, 6, 3)                                   # quad -> 2 (fan), then 1 + 1
+    assert np.array_equal(m.tris[0, :3], [[0, 0, 0], [1, 0, 0], [1, 1, 0]])
+    assert np.array_equal(m.tris[1, :3], [[0, 0, 0], [1, 1, 0], [0, 1, 0]])
+    assert np.array_equal(m.tris[0, 3:], np.broadcast_to([0, 0, 1.0], (3, 3)))      # face normal
+    assert np.array_equal(m.tris[2, 3:], [[0, 0, 1], [0, 0, 1], [0, 1, 0]])          # explicit vn
+    assert np.array_equal(m.tris[3, :3], [[0, 0, 0], [1, 0, 0], [1, 1, 0]])          # negative indices
+    assert np.array_equal(m.tris[3, 3:], np.broadcast_to([0, 0, 1.0], (3, 3)))      # one corner lacks vn -> face normal
+    with pytest.raises(ValueError):
+        load_obj(io.StringIO("v 0 0 0\nf 1 2 3\n"))
+    p = tmp_path / "t.stl"
+    p.write_bytes(b"\0" * 80 + struct.pack("<I", 1) + struct.pack("<12f", 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 2, 0) + b"\0\0")
+    s = load_stl(str(p))
+    assert s.tris.shape == (1, 6, 3) and np.array_equal(s.tris[0, 3], [0, 0, 1])
+    q = tmp_path / "a.stl"
+    q.write_text("solid x\nfacet normal 0 0 0\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\nendloop\nendfacet\nendsolid x\n")
+    assert load_stl(str(q)).tris.shape == (1, 6, 3)
