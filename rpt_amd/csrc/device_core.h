@@ -164,13 +164,12 @@ RPT_DEV float hit_plane(const F4& nv, V o, V d, float tmin) {
 // pre-solved on the host.  Accepts t in [tmin, tmax).
 RPT_DEV float hit_tri(const F4& pn, const F4& A, const F4& B, V o, V d, float tmin, float tmax) {
     float c = dot3(pn, d);
-    if (fabsf(c) < 1e-8f) return -1.f;
     float t = (pn.w - dot3(pn, o)) * rcp(c);
-    if (!(t >= tmin && t < tmax)) return -1.f;
     V p = fma3(t, d, o);
     float v = dot3w(A, p), w = dot3w(B, p);
     float u = 1.f - v - w;
-    return (u >= 0.f && v >= 0.f && w >= 0.f) ? t : -1.f;
+    bool ok = fabsf(c) >= 1e-8f && t >= tmin && t < tmax && u >= 0.f && v >= 0.f && w >= 0.f;
+    return ok ? t : -1.f;
 }
 // Axis-aligned box in world space (a cube under positive scale + translation): the reference's
 // local slab test (src/shape/cube.rs:22-74) evaluated in world coordinates, where it yields the
@@ -186,7 +185,7 @@ RPT_DEV float hit_aabb(const F4& lo, const F4& hi, V o, V inv, float tmin, uint3
     float zl = sz ? z2 : z1, zh = sz ? z1 : z2;
     float start = max3(xl, yl, zl);
     float end = min3(xh, yh, zh);
-    if (start > end || end < tmin) return -1.f;
+    const bool miss = start > end || end < tmin;
     bool use_end = start < tmin;
     if (WANT_FACE) {
         uint32_t as, ae;
@@ -197,7 +196,7 @@ RPT_DEV float hit_aabb(const F4& lo, const F4& hi, V o, V inv, float tmin, uint3
         bool positive = use_end ? !swapped : swapped;
         face = ax | (positive ? 4u : 0u);
     }
-    return use_end ? end : start;
+    return miss ? -1.f : (use_end ? end : start);
 }
 // Axis-aligned rectangle = two coplanar triangles of src/shape/mesh.rs:50-83 (u,v,w >= 0 on one
 // of them <=> the point lies in the closed rectangle).  oa/da/ia: origin, direction and 1/direction
@@ -205,9 +204,9 @@ RPT_DEV float hit_aabb(const F4& lo, const F4& hi, V o, V inv, float tmin, uint3
 RPT_DEV float hit_rect(const F4& a, float vmax, float oa, float ia, float ou, float du, float ov, float dv,
                        float tmin, float tmax) {
     float t = (a.x - oa) * ia;
-    if (!(t >= tmin && t < tmax)) return -1.f;
     float pu = fmaf(t, du, ou), pv = fmaf(t, dv, ov);
-    return (pu >= a.y && pu <= a.z && pv >= a.w && pv <= vmax) ? t : -1.f;
+    bool ok = t >= tmin && t < tmax && pu >= a.y && pu <= a.z && pv >= a.w && pv <= vmax;
+    return ok ? t : -1.f;
 }
 RPT_DEV void to_local(const XfScan& x, V o, V d, V& ol, V& dl) {
     ol = mk(dot3w(x.r0, o), dot3w(x.r1, o), dot3w(x.r2, o));
