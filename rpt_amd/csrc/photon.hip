@@ -613,6 +613,39 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
     return true;
 }
 
+// kd-tree `nearests(q, K)`: the K photons of least squared distance, kept unsorted in the lane's LDS
+// column (gd = squared distances, gi = sorted-array indices).  Returns the number found.
+RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, V x, uint32_t K, float* gd,
+                            uint32_t* gi, float& max_d2) {
+    uint32_t found = 0;
+    float bound = kInf, worst = 0.f;
+    uint32_t worst_slot = 0;
+    if (K > 0) {
+        knn_walk(nodes, photons, n, x, bound, [&](uint32_t idx, float d2) {
+            if (found < K) {
+                gd[found * 256u] = d2;
+                gi[found * 256u] = idx;
+                found++;
+                if (found < K) return kInf;
+            } else if (d2 < worst) {
+                gd[worst_slot * 256u] = d2;
+                gi[worst_slot * 256u] = idx;
+            } else {
+                return worst;
+            }
+            worst = -1.f;  // (re)locate the current worst
+            for (uint32_t k = 0; k < K; k++) {
+                float v = gd[k * 256u];
+                if (v > worst) { worst = v; worst_slot = k; }
+            }
+            return worst;
+        });
+    }
+    max_d2 = 0.f;
+    for (uint32_t k = 0; k < found; k++) max_d2 = fmaxf(max_d2, gd[k * 256u]);
+    return found;
+}
+
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
 template <bool MEDIUM, bool BVH>
@@ -621,7 +654,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
     const RenderArgs& a = q.r;
     const SceneView& sc = a.sc;
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
-    const uint32_t K = q.gather_size;
+    const uint32_t K = max(q.gather_size, q.gather_size_volume);  // LDS columns are sized for the larger gather
     // gather list: [K][256] floats then [K][256] indices, after the BVH stack region
     float* gd = reinterpret_cast<float*>(dyn_lds + (BVH ? 32u * 256u : 0u)) + threadIdx.x;
     uint32_t* gi = reinterpret_cast<uint32_t*>(gd - threadIdx.x + K * 256u) + threadIdx.x;
@@ -693,8 +726,9 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
         V ro = mk(0, 0, 0), rd = mk(0, 0, 1), wo = mk(0, 0, -1);
         float tmin = 0.f, t = kInf;
         uint32_t code = CODE_MISS;
+        Rng rng;
+        rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
         if (active) {
-            Rng rng;
             rng.seed(a.seed_mixed, pix, a.sample_offset + s);
             s++;
             c_samp++;
@@ -706,7 +740,31 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
         }
         const bool hit = code != CODE_MISS;
         V color = mk(0, 0, 0);
-        if (MEDIUM) {  // beam x point volume estimate, src/photon.rs:439-502
+        bool surface_on = hit;
+        float surface_scale = 1.f;
+        if (MEDIUM && q.kind == RPT_PHOTON_MAP) {  // point x point volume estimate, src/photon.rs:384-438
+            if (active) {
+                const float xi = rng.range(0.f, 1.f);               // Medium::sample_d
+                const float dd = -__logf(xi) / sigma_t;
+                const float tr_d = __expf(-sigma_t * dd);
+                if (!hit || dd < t) {
+                    surface_on = false;
+                    const V x = fma3(dd, rd, ro);
+                    const bool hi = sc.medium_kind == 1u && x.y > 250.f;
+                    const V mcol = hi ? mk(sc.medium_color_hi[0], sc.medium_color_hi[1], sc.medium_color_hi[2]) : mcol0;
+                    float max_d2;
+                    const uint32_t found = gather_knn(q.v_nodes, q.v_ph, q.n_v, x, q.gather_size_volume, gd, gi, max_d2);
+                    V sum = mk(0, 0, 0);
+                    for (uint32_t k = 0; k < found; k++) sum = sum + xyz(q.v_ph[gi[k * 256u]].pow);
+                    // / (4/3 pi r^3) / extinction * transmittance / pdf, pdf = sigma_t * transmittance
+                    const float r3 = max_d2 * __builtin_sqrtf(max_d2);
+                    const float scale = sc.medium_phase * rcp((4.f / 3.f) * kPi * r3) * rcp(sigma_t) * tr_d * rcp(sigma_t * tr_d);
+                    color = scale * (sum * mcol);
+                } else {
+                    surface_scale = __expf(-sigma_t * t) * rcp(tr_d);   // transmittance(t) / (1 - cdf), 1 - cdf = T(d)
+                }
+            }
+        } else if (MEDIUM) {  // beam x point volume estimate, src/photon.rs:439-502
             V vc = mk(0, 0, 0);
             const float phase = sc.medium_phase;
             auto visit = [&](const PhotonRec& ph) {
@@ -733,45 +791,14 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
             acc = acc + env;  // src/photon.rs:597
             continue;
         }
-        if (hit) {  // surface estimate, src/photon.rs:327-375
+        if (surface_on) {  // surface estimate, src/photon.rs:327-375
             V n;
             uint32_t obj;
             finalize_hit(sc, ro, rd, tmin, t, code, n, obj);
             const Mat mat = load_mat(sc, obj);
             const V x = fma3(t, rd, ro);
-            uint32_t found = 0;
-            float bound = kInf, worst = 0.f;
-            uint32_t worst_slot = 0;
-            if (K > 0) {
-                knn_walk(q.s_nodes, q.s_ph, q.n_s, x, bound, [&](uint32_t idx, float d2) {
-                    if (found < K) {
-                        gd[found * 256u] = d2;
-                        gi[found * 256u] = idx;
-                        found++;
-                        if (found == K) {  // locate the current worst
-                            worst = -1.f;
-                            for (uint32_t k = 0; k < K; k++) {
-                                float v = gd[k * 256u];
-                                if (v > worst) { worst = v; worst_slot = k; }
-                            }
-                            return worst;
-                        }
-                        return kInf;
-                    }
-                    if (d2 < worst) {
-                        gd[worst_slot * 256u] = d2;
-                        gi[worst_slot * 256u] = idx;
-                        worst = -1.f;
-                        for (uint32_t k = 0; k < K; k++) {
-                            float v = gd[k * 256u];
-                            if (v > worst) { worst = v; worst_slot = k; }
-                        }
-                    }
-                    return worst;
-                });
-            }
-            float max_d2 = 0.f;
-            for (uint32_t k = 0; k < found; k++) max_d2 = fmaxf(max_d2, gd[k * 256u]);
+            float max_d2;
+            const uint32_t found = gather_knn(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2);
             V sc_col = mat_emit(mat) * mat_color(mat);
             for (uint32_t k = 0; k < found; k++) {
                 const PhotonRec ph = q.s_ph[gi[k * 256u]];
@@ -801,7 +828,8 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                 }
             }
             sc_col = (kInvPi * rcp(max_d2)) * sc_col;
-            if (MEDIUM) sc_col = __expf(-sigma_t * t) * sc_col;  // :610-611
+            if (MEDIUM && q.kind == RPT_PHOTON_MAP) sc_col = surface_scale * sc_col;  // :433-435
+            else if (MEDIUM) sc_col = __expf(-sigma_t * t) * sc_col;                  // :610-611
             color = color + sc_col;
         }
         acc = acc + color;
@@ -941,8 +969,8 @@ int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, doub
     rpti::SceneDev sd = rpti::scene_dev(s);
     if (!sd.committed) return rpti::fail(RPT_ERR_STATE, "rpt_scene_commit must be called first");
     if (photon_count == 0) return rpti::fail(RPT_ERR_INVALID, "photon_count must be > 0");
-    if (kind != RPT_PHOTON_POINT_BEAM)
-        return rpti::fail(RPT_ERR_UNSUPPORTED, "only the point-beam photon map (photon_point_query_beam_render) is built on the device");
+    if (kind != RPT_PHOTON_POINT_BEAM && kind != RPT_PHOTON_MAP)
+        return rpti::fail(RPT_ERR_UNSUPPORTED, "the beam-beam photon map (photon_beam_query_beam_render) is not built on the device yet");
     if (sd.first_object_light < 0)
         return rpti::fail(RPT_ERR_INVALID, "Only found non-object lights while photon mapping");  // the reference's panic
     RPTI_HIP_TRY(hipSetDevice(sd.device));
@@ -998,7 +1026,7 @@ int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, doub
     RPTI_HIP_TRY(launch_shoot<true>(a, medium, bvh, blocks, st));
     RPTI_HIP_TRY(hipEventRecord(e1, st));
     int rc = build_lbvh(raw_s, uint32_t(ts), false, pm->surf, st);
-    if (rc == RPT_OK) rc = build_lbvh(raw_v, uint32_t(tv), true, pm->vol, st);
+    if (rc == RPT_OK) rc = build_lbvh(raw_v, uint32_t(tv), kind == RPT_PHOTON_POINT_BEAM, pm->vol, st);
     if (rc != RPT_OK) {
         pm->release();
         delete pm;
@@ -1057,7 +1085,9 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
                               double* d_out, hipStream_t st, bool sync_counters) {
     auto* pm = s ? static_cast<PhotonMapDev*>(rpti::photon_slot(s)) : nullptr;
     if (!pm) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
-    if (gather_size > 56) return rpti::fail(RPT_ERR_UNSUPPORTED, "gather_size > 56 does not fit the LDS gather list");
+    if (std::max(gather_size, gather_size_volume) > 56)
+        return rpti::fail(RPT_ERR_UNSUPPORTED, "gather sizes > 56 do not fit the LDS gather list");
+    const uint64_t gather_lds = pm->kind == RPT_PHOTON_MAP ? std::max(gather_size, gather_size_volume) : gather_size;
     QueryArgs q{};
     int rc = rpti::prepare_render(s, cam, prm, num_samples, seed, sample_offset, q.r);
     if (rc) return rc;
@@ -1065,9 +1095,9 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     q.v_nodes = pm->vol.nodes; q.v_ph = pm->vol.sorted; q.n_v = pm->vol.n;
     q.kind = uint32_t(pm->kind);
     q.gather_size = uint32_t(gather_size);
-    q.gather_size_volume = uint32_t(gather_size_volume);
+    q.gather_size_volume = pm->kind == RPT_PHOTON_MAP ? uint32_t(gather_size_volume) : 0u;  // only the point-point estimate gathers in the volume
     const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_mesh != 0;
-    const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + size_t(gather_size) * 256u * 8u + 4u * kBeamCap * 4u + 4u * 256u * 16u;
+    const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + size_t(gather_lds) * 256u * 8u + 4u * kBeamCap * 4u + 4u * 256u * 16u;
     if (!pm->d_overflow) RPTI_HIP_TRY(hipMalloc((void**)&pm->d_overflow, 64));
     RPTI_HIP_TRY(hipMemsetAsync(pm->d_overflow, 0, 4, st));
     q.overflow = pm->d_overflow;

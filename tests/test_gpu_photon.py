@@ -76,6 +76,26 @@ def test_photon_camera_pass_matches_oracle(name, tol):
     assert (d > 0.01).mean() < 0.03
 
 
+@pytest.mark.parametrize("name,tol", [("C4", 2e-2), ("C2", 3e-2)])
+def test_point_point_photon_map_matches_oracle(name, tol):
+    """PhotonRenderKind::PhotonMap (photon_map_render): k-nearest volume gather at a sampled distance
+    (src/photon.rs:384-438) or the surface estimate scaled by T(t) / (1 - cdf)."""
+    scene, cam, cfg = scenes.CONFIGS[name]()
+    n, size, spp = 20000, 64, 4
+    watts = 14.65 * n
+    r = Renderer(scene, cam).width(size).height(size).watts(watts).gather_size(20).gather_size_volume(8).seed(2)
+    st = r.photon_map_build(n, Renderer.PHOTON_MAP)
+    got = r.photon_sample_array(spp)
+    pm = _oracle(scene).photon_map(n, 0, watts, 20, 8, seed=2, robust=1)
+    exp = pm.render(cam, size, size, spp, seed=2)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    # the volume gather's 1/r^3 amplifies the few fp32-flipped photon chains more than the beam estimate does
+    assert rel_rms(got, exp) < tol
+    assert abs(got.mean() - exp.mean()) / exp.mean() < 5e-3
+    d = np.abs(got - exp).sum(axis=1) / (np.abs(exp).sum(axis=1) + 1e-9)
+    assert (d > 0.01).mean() < 0.05
+
+
 def test_photon_render_builder_entry_point_and_sharding():
     scene, cam, cfg = scenes.CONFIGS["C4"]()
     size = 64
