@@ -146,9 +146,8 @@ int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* g
 int rpt_set_option(const char* name, int64_t value);
 
 /* ---- photon mapping (next tier: src/photon.rs; config C4 = photon_point_query_beam_render) ----
- * `enum PhotonRenderKind` (src/photon.rs:631-639).  The device builds the point maps for the
- * point-point (RPT_PHOTON_MAP) and beam-point (RPT_PHOTON_POINT_BEAM) estimates;
- * RPT_PHOTON_BEAM_BEAM returns RPT_ERR_UNSUPPORTED for now. */
+ * `enum PhotonRenderKind` (src/photon.rs:631-639): point-point (photon_map_render), beam-point
+ * (photon_point_query_beam_render, config C4) and beam-beam (photon_beam_query_beam_render). */
 enum { RPT_PHOTON_MAP = 0, RPT_PHOTON_POINT_BEAM = 1, RPT_PHOTON_BEAM_BEAM = 2 };
 /* Renderer::photon_render, first half (src/photon.rs:655-704): shoot `photon_count` photons of
  * power watts/photon_count from the first Light::Object (shoot_photon / trace_photon, :724-946),

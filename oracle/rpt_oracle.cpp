@@ -1070,7 +1070,7 @@ static void trace_photon(const Renderer& r, Ray ray, V3 power, Rng& rng, PhotonL
     }
 }
 // shoot_photon, src/photon.rs:724-799 (first Light::Object only, as written)
-static bool shoot_photon(const Renderer& r, double power, Rng& rng, int kind, PhotonList& out) {
+static bool shoot_photon(const Renderer& r, double power, Rng& rng, Rng& thin, int kind, PhotonList& out) {
     for (const Light& light : r.scene.lights) {
         if (light.kind != L_OBJECT) continue;
         SurfSample s = light.object.shape->sample(V3(0, 0, 0), rng);
@@ -1084,9 +1084,9 @@ static bool shoot_photon(const Renderer& r, double power, Rng& rng, int kind, Ph
         trace_photon(r, Ray{s.v, direction}, power * light.object.material.color(), rng, mine);
         for (const Photon& p : mine.surface) out.surface.push_back(p);
         for (Photon p : mine.volume) {
-            if (kind == PK_BEAM_BEAM) {  // :779-787 thinning
+            if (kind == PK_BEAM_BEAM) {  // :779-787 thinning (iid Bernoulli draws; taken from a side stream in path order)
                 const double thresh = 0.001;
-                if (rng.uniform() < thresh) {
+                if (thin.uniform() < thresh) {
                     p.power = p.power / thresh;
                     out.volume.push_back(p);
                 }
@@ -1143,28 +1143,33 @@ struct PointKd {
         }
     }
 };
-// Median-split BVH over photon spheres; visit() is called for every sphere whose box the ray hits.
+// Median-split BVH over item boxes (photon spheres or photon beams); visit() is called for every
+// item whose own AABB the half-infinite ray hits: the candidate set of bvh 0.6 `traverse`.
 struct SphereBvh {
     struct Node { V3 lo, hi; uint32_t left, right, first, count; };
     std::vector<Node> nodes;
     std::vector<uint32_t> order;
-    const std::vector<V3>* pos = nullptr;
-    const std::vector<double>* rad = nullptr;
+    std::vector<V3> ilo, ihi;
     void build(const std::vector<V3>& p, const std::vector<double>& r) {
-        pos = &p; rad = &r;
-        order.resize(p.size());
-        for (size_t i = 0; i < p.size(); i++) order[i] = uint32_t(i);
-        nodes.clear();
-        if (!p.empty()) rec(0, uint32_t(p.size()));
+        std::vector<V3> lo(p.size()), hi(p.size());
+        for (size_t i = 0; i < p.size(); i++) { lo[i] = p[i] - V3(r[i], r[i], r[i]); hi[i] = p[i] + V3(r[i], r[i], r[i]); }
+        build_boxes(lo, hi);
     }
+    void build_boxes(const std::vector<V3>& lo, const std::vector<V3>& hi) {
+        ilo = lo; ihi = hi;
+        order.resize(lo.size());
+        for (size_t i = 0; i < lo.size(); i++) order[i] = uint32_t(i);
+        nodes.clear();
+        if (!lo.empty()) rec(0, uint32_t(lo.size()));
+    }
+    V3 centre(uint32_t i) const { return 0.5 * (ilo[i] + ihi[i]); }
     uint32_t rec(uint32_t first, uint32_t count) {
         uint32_t me = uint32_t(nodes.size());
         nodes.push_back(Node{});
         V3 lo(INF, INF, INF), hi(-INF, -INF, -INF), clo(INF, INF, INF), chi(-INF, -INF, -INF);
         for (uint32_t i = first; i < first + count; i++) {
-            const V3& c = (*pos)[order[i]];
-            double r = (*rad)[order[i]];
-            lo = vmin(lo, c - V3(r, r, r)); hi = vmax(hi, c + V3(r, r, r));
+            lo = vmin(lo, ilo[order[i]]); hi = vmax(hi, ihi[order[i]]);
+            V3 c = centre(order[i]);
             clo = vmin(clo, c); chi = vmax(chi, c);
         }
         nodes[me].lo = lo; nodes[me].hi = hi; nodes[me].first = first; nodes[me].count = count;
@@ -1174,11 +1179,17 @@ struct SphereBvh {
             int ax = (e.x > e.y && e.x > e.z) ? 0 : (e.y > e.z ? 1 : 2);
             uint32_t mid = first + count / 2;
             std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
-                             [&](uint32_t a, uint32_t b) { return (*pos)[a][ax] < (*pos)[b][ax]; });
+                             [&](uint32_t a, uint32_t b) { return centre(a)[ax] < centre(b)[ax]; });
             uint32_t l = rec(first, mid - first), rr = rec(mid, first + count - mid);
             nodes[me].left = l; nodes[me].right = rr; nodes[me].count = 0;
         }
         return me;
+    }
+    static bool box_hit(const V3& lo, const V3& hi, const Ray& ray) {
+        BBox b; b.p_min = lo; b.p_max = hi;
+        double t0, t1;
+        b.intersect(ray, t0, t1);
+        return t1 >= std::fmax(t0, 0.0);
     }
     template <class F>
     void traverse(const Ray& ray, F&& visit) const {
@@ -1188,12 +1199,11 @@ struct SphereBvh {
         stack[sp++] = 0;
         while (sp) {
             const Node& n = nodes[stack[--sp]];
-            BBox b; b.p_min = n.lo; b.p_max = n.hi;
-            double t0, t1;
-            b.intersect(ray, t0, t1);
-            if (!(t1 >= std::fmax(t0, 0.0))) continue;
-            if (n.count) { for (uint32_t i = n.first; i < n.first + n.count; i++) visit(order[i]); }
-            else { stack[sp++] = n.left; stack[sp++] = n.right; }
+            if (!box_hit(n.lo, n.hi, ray)) continue;
+            if (n.count) {
+                for (uint32_t i = n.first; i < n.first + n.count; i++)
+                    if (box_hit(ilo[order[i]], ihi[order[i]], ray)) visit(order[i]);
+            } else { stack[sp++] = n.left; stack[sp++] = n.right; }
         }
     }
 };
@@ -1208,6 +1218,20 @@ struct PhotonMap {  // src/photon.rs:181-311
     void build() {
         surface_kd.build(list.surface);
         volume_kd.build(list.volume);
+        if (kind == PK_BEAM_BEAM) {  // :250-305: fixed radius 3, beam = segment from the previous vertex
+            size_t n = list.volume.size();
+            std::vector<V3> lo(n), hi(n);
+            sphere_radius.assign(n, 3.0);
+            for (size_t i = 0; i < n; i++) {  // impl Bounded for PhotonBeam, :74-104
+                V3 a = list.volume[i].starting_position, b = list.volume[i].position;
+                double cx = (a.x - b.x) * (a.x - b.x), cy = (a.y - b.y) * (a.y - b.y), cz = (a.z - b.z) * (a.z - b.z);
+                double sum = cx + cy + cz;
+                V3 adj(std::sqrt((cy + cz) / sum) * 3.0, std::sqrt((cx + cz) / sum) * 3.0, std::sqrt((cx + cy) / sum) * 3.0);
+                lo[i] = vmin(a, b) - adj;
+                hi[i] = vmax(a, b) + adj;
+            }
+            bvh.build_boxes(lo, hi);
+        }
         if (kind == PK_POINT_BEAM) {  // :204-247
             size_t n = list.volume.size();
             sphere_pos.resize(n);
@@ -1297,6 +1321,39 @@ static V3 photon_estimate_indirect(const Renderer& r, const PhotonMap& pm, const
         });
         return volume_color;
     };
+    auto volume_beam_beam = [&](const HitRecord* hp) {  // :503-593
+        V3 dummy(0, 0, 0);
+        V3 medium_color = medium->color(dummy);
+        double extinction = medium->extinction(dummy);
+        V3 volume_color(0, 0, 0);
+        pm.bvh.traverse(ray, [&](uint32_t i) {
+            const Photon& ph = pm.list.volume[i];
+            const double radius = pm.sphere_radius[i];
+            V3 bstart = ph.starting_position, bend = ph.position;
+            V3 bdir = normalize(bend - bstart);
+            V3 l = bstart - ray.origin;
+            V3 u = normalize(cross(l, bdir));
+            V3 n = normalize(cross(bdir, u));
+            double t = dot(n, l) / dot(n, ray.dir);
+            V3 query_collision = ray.at(t);
+            if (hp && t >= hp->time) return;
+            double dd = dot(ray.dir, bdir);
+            double inv_sin_theta = 1.0 / std::sqrt(std::fmax(0.0, 1.0 - dd * dd));
+            double beam_t = dot(bdir, query_collision - bstart);
+            double beam_len = length(bend - bstart);
+            if (beam_t < 0.0 || beam_t > beam_len) return;
+            V3 beam_collision = bstart + beam_t * bdir;
+            double dist = length(query_collision - beam_collision);
+            if (dist >= radius) return;
+            double tmp = 1.0 - dist / radius;
+            double k2 = (3.0 / PI) * tmp * tmp;
+            V3 color = extinction * cmul(ph.power, medium_color) * medium->phase(-bdir, -ray.dir) * inv_sin_theta *
+                       std::exp(-extinction * t) * std::exp(-extinction * beam_t) * k2 / (2.0 * radius);
+            volume_color = volume_color + color;
+        });
+        (void)rng.uniform();  // the debug print's draw, src/photon.rs:587
+        return volume_color;
+    };
     auto volume_point = [&](const HitRecord* hp, const Material* material) {  // :384-438
         double d, d_pdf, d_cdf;
         medium->sample_d(ray, rng, d, d_pdf, d_cdf);
@@ -1321,12 +1378,13 @@ static V3 photon_estimate_indirect(const Renderer& r, const PhotonMap& pm, const
     };
     if (!hit) {
         if (!medium) return scene.environment;
+        if (pm.kind == PK_BEAM_BEAM) return volume_beam_beam(nullptr);
         return pm.kind == PK_PHOTON_MAP ? volume_point(nullptr, nullptr) : volume_beam(nullptr);
     }
     const Material& material = scene.objects[oi].material;
     if (!medium) return photon_surface_estimate(r, pm, pp, ray, h, material, wo);
     if (pm.kind == PK_PHOTON_MAP) return volume_point(&h, &material);
-    V3 volume_color = volume_beam(&h);
+    V3 volume_color = pm.kind == PK_BEAM_BEAM ? volume_beam_beam(&h) : volume_beam(&h);
     V3 surface_color = photon_surface_estimate(r, pm, pp, ray, h, material, wo) * medium->transmittence(ray, h.time);
     (void)rng.uniform();  // the debug print's draw, src/photon.rs:619
     return surface_color + volume_color;
@@ -1640,7 +1698,8 @@ orc_photon_map* orc_photon_map_build(orc_scene* s, uint64_t photon_count, int ki
     double power = watts / double(photon_count);
     for (uint64_t i = 0; i < photon_count; i++) {
         Rng rng(seed, uint32_t(i), 0x80000000u + uint32_t(i >> 32));
-        if (!shoot_photon(r, power, rng, kind, m->pm.list)) {
+        Rng thin(seed, uint32_t(i), 0xC0000000u + uint32_t(i >> 32));
+        if (!shoot_photon(r, power, rng, thin, kind, m->pm.list)) {
             delete m;
             return nullptr;
         }
@@ -1656,7 +1715,9 @@ uint64_t orc_photon_map_get(orc_photon_map* m, int which, double* out) {
         for (size_t i = 0; i < v.size(); i++) {
             double* o = out + i * 10;
             o[0] = v[i].position.x; o[1] = v[i].position.y; o[2] = v[i].position.z;
-            o[3] = v[i].direction.x; o[4] = v[i].direction.y; o[5] = v[i].direction.z;
+            const bool beam = which == 1 && m->pm.kind == PK_BEAM_BEAM;  // beams: slots 3..5 = start of the beam
+            const V3& dd = beam ? v[i].starting_position : v[i].direction;
+            o[3] = dd.x; o[4] = dd.y; o[5] = dd.z;
             o[6] = v[i].power.x; o[7] = v[i].power.y; o[8] = v[i].power.z;
             o[9] = (which == 1 && i < m->pm.sphere_radius.size()) ? m->pm.sphere_radius[i] : 0.0;
         }

@@ -34,6 +34,7 @@ struct ShootArgs {
     uint64_t n_photons, seed_mixed;
     float power;  // watts / photon_count
     uint32_t light_index;
+    uint32_t kind;  // RPT_PHOTON_*: beam-beam thins the volume photons and records each beam's start
     uint32_t* cnt_s;
     uint32_t* cnt_v;
     const uint64_t* off_s;
@@ -53,8 +54,10 @@ __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
     const float albedo_med = MEDIUM ? sc.sigma_s / sigma_t : 0.f;
     const Light L = uload(&sc.lights[a.light_index]);
     for (uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x; i < a.n_photons; i += uint64_t(gridDim.x) * 256u) {
-        Rng rng;
+        Rng rng, thin;
         rng.seed(a.seed_mixed, uint32_t(i), 0x80000000u + uint32_t(i >> 32));
+        thin.seed(a.seed_mixed, uint32_t(i), 0xC0000000u + uint32_t(i >> 32));  // thinning side stream
+        const bool beams = a.kind == RPT_PHOTON_BEAM_BEAM;
         V ro, n0;
         float p0;
         sample_light_shape(sc, L, mk(0.f, 0.f, 0.f), rng, ro, n0, p0);  // :733-734 (target is a dummy)
@@ -86,14 +89,19 @@ __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
                 bool hi = sc.medium_kind == 1u && x.y > 250.f;
                 V mcol = hi ? mk(sc.medium_color_hi[0], sc.medium_color_hi[1], sc.medium_color_hi[2])
                             : mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);
-                if (WRITE) {
-                    PhotonRec r;
-                    r.pos_r = F4{x.x, x.y, x.z, 0.f};
-                    r.dir = F4{wo.x, wo.y, wo.z, 0.f};
-                    r.pow = F4{power.x, power.y, power.z, 0.f};
-                    a.vol[ov + nv] = r;
+                // beam-beam map: keep 0.1 % of the volume photons at 1000x power (src/photon.rs:779-787)
+                const bool keep = !beams || thin.uniform() < 0.001f;
+                if (keep) {
+                    if (WRITE) {
+                        const float boost = beams ? 1000.f : 1.f;
+                        PhotonRec r;
+                        r.pos_r = F4{x.x, x.y, x.z, beams ? 3.f : 0.f};          // beams: fixed radius 3 (:280)
+                        r.dir = beams ? F4{ro.x, ro.y, ro.z, 0.f} : F4{wo.x, wo.y, wo.z, 0.f};  // beams: start of the beam
+                        r.pow = F4{boost * power.x, boost * power.y, boost * power.z, 0.f};
+                        a.vol[ov + nv] = r;
+                    }
+                    nv++;
                 }
-                nv++;
                 if (!(rng.uniform() < albedo_med)) break;
                 float ax = rng.range(-1.f, 1.f), ay = rng.range(-1.f, 1.f), az = rng.range(-1.f, 1.f);
                 power = albedo_med * (power * mcol);  // phase / ph_p == 1
@@ -151,11 +159,35 @@ RPT_DEV uint64_t expand21(uint32_t v) {  // spread 21 bits to every third bit
     x = (x | x << 2) & 0x1249249249249249ull;
     return x;
 }
-__global__ void bounds_kernel(const PhotonRec* p, uint32_t n, float* lohi /*6, pre-set to +inf/-inf*/) {
+// Leaf box of a photon record.  mode 0: the point; 1: sphere of radius pos_r.w; 2: photon beam from
+// dir.xyz (start) to pos_r.xyz (end) with radius pos_r.w, box as `impl Bounded for PhotonBeam`
+// (src/photon.rs:74-104).
+RPT_DEV void leaf_box(const PhotonRec& p, int mode, float lo[3], float hi[3]) {
+    const F4 q = p.pos_r;
+    if (mode == 2) {
+        const float a[3] = {p.dir.x, p.dir.y, p.dir.z}, b[3] = {q.x, q.y, q.z};
+        const float cx = (a[0] - b[0]) * (a[0] - b[0]), cy = (a[1] - b[1]) * (a[1] - b[1]), cz = (a[2] - b[2]) * (a[2] - b[2]);
+        const float is = rcp(cx + cy + cz);
+        const float k[3] = {__builtin_sqrtf((cy + cz) * is), __builtin_sqrtf((cx + cz) * is), __builtin_sqrtf((cx + cy) * is)};
+        for (int i = 0; i < 3; i++) {
+            float adj = k[i] * q.w * (1.f + 1e-6f);
+            lo[i] = fminf(a[i], b[i]) - adj;
+            hi[i] = fmaxf(a[i], b[i]) + adj;
+        }
+    } else {
+        const float r = mode == 1 ? q.w * (1.f + 1e-6f) : 0.f;
+        lo[0] = q.x - r; lo[1] = q.y - r; lo[2] = q.z - r;
+        hi[0] = q.x + r; hi[1] = q.y + r; hi[2] = q.z + r;
+    }
+}
+RPT_DEV V record_centre(const PhotonRec& p, int mode) {
+    return mode == 2 ? mk(0.5f * (p.pos_r.x + p.dir.x), 0.5f * (p.pos_r.y + p.dir.y), 0.5f * (p.pos_r.z + p.dir.z)) : xyz(p.pos_r);
+}
+__global__ void bounds_kernel(const PhotonRec* p, uint32_t n, float* lohi /*6, pre-set to +inf/-inf*/, int mode) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
     for (; i < n; i += gridDim.x * blockDim.x) {
-        F4 q = p[i].pos_r;
+        V q = record_centre(p[i], mode);
         lo[0] = fminf(lo[0], q.x); lo[1] = fminf(lo[1], q.y); lo[2] = fminf(lo[2], q.z);
         hi[0] = fmaxf(hi[0], q.x); hi[1] = fmaxf(hi[1], q.y); hi[2] = fmaxf(hi[2], q.z);
     }
@@ -173,10 +205,10 @@ __global__ void bounds_kernel(const PhotonRec* p, uint32_t n, float* lohi /*6, p
         }
     }
 }
-__global__ void morton_kernel(const PhotonRec* p, uint32_t n, const float* lohi, uint64_t* keys, uint32_t* vals) {
+__global__ void morton_kernel(const PhotonRec* p, uint32_t n, const float* lohi, uint64_t* keys, uint32_t* vals, int mode) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    F4 q = p[i].pos_r;
+    V q = record_centre(p[i], mode);
     float ex = fmaxf(lohi[3] - lohi[0], 1e-30f), ey = fmaxf(lohi[4] - lohi[1], 1e-30f), ez = fmaxf(lohi[5] - lohi[2], 1e-30f);
     const float s = 2097151.f;
     uint32_t x = uint32_t(fminf(fmaxf((q.x - lohi[0]) / ex * s, 0.f), s));
@@ -241,10 +273,9 @@ __global__ void refit_kernel(const PhotonRec* p, int n, const uint32_t* left, co
         uint32_t ch[2] = {left[node], right[node]};
         for (int c = 0; c < 2; c++) {
             if (ch[c] & BVH_LEAF) {
-                F4 q = p[ch[c] & 0x7FFFFFFFu].pos_r;
-                float r = use_radius ? q.w : 0.f;
-                lo[0] = fminf(lo[0], q.x - r); lo[1] = fminf(lo[1], q.y - r); lo[2] = fminf(lo[2], q.z - r);
-                hi[0] = fmaxf(hi[0], q.x + r); hi[1] = fmaxf(hi[1], q.y + r); hi[2] = fmaxf(hi[2], q.z + r);
+                float l[3], h[3];
+                leaf_box(p[ch[c] & 0x7FFFFFFFu], use_radius, l, h);
+                for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], l[k]); hi[k] = fmaxf(hi[k], h[k]); }
             } else {
                 const volatile float* b = box + size_t(ch[c]) * 6;
                 for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], b[k]); hi[k] = fmaxf(hi[k], b[3 + k]); }
@@ -267,10 +298,7 @@ __global__ void pack_kernel(const PhotonRec* p, int n, const uint32_t* left, con
     float lo[2][3], hi[2][3];
     for (int c = 0; c < 2; c++) {
         if (ch[c] & BVH_LEAF) {
-            F4 q = p[ch[c] & 0x7FFFFFFFu].pos_r;
-            float r = use_radius ? q.w * (1.f + 1e-6f) : 0.f;
-            lo[c][0] = q.x - r; lo[c][1] = q.y - r; lo[c][2] = q.z - r;
-            hi[c][0] = q.x + r; hi[c][1] = q.y + r; hi[c][2] = q.z + r;
+            leaf_box(p[ch[c] & 0x7FFFFFFFu], use_radius, lo[c], hi[c]);
         } else {
             const float* b = box + size_t(ch[c]) * 6;
             for (int k = 0; k < 3; k++) { lo[c][k] = b[k]; hi[c][k] = b[3 + k]; }
@@ -782,8 +810,46 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                     vc = fma3(w, xyz(ph.pow), vc);
                 }
             };
-            if (!beam_walk_packet(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit))
-                beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit);
+            // beam x beam estimate, src/photon.rs:503-593 (equation 38 of Jarosz et al.)
+            const V inv_rd = mk(rcp(rd.x), rcp(rd.y), rcp(rd.z));
+            auto visit_beam = [&](const PhotonRec& ph) {
+                c_leaf++;
+                float lo[3], hi[3], tn, tf;
+                leaf_box(ph, 2, lo, hi);
+                slab2(lo, hi, ro, inv_rd, tn, tf);
+                if (!(fmaxf(tn, 0.f) <= tf)) return;  // bvh `traverse`: only beams whose own box the ray hits
+                const V bstart = xyz(ph.dir), bend = xyz(ph.pos_r);
+                const float radius = ph.pos_r.w;
+                const V bvec = bend - bstart;
+                const float beam_len = __builtin_sqrtf(dot(bvec, bvec));
+                const V bdir = rcp(beam_len) * bvec;
+                const V l = bstart - ro;
+                const V u = normalize(cross(l, bdir));
+                const V nn = normalize(cross(bdir, u));
+                const float tq = dot(nn, l) * rcp(dot(nn, rd));
+                const V qc = fma3(tq, rd, ro);
+                const float dd = dot(rd, bdir);
+                const float beam_t = dot(bdir, qc - bstart);
+                const V bc = fma3(beam_t, bdir, bstart);
+                const V dq = qc - bc;
+                const float dist = __builtin_sqrtf(dot(dq, dq));
+                const bool ok = !(hit && tq >= t) && beam_t >= 0.f && beam_t <= beam_len && dist < radius;
+                if (ok) {
+                    c_acc++;
+                    const float inv_sin = rsq(fmaxf(0.f, 1.f - dd * dd));
+                    const float tmp = 1.f - dist * rcp(radius);
+                    const float w = sigma_t * phase * inv_sin * __expf(-sigma_t * tq) * __expf(-sigma_t * beam_t) *
+                                    (3.f * kInvPi) * tmp * tmp * rcp(2.f * radius);
+                    vc = fma3(w, xyz(ph.pow), vc);
+                }
+            };
+            if (q.kind == RPT_PHOTON_BEAM_BEAM) {
+                if (!beam_walk_packet(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit_beam))
+                    beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit_beam);
+            } else {
+                if (!beam_walk_packet(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit))
+                    beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit);
+            }
             color = vc * mcol0;
         }
         if (!active) continue;
@@ -884,7 +950,10 @@ struct Tmp {
 
 // Build the LBVH of `n` photons in `raw` (consumed: the sorted copy is kept).  radius_k > 0: also
 // compute the k-NN radii and refit the boxes with them (sphere map for the beam query).
-int build_lbvh(PhotonRec* raw, uint32_t n, bool with_radius, DevLbvh& out, hipStream_t st) {
+// mode 0: point map; 1: point map + k-NN radii, then sphere boxes; 2: beam map (boxes of whole beams)
+int build_lbvh(PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t st) {
+    const bool with_radius = mode == 1;
+    const int first_mode = mode == 2 ? 2 : 0;
     out = DevLbvh{};
     out.n = n;
     if (n == 0) return RPT_OK;
@@ -908,8 +977,8 @@ int build_lbvh(PhotonRec* raw, uint32_t n, bool with_radius, DevLbvh& out, hipSt
     float init[6] = {inf, inf, inf, -inf, -inf, -inf};
     RPTI_HIP_TRY(hipMemcpyAsync(lohi, init, sizeof(init), hipMemcpyHostToDevice, st));
     uint32_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(bounds_kernel, dim3(std::min(blocks, 1024u)), dim3(256), 0, st, raw, n, lohi);
-    hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(256), 0, st, raw, n, lohi, keys, vals);
+    hipLaunchKernelGGL(bounds_kernel, dim3(std::min(blocks, 1024u)), dim3(256), 0, st, raw, n, lohi, first_mode);
+    hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(256), 0, st, raw, n, lohi, keys, vals, first_mode);
     size_t temp_bytes = 0;
     RPTI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys2, vals, vals2, int(n), 0, 63, st));
     void* temp;
@@ -921,8 +990,8 @@ int build_lbvh(PhotonRec* raw, uint32_t n, bool with_radius, DevLbvh& out, hipSt
         RPTI_HIP_TRY(hipMalloc((void**)&out.nodes, size_t(n - 1) * sizeof(BvhNode)));
         hipLaunchKernelGGL(karras_kernel, dim3(blocks), dim3(256), 0, st, keys2, int(n), left, right, par_i, par_l);
         RPTI_HIP_TRY(hipMemsetAsync(flags, 0, size_t(n) * 4, st));
-        hipLaunchKernelGGL(refit_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, par_i, par_l, flags, box, 0);
-        hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, out.nodes, 0);
+        hipLaunchKernelGGL(refit_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, par_i, par_l, flags, box, first_mode);
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, out.nodes, first_mode);
     }
     if (with_radius) {
         float* radius;
@@ -969,8 +1038,8 @@ int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, doub
     rpti::SceneDev sd = rpti::scene_dev(s);
     if (!sd.committed) return rpti::fail(RPT_ERR_STATE, "rpt_scene_commit must be called first");
     if (photon_count == 0) return rpti::fail(RPT_ERR_INVALID, "photon_count must be > 0");
-    if (kind != RPT_PHOTON_POINT_BEAM && kind != RPT_PHOTON_MAP)
-        return rpti::fail(RPT_ERR_UNSUPPORTED, "the beam-beam photon map (photon_beam_query_beam_render) is not built on the device yet");
+    if (kind != RPT_PHOTON_POINT_BEAM && kind != RPT_PHOTON_MAP && kind != RPT_PHOTON_BEAM_BEAM)
+        return rpti::fail(RPT_ERR_INVALID, "unknown PhotonRenderKind");
     if (sd.first_object_light < 0)
         return rpti::fail(RPT_ERR_INVALID, "Only found non-object lights while photon mapping");  // the reference's panic
     RPTI_HIP_TRY(hipSetDevice(sd.device));
@@ -995,6 +1064,7 @@ int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, doub
     a.seed_mixed = rpti::seed_mix(seed);
     a.power = float(watts / double(photon_count));
     a.light_index = uint32_t(sd.first_object_light);
+    a.kind = uint32_t(kind);
     RPTI_HIP_TRY(tmp.alloc(&a.cnt_s, photon_count));
     RPTI_HIP_TRY(tmp.alloc(&a.cnt_v, photon_count));
     const bool medium = sd.view.has_medium != 0, bvh = sd.view.n_mesh != 0;
@@ -1025,8 +1095,9 @@ int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, doub
     a.vol = raw_v;
     RPTI_HIP_TRY(launch_shoot<true>(a, medium, bvh, blocks, st));
     RPTI_HIP_TRY(hipEventRecord(e1, st));
-    int rc = build_lbvh(raw_s, uint32_t(ts), false, pm->surf, st);
-    if (rc == RPT_OK) rc = build_lbvh(raw_v, uint32_t(tv), kind == RPT_PHOTON_POINT_BEAM, pm->vol, st);
+    int rc = build_lbvh(raw_s, uint32_t(ts), 0, pm->surf, st);
+    if (rc == RPT_OK)
+        rc = build_lbvh(raw_v, uint32_t(tv), kind == RPT_PHOTON_POINT_BEAM ? 1 : (kind == RPT_PHOTON_BEAM_BEAM ? 2 : 0), pm->vol, st);
     if (rc != RPT_OK) {
         pm->release();
         delete pm;

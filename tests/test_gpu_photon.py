@@ -96,6 +96,30 @@ def test_point_point_photon_map_matches_oracle(name, tol):
     assert (d > 0.01).mean() < 0.05
 
 
+def test_beam_beam_photon_map_matches_oracle():
+    """PhotonRenderKind::PhotonBeamBeam (photon_beam_query_beam_render): 0.1 % of the volume photons
+    survive as beams of radius 3 at 1000x power (src/photon.rs:779-787, 250-305) and the camera ray is
+    tested against whole beams (:503-593)."""
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    n, size, spp = 200000, 48, 2
+    watts = 14.65 * n
+    r = Renderer(scene, cam).width(size).height(size).watts(watts).gather_size(20).gather_size_volume(3).seed(5)
+    st = r.photon_map_build(n, Renderer.PHOTON_BEAM_BEAM)
+    pm = _oracle(scene).photon_map(n, 2, watts, 20, 3, seed=5, robust=1)
+    gb, eb = r.photon_map_download(1), pm.photons(1)
+    assert 200 < len(eb) < 800 and abs(len(gb) - len(eb)) <= 3           # ~0.1 % of ~400k volume photons
+    ok, j = _match(gb, eb)
+    assert ok.mean() > 0.99
+    gp, ep = gb[j[ok]], eb[ok]
+    assert np.quantile(np.abs(gp[:, 3:6] - ep[:, 3:6]).max(axis=1) / (1 + np.abs(ep[:, 3:6]).max(axis=1)), 0.99) < 1e-4   # beam start
+    assert np.allclose(gp[:, 9], 3.0) and np.quantile(np.abs(gp[:, 6:9] - ep[:, 6:9]) / (ep[:, 6:9] + 1e-9), 0.99) < 1e-4
+    got = r.photon_sample_array(spp)
+    exp = pm.render(cam, size, size, spp, seed=5)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert rel_rms(got, exp) < 3e-2
+    assert abs(got.mean() - exp.mean()) / exp.mean() < 5e-3
+
+
 def test_photon_render_builder_entry_point_and_sharding():
     scene, cam, cfg = scenes.CONFIGS["C4"]()
     size = 64
@@ -129,4 +153,4 @@ def test_photon_mapping_errors():
     with pytest.raises(RptError):
         r2.photon_sample_array(1)                              # no map built yet
     with pytest.raises(RptError):
-        r2.photon_map_build(100, Renderer.PHOTON_BEAM_BEAM)    # not on the device yet
+        r2.photon_map_build(100, 7)                            # unknown PhotonRenderKind

@@ -159,3 +159,58 @@ def test_photon_render_needs_an_object_light():
     scene.add(Light.Ambient(vec3(1, 1, 1)))
     with pytest.raises(ValueError):                          # panic!("Only found non-object lights ...")
         OracleScene(scene).photon_map(10, 1, 1.0)
+
+
+def test_beam_beam_estimate_matches_brute_force():
+    """PhotonBeamBeam (src/photon.rs:503-593) for camera rays that miss all geometry: the estimate is
+    the sum over every beam whose own box the ray hits, recomputed here in numpy."""
+    scene = Scene()
+    quad = polygon([vec3(30, 0, -30), vec3(30, 0, 30), vec3(-30, 0, 30), vec3(-30, 0, -30)])     # faces down
+    scene.add((quad, Material.light(vec3(1, 1, 1), 1.0)))
+    sa, ss = 0.002, 0.02
+    scene.add(Medium.homogeneous_isotropic(sa, ss))
+    osc = OracleScene(scene)
+    n = 60000
+    pm = osc.photon_map(n, 2, float(n), seed=4, robust=1)
+    beams = pm.photons(1)
+    assert 100 < len(beams) < 600 and np.allclose(beams[:, 9], 3.0)
+    cam = Camera.look_at(vec3(0, -60, 150), vec3(0, -60, 0), vec3(0, 1, 0), 0.3)
+    w = h = 8
+    pixels = np.arange(w * h, dtype=np.uint32)
+    got = pm.render(cam, w, h, 1, seed=2, threads=1, pixels=pixels)
+    ext = sa + ss
+    mcol = hex_color(0xD2B48C)
+    end, start, power = beams[:, :3], beams[:, 3:6], beams[:, 6:9]
+    bvec = end - start
+    blen = np.linalg.norm(bvec, axis=1)
+    bdir = bvec / blen[:, None]
+    sq = (start - end) ** 2
+    ssum = sq.sum(1)
+    adj = np.sqrt(np.stack([sq[:, 1] + sq[:, 2], sq[:, 0] + sq[:, 2], sq[:, 0] + sq[:, 1]], 1) / ssum[:, None]) * 3.0
+    lo, hi = np.minimum(start, end) - adj, np.maximum(start, end) + adj
+    nonzero = 0
+    for pix in pixels:
+        o, d = _camera_ray(cam, w, h, int(pix), 2, 0)
+        t, obj, _ = osc.intersect(o[None], d[None], robust=1)
+        assert obj[0] < 0                                   # the camera looks past the quad
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t1, t2 = (lo - o) / d, (hi - o) / d
+        tn, tf = np.minimum(t1, t2).max(1), np.maximum(t1, t2).min(1)
+        box = tf >= np.maximum(tn, 0.0)
+        l = start - o
+        u = np.cross(l, bdir)
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        nn = np.cross(bdir, u)
+        nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+        tq = (nn * l).sum(1) / (nn @ d)
+        qc = o + tq[:, None] * d
+        beam_t = (bdir * (qc - start)).sum(1)
+        dist = np.linalg.norm(qc - (start + beam_t[:, None] * bdir), axis=1)
+        ok = box & (beam_t >= 0) & (beam_t <= blen) & (dist < 3.0)
+        inv_sin = 1.0 / np.sqrt(np.maximum(0.0, 1.0 - (bdir @ d) ** 2))
+        k2 = (3 / math.pi) * (1 - dist / 3.0) ** 2
+        wgt = ext / (4 * math.pi) * inv_sin * np.exp(-ext * tq) * np.exp(-ext * beam_t) * k2 / 6.0
+        total = (wgt[ok, None] * power[ok]).sum(0) * mcol
+        nonzero += int(ok.any())
+        assert np.allclose(got[pix], total, rtol=1e-9, atol=1e-15)
+    assert nonzero > 5
