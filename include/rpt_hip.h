@@ -141,7 +141,7 @@ int rpt_get_counters(rpt_scene*, uint64_t out[8]);
  * milliseconds of the megakernel and of the resolve kernel on the stream they ran on, and the
  * persistent grid size.  Synchronises on the last recorded event. */
 int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* grid_blocks);
-/* Runtime options (all optional): "counters" 0/1, "chunk_spp" (samples per work item),
+/* Runtime options (all optional): "counters" 0/1, "chunk_spp" (samples per work item, 0 = auto),
  * "blocks_per_cu" (persistent grid size), "timing" 0/1; returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 

@@ -44,7 +44,7 @@ uint64_t seed_mix(uint64_t seed) {
     } while (0)
 
 static int64_t g_opt_counters = 0;
-static int64_t g_opt_chunk_spp = 32;
+static int64_t g_opt_chunk_spp = 0;  // 0 = auto: ceil(iterations / 64) clamped to [2, 32]
 static int64_t g_opt_blocks_per_cu = 0;  // 0 = occupancy query
 static int64_t g_opt_timing = 0;
 
@@ -381,7 +381,7 @@ int rpt_set_option(const char* name, int64_t value) {
     if (!name) return fail(RPT_ERR_INVALID, "null option name");
     std::string s(name);
     if (s == "counters") g_opt_counters = value;
-    else if (s == "chunk_spp") { if (value < 1) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 1"); g_opt_chunk_spp = value; }
+    else if (s == "chunk_spp") { if (value < 0) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 0 (0 = auto)"); g_opt_chunk_spp = value; }
     else if (s == "blocks_per_cu") g_opt_blocks_per_cu = value;
     else if (s == "timing") g_opt_timing = value;
     else return fail(RPT_ERR_INVALID, "unknown option " + s);
@@ -920,7 +920,11 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, const rpt_camera* cam, const
     a.max_bounces = prm->max_bounces;
     a.iterations = iterations;
     a.sample_offset = sample_offset;
-    a.chunk_spp = uint32_t(std::min<int64_t>(g_opt_chunk_spp, iterations));
+    // Samples per work item.  Small items keep the persistent grid's tail short when a GPU owns only
+    // 1/8 of the tiles; the value depends on `iterations` alone so that the fp32 partial sums, and
+    // hence the image bits, do not change with the shard count.  At most 64 chunks per pixel.
+    int64_t chunk = g_opt_chunk_spp > 0 ? g_opt_chunk_spp : std::min<int64_t>(32, std::max<int64_t>(2, (int64_t(iterations) + 63) / 64));
+    a.chunk_spp = uint32_t(std::min<int64_t>(chunk, iterations));
     a.n_chunks = (iterations + a.chunk_spp - 1) / a.chunk_spp;
     a.seed_mixed = seed_mix(seed);
 

@@ -1,0 +1,19 @@
+import sys, time
+sys.path.insert(0, '.')
+import torch, numpy as np
+import rpt_amd
+from rpt_amd import Renderer, scenes
+sc, cam, cfg = scenes.CONFIGS["C3"]()
+rpt_amd.set_option("timing", 1)
+d_out = torch.zeros(1024 * 1024 * 3, dtype=torch.float64, device="cuda")
+for chunk in (32, 16, 8):
+    rpt_amd.set_option("chunk_spp", chunk)
+    for count in (1, 8):
+        r = Renderer(sc, cam).width(1024).height(1024).max_bounces(10).seed(0).shard(0, count)
+        ms = []
+        for i in range(4):
+            r._sample_offset = 0
+            r.sample_device(256, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ms.append(r.timing()[0])
+        print("chunk", chunk, "shards", count, "kernel ms %.3f" % min(ms[1:]), "ideal %.3f" % (33.0 / count), flush=True)
