@@ -225,9 +225,15 @@ struct Medium {
     static Medium homogeneous_isotropic(double a, double s) { return {RPT_MEDIUM_HOMOGENEOUS_ISOTROPIC, a, s}; }
     static Medium colored_glowing_fog(double a, double s) { return {RPT_MEDIUM_COLORED_GLOWING_FOG, a, s}; }
 };
-struct Environment {
+struct Environment {  // environment.rs:3-77
     Color color{0, 0, 0};
-    static Environment Color_(Color c) { return {c}; }
+    uint32_t hdri_width = 0, hdri_height = 0;
+    std::vector<double> hdri;  // width*height*3, row-major
+    static Environment Color_(Color c) { return {c, 0, 0, {}}; }
+    static Environment Hdri(uint32_t width, uint32_t height, std::vector<double> buf) {
+        if (buf.size() != size_t(width) * height * 3 || width == 0 || height == 0) throw Error("Hdri::new: bad dimensions");
+        return {{0, 0, 0}, width, height, std::move(buf)};
+    }
 };
 
 // ---- scene.rs
@@ -453,7 +459,11 @@ class Renderer {
                 }
             }
             for (const Medium& m : scene_.media) check(rpt_scene_add_medium(h, m.kind, m.absorption, m.scattering));
-            check(rpt_scene_set_environment_color(h, scene_.environment.color.data()));
+            if (scene_.environment.hdri_width)
+                check(rpt_scene_set_environment_hdri(h, scene_.environment.hdri_width, scene_.environment.hdri_height,
+                                                     scene_.environment.hdri.data()));
+            else
+                check(rpt_scene_set_environment_color(h, scene_.environment.color.data()));
             check(rpt_scene_commit(h, p_.device));
         } catch (...) {
             rpt_scene_destroy(h);

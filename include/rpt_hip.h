@@ -105,6 +105,9 @@ int rpt_scene_add_light_object(rpt_scene*, const rpt_shape_desc*, const rpt_mate
 int rpt_scene_add_medium(rpt_scene*, int32_t kind, double absorption, double scattering);
 /* Environment::Color (src/environment.rs:56-77). */
 int rpt_scene_set_environment_color(rpt_scene*, const double rgb[3]);
+/* Environment::Hdri(Hdri::new(width, height, buf)) (src/environment.rs:3-52): equirectangular image of
+ * width*height linear-RGB triples, row-major, looked up bilinearly by direction. */
+int rpt_scene_set_environment_hdri(rpt_scene*, uint32_t width, uint32_t height, const double* rgb);
 /* Flatten to the device layout and upload; the scene is immutable afterwards
  * (the reference shares `&Scene` immutably across rayon workers, src/renderer.rs:25). */
 int rpt_scene_commit(rpt_scene*, int device);

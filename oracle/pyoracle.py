@@ -63,6 +63,7 @@ def lib():
         L.orc_add_light.argtypes = [P, C.c_int, D, D, C.POINTER(ShapeDesc), C.POINTER(MaterialDesc), C.c_int]
         L.orc_add_medium.argtypes = [P, C.c_int, C.c_double, C.c_double]
         L.orc_set_environment.argtypes = [P, D]
+        L.orc_set_environment_hdri.argtypes = [P, C.c_uint32, C.c_uint32, D]
         L.orc_render.argtypes = [P, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.c_uint64, C.c_uint32, P,
                                  C.c_int, C.POINTER(Counters), P, C.c_uint64]
         L.orc_intersect.argtypes = [P, C.c_uint64, P, P, C.c_int, P, P, P]
@@ -144,7 +145,11 @@ class OracleScene:
                                 None, -1)
         for m in scene.media:
             L.orc_add_medium(self.h, m.kind, m.absorption, m.scattering)
-        L.orc_set_environment(self.h, _d3(scene.environment.color))
+        if getattr(scene.environment, "hdri", None) is not None:
+            hd = scene.environment.hdri
+            L.orc_set_environment_hdri(self.h, hd.shape[1], hd.shape[0], _d3(hd))
+        else:
+            L.orc_set_environment(self.h, _d3(scene.environment.color))
 
     def render(self, camera, width, height, iterations, max_bounces, seed=0, sample_offset=0, exposure_value=0.0,
                robust=0, threads=None, counters=False, pixels=None):

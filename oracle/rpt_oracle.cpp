@@ -799,7 +799,25 @@ struct Scene {  // src/scene.rs:12-24
     std::vector<Object> objects;
     std::vector<Light> lights;
     std::vector<Medium> media;
-    V3 environment = V3(0, 0, 0);  // Environment::Color only (src/environment.rs:64-77)
+    V3 environment = V3(0, 0, 0);  // Environment::Color (src/environment.rs:64-77)
+    // Environment::Hdri (src/environment.rs:3-52): equirectangular image, bilinear lookup
+    uint32_t hdri_w = 0, hdri_h = 0;
+    std::vector<V3> hdri;
+    V3 env_color(const V3& dir_in) const {
+        if (hdri_w == 0) return environment;
+        V3 dir = normalize(dir_in);
+        double azimuth = std::atan2(dir.z, dir.x) + PI;
+        double polar = std::acos(dir.y);
+        double x = azimuth / (2.0 * PI) * double(hdri_w - 1);
+        double y = polar / PI * double(hdri_h - 1);
+        uint32_t x0 = std::min(uint32_t(x), hdri_w - 1), y0 = std::min(uint32_t(y), hdri_h - 1);
+        double ax = x - double(x0), ay = y - double(y0);
+        // the reference indexes x0+1 / y0+1 unclamped (it panics or wraps exactly where ax or ay is 0)
+        uint32_t x1 = std::min(x0 + 1, hdri_w - 1), y1 = std::min(y0 + 1, hdri_h - 1);
+        auto mix = [](const V3& a, const V3& b, double t) { return a * (1.0 - t) + b * t; };
+        return mix(mix(hdri[size_t(y0) * hdri_w + x0], hdri[size_t(y0) * hdri_w + x1], ax),
+                   mix(hdri[size_t(y1) * hdri_w + x0], hdri[size_t(y1) * hdri_w + x1], ax), ay);
+    }
 };
 
 // ------------------------------------------------------------------ renderer.rs
@@ -913,7 +931,7 @@ struct Renderer {
             int oi;
             if (!get_closest_hit(ray, h, oi)) {
                 const double background_dist = 400.0;
-                surface_color = (d >= background_dist) ? scene.environment : V3(0, 0, 0);
+                surface_color = (d >= background_dist) ? scene.env_color(ray.dir) : V3(0, 0, 0);
                 max_dist = background_dist;
             } else {
                 if (d >= h.time) {
@@ -962,7 +980,7 @@ struct Renderer {
         }
         HitRecord h;
         int oi;
-        if (!get_closest_hit(ray, h, oi)) return scene.environment;
+        if (!get_closest_hit(ray, h, oi)) return scene.env_color(ray.dir);
         V3 world_pos = ray.at(h.time);
         const Material& material = scene.objects[oi].material;
         V3 wo = -normalize(ray.dir);
@@ -1377,7 +1395,7 @@ static V3 photon_estimate_indirect(const Renderer& r, const PhotonMap& pm, const
         return photon_surface_estimate(r, pm, pp, ray, *hp, *material, wo) * medium->transmittence(ray, hp->time) / (1.0 - d_cdf);
     };
     if (!hit) {
-        if (!medium) return scene.environment;
+        if (!medium) return scene.env_color(ray.dir);
         if (pm.kind == PK_BEAM_BEAM) return volume_beam_beam(nullptr);
         return pm.kind == PK_PHOTON_MAP ? volume_point(nullptr, nullptr) : volume_beam(nullptr);
     }
@@ -1507,6 +1525,12 @@ int orc_add_medium(orc_scene* s, int kind, double absorption, double scattering)
     return 0;
 }
 void orc_set_environment(orc_scene* s, const double* rgb) { s->scene.environment = v3(rgb); }
+void orc_set_environment_hdri(orc_scene* s, uint32_t w, uint32_t h, const double* rgb) {
+    s->scene.hdri_w = w;
+    s->scene.hdri_h = h;
+    s->scene.hdri.resize(size_t(w) * h);
+    for (size_t i = 0; i < size_t(w) * h; i++) s->scene.hdri[i] = v3(rgb + 3 * i);
+}
 
 static Camera make_camera(const orc_camera* c) {
     return Camera{v3(c->eye), v3(c->direction), v3(c->up), c->fov, c->aperture, c->focal_distance};

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("rpt_scene_add_light_object", C.c_int, [_P, C.POINTER(ShapeDesc), C.POINTER(MaterialDesc)]),
     ("rpt_scene_add_medium", C.c_int, [_P, C.c_int32, C.c_double, C.c_double]),
     ("rpt_scene_set_environment_color", C.c_int, [_P, _D3]),
+    ("rpt_scene_set_environment_hdri", C.c_int, [_P, C.c_uint32, C.c_uint32, _D3]),
     ("rpt_scene_commit", C.c_int, [_P, C.c_int]),
     ("rpt_render_sample", C.c_int,
      [_P, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_uint32, C.c_uint64, C.c_uint32, _P]),

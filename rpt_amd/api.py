@@ -343,18 +343,21 @@ class Medium:
 
 
 class Environment:
-    """environment.rs:56-77 (Color arm; Hdri is outside the hot-path scope)."""
+    """environment.rs:3-77: Environment::Color(c) or Environment::Hdri(Hdri::new(width, height, buf))."""
 
-    def __init__(self, color):
+    def __init__(self, color=(0, 0, 0), hdri=None):
         self.color = _v(color)
+        self.hdri = hdri          # (height, width, 3) fp64 array or None
 
     @staticmethod
     def Color(color):
         return Environment(color)
 
     @staticmethod
-    def Hdri(*_a, **_k):
-        raise NotImplementedError("Environment::Hdri is out of scope of the MI355X hot path (SURVEY.md section 2)")
+    def Hdri(width, height, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.float64).reshape(-1, 3)
+        assert buf.shape[0] == width * height and width > 0 and height > 0     # Hdri::new, environment.rs:18-22
+        return Environment((0, 0, 0), buf.reshape(height, width, 3))
 
 
 class Scene:
@@ -415,7 +418,11 @@ class Scene:
                         h, C.byref(sd), C.byref(material_desc(l.object.material_, _lib.MaterialDesc))))
             for m in self.media:
                 _lib.check(lib.rpt_scene_add_medium(h, m.kind, m.absorption, m.scattering))
-            _lib.check(lib.rpt_scene_set_environment_color(h, _dp(self.environment.color)))
+            env = self.environment
+            if env.hdri is not None:
+                _lib.check(lib.rpt_scene_set_environment_hdri(h, env.hdri.shape[1], env.hdri.shape[0], _dp(env.hdri)))
+            else:
+                _lib.check(lib.rpt_scene_set_environment_color(h, _dp(env.color)))
             _lib.check(lib.rpt_scene_commit(h, device))
         except Exception:
             lib.rpt_scene_destroy(h)

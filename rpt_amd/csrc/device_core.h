@@ -568,6 +568,24 @@ RPT_DEV void illuminate_object(const SceneView& sc, const Light& L, V pos, Rng& 
     dist = len2 * ilen;
 }
 
+// ------------------------------------------------------------------ environment
+// Environment::get_color, src/environment.rs:72-77; Hdri::get_color / bilinear_sample :25-52.
+RPT_DEV V env_color(const SceneView& sc, V dir) {
+    if (sc.hdri_w == 0) return mk(sc.env[0], sc.env[1], sc.env[2]);
+    const V d = normalize(dir);
+    const float azimuth = atan2f(d.z, d.x) + kPi;
+    const float polar = acosf(fminf(fmaxf(d.y, -1.f), 1.f));
+    const float x = azimuth * (0.5f * kInvPi) * float(sc.hdri_w - 1u);
+    const float y = polar * kInvPi * float(sc.hdri_h - 1u);
+    const uint32_t x0 = min(uint32_t(x), sc.hdri_w - 1u), y0 = min(uint32_t(y), sc.hdri_h - 1u);
+    const float ax = x - float(x0), ay = y - float(y0);
+    const uint32_t x1 = min(x0 + 1u, sc.hdri_w - 1u), y1 = min(y0 + 1u, sc.hdri_h - 1u);  // weight 0 where clamped
+    const V c00 = xyz(sc.hdri[y0 * sc.hdri_w + x0]), c01 = xyz(sc.hdri[y0 * sc.hdri_w + x1]);
+    const V c10 = xyz(sc.hdri[y1 * sc.hdri_w + x0]), c11 = xyz(sc.hdri[y1 * sc.hdri_w + x1]);
+    const V top = (1.f - ax) * c00 + ax * c01, bot = (1.f - ax) * c10 + ax * c11;
+    return (1.f - ay) * top + ay * bot;
+}
+
 // ------------------------------------------------------------------ camera
 // Camera::cast_ray, src/camera.rs:65-82 (cot(fov/2)*direction and `right` hoisted to the host).
 RPT_DEV void cast_ray(const CameraG& c, float x, float y, Rng& rng, V& o, V& d) {

@@ -135,6 +135,9 @@ struct SceneView {
     float medium_color_hi[3];   // colored_glowing_fog colour for y > 250
     float medium_emission, medium_phase;
     float env[3];
+    // Environment::Hdri (src/environment.rs:3-52): hdri_w = 0 means Environment::Color(env)
+    const F4* hdri;
+    uint32_t hdri_w, hdri_h;
 };
 
 struct CameraG {

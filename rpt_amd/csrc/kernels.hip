@@ -61,7 +61,6 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
     const float sigma_t = sc.sigma_a + sc.sigma_s;
     const float inv_sigma_t = MEDIUM ? 1.f / sigma_t : 0.f;
     const float albedo_med = MEDIUM ? sc.sigma_s / sigma_t : 0.f;
-    const V env = mk(sc.env[0], sc.env[1], sc.env[2]);
 
     Rng rng;
     rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
         const bool ev_medium = MEDIUM && (dmed < (hit ? t : 400.f));  // src/renderer.rs:197-243
         const bool ev_surface = !ev_medium && hit;
         if (!ev_medium && !ev_surface) {  // miss: environment (src/renderer.rs:198-206, 288)
-            acc = acc + vmin(fma3(Q, env, P), Rc);
+            acc = acc + vmin(fma3(Q, env_color(sc, rd), P), Rc);
             need_path = true;
             continue;
         }

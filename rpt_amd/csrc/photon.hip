@@ -146,10 +146,6 @@ __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
 }
 
 // ------------------------------------------------------------------ LBVH over points
-struct Lbvh {
-    BvhNode* nodes = nullptr;   // n-1 two-box nodes; leaf entry = BVH_LEAF | sorted index
-    uint32_t n = 0;
-};
 RPT_DEV uint64_t expand21(uint32_t v) {  // spread 21 bits to every third bit
     uint64_t x = v & 0x1FFFFFu;
     x = (x | x << 32) & 0x1F00000000FFFFull;
@@ -393,86 +389,10 @@ struct QueryArgs {
     uint32_t* overflow;  // set to 1 if a beam-walk stack overflowed (the render is then rejected)
 };
 
-// Ray vs. sphere-box LBVH: visit every leaf whose padded box the half-infinite ray hits.
-template <class F>
-RPT_DEV void beam_walk(const BvhNode* nodes, uint32_t n, V o, V d, F&& visit) {
-    if (n == 0) return;
-    if (n == 1) { visit(0u); return; }
-    const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
-    uint32_t stack[64];
-    int sp = 0;
-    uint32_t cur = 0;
-    for (;;) {
-        if (cur & BVH_LEAF) {
-            visit(cur & 0x7FFFFFFFu);
-        } else {
-            const BvhNode nd = nodes[cur];
-            float n0, f0, n1, f1;
-            slab2(nd.lo0, nd.hi0, o, inv, n0, f0);
-            slab2(nd.lo1, nd.hi1, o, inv, n1, f1);
-            bool h0 = fmaxf(n0, 0.f) <= f0, h1 = fmaxf(n1, 0.f) <= f1;
-            if (h0 && h1) {
-                if (sp < 64) stack[sp++] = nd.e1;
-                cur = nd.e0;
-                continue;
-            }
-            if (h0 || h1) {
-                cur = h0 ? nd.e0 : nd.e1;
-                continue;
-            }
-        }
-        if (sp == 0) break;
-        cur = stack[--sp];
-    }
-}
-
-// Wave-cooperative variant: the 64 camera rays of a wave come from one 8x8 pixel tile, so the
-// wave walks the tree ONCE.  The node index is wave-uniform (scalar loads of the 64-byte node and the
-// 48-byte photon record), a child is entered when ANY lane's ray hits its box (ballot), and the stack
-// lives in the 64 lanes of one VGPR (lane-select write / v_readlane with a uniform stack pointer).
-// Must be called by every lane of the wave; lanes with active == false only take part in the votes.
-template <class F>
-RPT_DEV void beam_walk_wave(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
-                            F&& visit) {
-    if (n == 0) return;
-    const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t stackreg = 0;
-    uint32_t sp = 0;
-    uint32_t cur = (n == 1) ? BVH_LEAF : 0u;
-    for (;;) {
-        cur = __builtin_amdgcn_readfirstlane(cur);
-        if (cur & BVH_LEAF) {
-            const PhotonRec ph = uload(&photons[cur & 0x7FFFFFFFu]);
-            if (active) visit(ph);
-        } else {
-            const BvhNode nd = uload(&nodes[cur]);
-            float n0, f0, n1, f1;
-            slab2(nd.lo0, nd.hi0, o, inv, n0, f0);
-            slab2(nd.lo1, nd.hi1, o, inv, n1, f1);
-            const bool a0 = __ballot(active && fmaxf(n0, 0.f) <= f0) != 0;
-            const bool a1 = __ballot(active && fmaxf(n1, 0.f) <= f1) != 0;
-            if (a0 && a1) {
-                if (sp < 64) {
-                    stackreg = (lane == sp) ? nd.e1 : stackreg;  // lane `sp` of the VGPR holds entry `sp`
-                    sp++;
-                }
-                cur = nd.e0;
-                continue;
-            }
-            if (a0 || a1) {
-                cur = a0 ? nd.e0 : nd.e1;
-                continue;
-            }
-        }
-        if (sp == 0) break;
-        sp--;
-        cur = __builtin_amdgcn_readlane(stackreg, sp);
-    }
-}
-
-// Batched wave-cooperative walk.  The single-node walk above is one dependent memory round trip per
-// node (~3,400 cycles each with 220 MB of nodes + photons far beyond L2).  Here the wave pops up to
+// Batched wave-cooperative walk (used when the rays of a wave do not form a packet).  Walking one
+// node at a time costs one dependent memory round trip per node (~3,400 cycles each with 220 MB of
+// nodes + photons far beyond L2: measured 118 ms per-lane, 56 ms wave-uniform for the same pass that
+// takes 39 ms batched and 18 ms as a packet).  Here the wave pops up to
 // 64 pending entries at once, lane i fetches entry i's node / photon record (64 loads in flight),
 // stages it in LDS, and then all lanes test their own ray against each staged record in turn
 // (broadcast LDS reads, ballot to decide which children to push).  Pending entries live on a
@@ -691,7 +611,6 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
     F4* stage = reinterpret_cast<F4*>(reinterpret_cast<uint32_t*>(gi - threadIdx.x + K * 256u) + 4u * kBeamCap) + (threadIdx.x >> 6) * 256u;
     const float sigma_t = sc.sigma_a + sc.sigma_s;
     const V mcol0 = mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);  // medium.color(dummy_pos = 0)
-    const V env = mk(sc.env[0], sc.env[1], sc.env[2]);
 
     V acc = mk(0, 0, 0);
     uint32_t slab_idx = 0, s = 0, s_end = 0, pix = 0;
@@ -854,7 +773,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
         }
         if (!active) continue;
         if (!hit && !MEDIUM) {
-            acc = acc + env;  // src/photon.rs:597
+            acc = acc + env_color(sc, rd);  // src/photon.rs:597
             continue;
         }
         if (surface_on) {  // surface estimate, src/photon.rs:327-375

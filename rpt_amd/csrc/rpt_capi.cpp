@@ -306,6 +306,8 @@ struct rpt_scene {
     std::vector<HLight> lights;
     std::vector<HMedium> media;
     double env[3] = {0, 0, 0};
+    uint32_t hdri_w = 0, hdri_h = 0;
+    std::vector<float> hdri;  // w*h*4
     bool committed = false;
     int device = 0;
     int n_cus = 256;
@@ -462,6 +464,21 @@ int rpt_scene_set_environment_color(rpt_scene* s, const double rgb[3]) {
     if (!s || !rgb) return fail(RPT_ERR_INVALID, "null argument");
     if (s->committed) return fail(RPT_ERR_STATE, "scene is immutable after rpt_scene_commit");
     std::memcpy(s->env, rgb, 24);
+    s->hdri_w = s->hdri_h = 0;
+    s->hdri.clear();
+    return RPT_OK;
+}
+int rpt_scene_set_environment_hdri(rpt_scene* s, uint32_t width, uint32_t height, const double* rgb) {
+    if (!s || !rgb) return fail(RPT_ERR_INVALID, "null argument");
+    if (s->committed) return fail(RPT_ERR_STATE, "scene is immutable after rpt_scene_commit");
+    if (width == 0 || height == 0) return fail(RPT_ERR_INVALID, "Hdri::new asserts width > 0 && height > 0");
+    s->hdri_w = width;
+    s->hdri_h = height;
+    s->hdri.resize(size_t(width) * height * 4);
+    for (size_t i = 0; i < size_t(width) * height; i++) {
+        s->hdri[4 * i] = float(rgb[3 * i]); s->hdri[4 * i + 1] = float(rgb[3 * i + 1]); s->hdri[4 * i + 2] = float(rgb[3 * i + 2]);
+        s->hdri[4 * i + 3] = 0.f;
+    }
     return RPT_OK;
 }
 
@@ -801,6 +818,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     size_t o_lights = reserve(lights.size() * sizeof(Light));
     size_t o_ltris = reserve(ltris.size() * sizeof(LightTri));
     size_t o_lxf = reserve(lxf.size() * sizeof(LightXf));
+    size_t o_hdri = reserve(s->hdri.size() * sizeof(float));
     std::vector<char> host(off, 0);
     auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
     put(o_sph, sph.data(), sph.size() * sizeof(XfScan));       put(o_sphs, sph_sh.data(), sph_sh.size() * sizeof(XfShade));
@@ -816,6 +834,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     put(o_lights, lights.data(), lights.size() * sizeof(Light));
     put(o_ltris, ltris.data(), ltris.size() * sizeof(LightTri));
     put(o_lxf, lxf.data(), lxf.size() * sizeof(LightXf));
+    put(o_hdri, s->hdri.data(), s->hdri.size() * sizeof(float));
     HIP_TRY(hipMalloc(&s->arena, off));
     HIP_TRY(hipMemcpy(s->arena, host.data(), off, hipMemcpyHostToDevice));
     char* base = static_cast<char*>(s->arena);
@@ -860,6 +879,9 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         }
     }
     for (int i = 0; i < 3; i++) v.env[i] = float(s->env[i]);
+    v.hdri = (const F4*)(base + o_hdri);
+    v.hdri_w = s->hdri_w;
+    v.hdri_h = s->hdri_h;
     s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size() + aabb.size() + rect.size();
     s->stats[0] = sph.size(); s->stats[1] = cub.size(); s->stats[2] = pln.size(); s->stats[3] = tri.size();
     s->stats[4] = aabb.size(); s->stats[5] = rect.size(); s->stats[6] = btri.size(); s->stats[7] = nodes.size();

@@ -357,3 +357,24 @@ def test_rng_uniform_is_open_interval_and_exact_in_fp32():
     assert np.array_equal(u.astype(np.float32).astype(np.float64), u)          # representable in fp32
     assert np.all((u * 2 ** 24) % 2 == 1)                                      # odd multiples of 2^-24
     assert abs(u.mean() - 0.5) < 0.02
+
+
+def test_hdri_lookup_is_equirectangular_bilinear():
+    """Hdri::get_color (src/environment.rs:25-52): azimuth = atan2(z, x) + pi, polar = acos(y)."""
+    from rpt_amd import Environment
+    w, h = 8, 4
+    img = np.zeros((h, w, 3))
+    img[..., 0] = np.arange(w)[None, :]          # red encodes the column
+    img[..., 1] = np.arange(h)[:, None]          # green encodes the row
+    sc = Scene()
+    sc.environment = Environment.Hdri(w, h, img.reshape(-1, 3))
+    osc = OracleScene(sc)
+    # no geometry: every camera ray misses and returns the environment
+    for d in [(1.0, 0.0, 0.0), (0.0, 0.0, 1.0), (-1.0, 0.2, 0.0), (0.3, 0.9, -0.3), (0.0, -0.7, 0.7)]:
+        dv = np.array(d) / np.linalg.norm(d)
+        cam = Camera(eye=vec3(0, 0, 0), direction=dv, up=np.cross(np.cross(dv, [0.1, 0.9, 0.3]), dv), fov=1e-6)
+        got = osc.render(cam, 1, 1, 1, 0, seed=0)[0]
+        az = math.atan2(dv[2], dv[0]) + math.pi
+        x = az / (2 * math.pi) * (w - 1)
+        y = math.acos(dv[1]) / math.pi * (h - 1)
+        assert np.allclose(got, [x, y, 0.0], atol=1e-4)        # a linear ramp is reproduced exactly by bilinear lookup
