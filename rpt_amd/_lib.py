@@ -85,6 +85,7 @@ SYMBOLS = [
     ("rpt_intersect_batch", C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P]),
     ("rpt_scene_stats", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("rpt_get_counters", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("rpt_debug_trip_stamps", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("rpt_get_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("rpt_set_option", C.c_int, [C.c_char_p, C.c_int64]),
     ("rpt_photon_map_build", C.c_int, [_P, C.c_uint64, C.c_int32, C.c_double, C.c_uint64]),

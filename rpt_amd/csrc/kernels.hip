@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
     uint32_t depth = 0, slab_idx = 0, s = 0, s_end = 0, pix = 0;
     float xn = 0.f, yn = 0.f;
     bool alive = true, have_item = false, need_path = true;
+    bool drained = false;  // wave-uniform: the global queue is exhausted
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform cursor into the current batch of work items
+
     uint32_t c_samples = 0, c_rays = 0, c_vertices = 0, c_trips = 0, c_nodes = 0, c_btris = 0;
 
     for (;;) {
@@ -88,11 +90,15 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
                 const uint64_t m = __ballot(want);
                 if (m == 0) break;
                 if (pool_next == pool_end) {
-                    unsigned long long base = 0;
-                    if ((threadIdx.x & 63u) == 0) base = atomicAdd(a.queue, 64ull);
+                    // once this wave has seen the queue run dry it never touches the counter again: at the end
+                    // of a launch every lane of every wave retires through here, and 4096 waves x 64 atomics on
+                    // one address (~88 dequeues/us) used to cost ~1 ms per launch
+                    unsigned long long base = ~0ull;
+                    if (!drained && (threadIdx.x & 63u) == 0) base = atomicAdd(a.queue, 64ull);
                     const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(base));
                     const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(base >> 32));
-                    if (hi != 0 || lo >= a.n_items) {  // queue exhausted: the waiting lanes retire
+                    if (hi != 0 || lo >= a.n_items) {
+                        drained = true;  // queue exhausted: the waiting lanes retire
                         if (want) alive = false;
                         break;
                     }
@@ -139,7 +145,12 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
             }
         }
         if (!__any(alive)) break;
-        if (COUNT && (threadIdx.x & 63u) == 0) c_trips++;
+        if (COUNT && (threadIdx.x & 63u) == 0) {
+            // diagnostic: wave 0 of block 0 stamps the 100 MHz wall clock every 32 trips (slots 8..63)
+            if (blockIdx.x == 0 && threadIdx.x == 0 && (c_trips & 31u) == 0 && (c_trips >> 5) < 56u)
+                a.counters[8u + (c_trips >> 5)] = wall_clock64();
+            c_trips++;
+        }
         if (!alive) continue;
 
         // ---- one path vertex (one trace_ray invocation, src/renderer.rs:187-322)

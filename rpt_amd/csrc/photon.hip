@@ -616,6 +616,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
     uint32_t slab_idx = 0, s = 0, s_end = 0, pix = 0;
     float xn = 0.f, yn = 0.f;
     bool alive = true, have_item = false;
+    bool drained = false;  // wave-uniform: the global queue is exhausted
     uint32_t pool_next = 0, pool_end = 0;
     uint32_t c0 = 0, c1 = 0;
     unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
@@ -630,11 +631,15 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                 const uint64_t m = __ballot(want);
                 if (m == 0) break;
                 if (pool_next == pool_end) {
-                    unsigned long long base = 0;
-                    if ((threadIdx.x & 63u) == 0) base = atomicAdd(a.queue, 64ull);
+                    // once this wave has seen the queue run dry it never touches the counter again: at the end
+                    // of a launch every lane of every wave retires through here, and 4096 waves x 64 atomics on
+                    // one address (~88 dequeues/us) used to cost ~1 ms per launch
+                    unsigned long long base = ~0ull;
+                    if (!drained && (threadIdx.x & 63u) == 0) base = atomicAdd(a.queue, 64ull);
                     const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(base));
                     const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(base >> 32));
                     if (hi != 0 || lo >= a.n_items) {
+                        drained = true;
                         if (want) alive = false;
                         break;
                     }

@@ -323,7 +323,7 @@ struct rpt_scene {
     unsigned long long* d_counters = nullptr;
     double* d_out = nullptr;
     size_t out_cap = 0;  // bytes
-    uint64_t last_counters[8] = {0};
+    uint64_t last_counters[64] = {0};  // [0..7] counters, [8..63] diagnostic trip stamps
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // before render, after render, after resolve
     bool ev_valid = false;
     int last_blocks = 0;
@@ -890,7 +890,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     s->stats[9] = off;
 
     HIP_TRY(hipMalloc((void**)&s->d_queue, 256));
-    HIP_TRY(hipMalloc((void**)&s->d_counters, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&s->d_counters, 64 * sizeof(unsigned long long)));
     s->device = device;
     s->committed = true;
     return RPT_OK;
@@ -991,7 +991,7 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, const rpt_camera* cam, const
 extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st,
                          int blocks_per_cu, const std::function<hipError_t(const RenderArgs&, int, hipStream_t)>& launch) {
     HIP_TRY(hipMemsetAsync(a.queue, 0, 8, st));
-    if (a.counters) HIP_TRY(hipMemsetAsync(a.counters, 0, 64, st));
+    if (a.counters) HIP_TRY(hipMemsetAsync(a.counters, 0, 512, st));
     uint32_t shard_count = prm->shard_count == 0 ? 1 : prm->shard_count;
     if (shard_count > 1) HIP_TRY(hipMemsetAsync(d_out, 0, size_t(prm->width) * prm->height * 24, st));
     if (a.n_items) {
@@ -1042,7 +1042,7 @@ extern "C++" double* rpti::scratch_out(rpt_scene* s, size_t bytes) {
 extern "C++" int rpti::fetch_counters(rpt_scene* s, const RenderArgs& a) {
     std::memset(s->last_counters, 0, sizeof(s->last_counters));
     if (a.counters) {
-        HIP_TRY(hipMemcpy(s->last_counters, a.counters, 64, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(s->last_counters, a.counters, 512, hipMemcpyDeviceToHost));
         s->last_counters[4] = s->last_counters[1] * s->prims_per_ray;
     }
     return RPT_OK;
@@ -1104,6 +1104,11 @@ int rpt_scene_stats(rpt_scene* s, uint64_t out[16]) {
 int rpt_get_counters(rpt_scene* s, uint64_t out[8]) {
     if (!s || !out) return fail(RPT_ERR_INVALID, "null argument");
     std::memcpy(out, s->last_counters, 64);
+    return RPT_OK;
+}
+int rpt_debug_trip_stamps(rpt_scene* s, uint64_t out[56]) {
+    if (!s || !out) return fail(RPT_ERR_INVALID, "null argument");
+    std::memcpy(out, s->last_counters + 8, 56 * 8);
     return RPT_OK;
 }
 
