@@ -1,0 +1,92 @@
+"""Edge cases of the HIP path: empty / ragged inputs, degenerate sizes, option handling, and the
+non-packet fallback of the photon beam walk.  All compared with the oracle where a value exists."""
+import numpy as np
+import pytest
+
+import rpt_amd
+from rpt_amd import (Camera, Environment, Light, Material, Medium, Object, Renderer, RptError, Scene, polygon, scenes,
+                     sphere, vec3)
+from tests.util import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(scene):
+    from oracle.pyoracle import OracleScene
+    return OracleScene(scene)
+
+
+def test_empty_scene_returns_the_environment():
+    sc = Scene()
+    sc.environment = Environment.Color(vec3(0.25, 0.5, 0.75))
+    out = Renderer(sc, Camera()).width(5).height(3).max_bounces(2).sample_array(3)
+    assert out.shape == (15, 3) and np.allclose(out, [0.25, 0.5, 0.75], rtol=1e-6)
+    fog = Scene()                                             # empty scene inside a medium: medium events only,
+    fog.add(Medium.homogeneous_isotropic(0.1, 0.4))           # no light -> black (renderer.rs:198-206, 243-282)
+    out = Renderer(fog, Camera()).width(4).height(4).sample_array(8)
+    assert np.all(out == 0.0)
+
+
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 1), (7, 3, 33), (33, 65, 2), (64, 1, 5)])
+def test_ragged_image_and_sample_counts(w, h, spp):
+    scene, cam, cfg = scenes.cornell()
+    got = Renderer(scene, cam).width(w).height(h).max_bounces(2).seed(9).sample_array(spp)
+    exp = _oracle(scene).render(cam, w, h, spp, 2, seed=9, robust=1)
+    assert got.shape == (w * h, 3) and np.all(np.isfinite(got))
+    assert rel_rms(got, exp) < 5e-3
+
+
+def test_zero_bounces_and_scene_without_lights():
+    scene, cam, cfg = scenes.cornell()
+    scene.lights.clear()                                      # emission is still seen at depth 0 (renderer.rs:295-299)
+    got = Renderer(scene, cam).width(48).height(48).max_bounces(0).seed(1).sample_array(4)
+    exp = _oracle(scene).render(cam, 48, 48, 4, 0, seed=1, robust=1)
+    assert got.max() > 50 and rel_rms(got, exp) < 1e-5       # only the light quad's emittance * colour
+
+
+def test_chunk_option_changes_rounding_only_and_is_validated():
+    scene, cam, cfg = scenes.lampshade()
+    def render():
+        s2, c2, _ = scenes.lampshade()
+        return Renderer(s2, c2).width(40).height(40).max_bounces(10).seed(3).sample_array(24)
+    base = render()
+    try:
+        rpt_amd.set_option("chunk_spp", 5)                    # 24 = 4 full chunks + one of 4
+        other = render()
+    finally:
+        rpt_amd.set_option("chunk_spp", 0)
+    assert not np.array_equal(base, other) or True            # may or may not differ in the last bit
+    assert np.allclose(base, other, rtol=1e-5, atol=1e-9)
+    with pytest.raises(RptError):
+        rpt_amd.set_option("chunk_spp", -1)
+    with pytest.raises(RptError):
+        rpt_amd.set_option("no_such_option", 1)
+
+
+def test_render_argument_errors():
+    scene, cam, cfg = scenes.cornell()
+    r = Renderer(scene, cam).width(0).height(4)
+    with pytest.raises(RptError):
+        r.sample_array(1)                                     # empty image
+    r = Renderer(scene, cam).width(4).height(4)
+    with pytest.raises(RptError):
+        r.sample_array(0)                                     # zero iterations
+    with pytest.raises(RptError):
+        Renderer(scene, cam).width(4).height(4).shard(3, 2).sample_array(1)
+    with pytest.raises(RptError):
+        scene.add(Object(sphere()))                           # committed scenes are immutable
+
+
+def test_photon_beam_walk_without_a_common_ray_origin():
+    """Thin-lens camera: every lane's ray starts at a different lens point, so the wave cannot form a
+    frustum packet and takes the batched per-ray voting walk; same estimate, same oracle."""
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    lens = Camera(cam.eye, cam.direction, cam.up, cam.fov).focus(vec3(278.0, 273.0, 280.0), 12.0)
+    n, size, spp = 10000, 40, 3
+    r = Renderer(scene, lens).width(size).height(size).watts(14.65 * n).gather_size(12).gather_size_volume(3).seed(6)
+    r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    got = r.photon_sample_array(spp)
+    pm = _oracle(scene).photon_map(n, 1, 14.65 * n, 12, 3, seed=6, robust=1)
+    exp = pm.render(lens, size, size, spp, seed=6)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert rel_rms(got, exp) < 1e-2 and abs(got.mean() - exp.mean()) / exp.mean() < 3e-3
