@@ -387,6 +387,7 @@ struct QueryArgs {
     const BvhNode* v_nodes; const PhotonRec* v_ph; uint32_t n_v;   // volume photons (spheres for the beam query)
     uint32_t kind, gather_size, gather_size_volume;
     uint32_t* overflow;  // set to 1 if a beam-walk stack overflowed (the render is then rejected)
+    uint32_t region_dwords;  // LDS dwords per wave: max(gather lists, beam stack + staging)
 };
 
 // Batched wave-cooperative walk (used when the rays of a wave do not form a packet).  Walking one
@@ -562,7 +563,8 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
 }
 
 // kd-tree `nearests(q, K)`: the K photons of least squared distance, kept unsorted in the lane's LDS
-// column (gd = squared distances, gi = sorted-array indices).  Returns the number found.
+// column of its wave's region (gd[k * 64] = squared distances, gi[k * 64] = sorted-array indices).
+// Returns the number found.
 RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, V x, uint32_t K, float* gd,
                             uint32_t* gi, float& max_d2) {
     uint32_t found = 0;
@@ -571,26 +573,26 @@ RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint
     if (K > 0) {
         knn_walk(nodes, photons, n, x, bound, [&](uint32_t idx, float d2) {
             if (found < K) {
-                gd[found * 256u] = d2;
-                gi[found * 256u] = idx;
+                gd[found * 64u] = d2;
+                gi[found * 64u] = idx;
                 found++;
                 if (found < K) return kInf;
             } else if (d2 < worst) {
-                gd[worst_slot * 256u] = d2;
-                gi[worst_slot * 256u] = idx;
+                gd[worst_slot * 64u] = d2;
+                gi[worst_slot * 64u] = idx;
             } else {
                 return worst;
             }
             worst = -1.f;  // (re)locate the current worst
             for (uint32_t k = 0; k < K; k++) {
-                float v = gd[k * 256u];
+                float v = gd[k * 64u];
                 if (v > worst) { worst = v; worst_slot = k; }
             }
             return worst;
         });
     }
     max_d2 = 0.f;
-    for (uint32_t k = 0; k < found; k++) max_d2 = fmaxf(max_d2, gd[k * 256u]);
+    for (uint32_t k = 0; k < found; k++) max_d2 = fmaxf(max_d2, gd[k * 64u]);
     return found;
 }
 
@@ -603,12 +605,15 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
     const SceneView& sc = a.sc;
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
     const uint32_t K = max(q.gather_size, q.gather_size_volume);  // LDS columns are sized for the larger gather
-    // gather list: [K][256] floats then [K][256] indices, after the BVH stack region
-    float* gd = reinterpret_cast<float*>(dyn_lds + (BVH ? 32u * 256u : 0u)) + threadIdx.x;
-    uint32_t* gi = reinterpret_cast<uint32_t*>(gd - threadIdx.x + K * 256u) + threadIdx.x;
-    // per-wave beam-walk stack and staging area (after the gather lists)
-    uint32_t* wstack = reinterpret_cast<uint32_t*>(gi - threadIdx.x + K * 256u) + (threadIdx.x >> 6) * kBeamCap;
-    F4* stage = reinterpret_cast<F4*>(reinterpret_cast<uint32_t*>(gi - threadIdx.x + K * 256u) + 4u * kBeamCap) + (threadIdx.x >> 6) * 256u;
+    // One wave-private LDS region (after the BVH stack) serves two phases that never overlap in time
+    // within a wave: the gather lists ([K][64] distances + [K][64] indices) of the k-nearest walks, and
+    // the beam walk's pending-entry stack + staging slots.
+    const uint32_t lane_ = threadIdx.x & 63u, wave_ = threadIdx.x >> 6;
+    uint32_t* region = dyn_lds + (BVH ? 32u * 256u : 0u) + wave_ * q.region_dwords;
+    float* gd = reinterpret_cast<float*>(region) + lane_;
+    uint32_t* gi = region + K * 64u + lane_;
+    uint32_t* wstack = region;
+    F4* stage = reinterpret_cast<F4*>(region + kBeamCap);
     const float sigma_t = sc.sigma_a + sc.sigma_s;
     const V mcol0 = mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);  // medium.color(dummy_pos = 0)
 
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                     float max_d2;
                     const uint32_t found = gather_knn(q.v_nodes, q.v_ph, q.n_v, x, q.gather_size_volume, gd, gi, max_d2);
                     V sum = mk(0, 0, 0);
-                    for (uint32_t k = 0; k < found; k++) sum = sum + xyz(q.v_ph[gi[k * 256u]].pow);
+                    for (uint32_t k = 0; k < found; k++) sum = sum + xyz(q.v_ph[gi[k * 64u]].pow);
                     // / (4/3 pi r^3) / extinction * transmittance / pdf, pdf = sigma_t * transmittance
                     const float r3 = max_d2 * __builtin_sqrtf(max_d2);
                     const float scale = sc.medium_phase * rcp((4.f / 3.f) * kPi * r3) * rcp(sigma_t) * tr_d * rcp(sigma_t * tr_d);
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
             const uint32_t found = gather_knn(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2);
             V sc_col = mat_emit(mat) * mat_color(mat);
             for (uint32_t k = 0; k < found; k++) {
-                const PhotonRec ph = q.s_ph[gi[k * 256u]];
+                const PhotonRec ph = q.s_ph[gi[k * 64u]];
                 V disp = x - xyz(ph.pos_r);
                 float len2 = dot(disp, disp);
                 float ilen = rsq(len2);
@@ -1092,7 +1097,8 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     q.gather_size = uint32_t(gather_size);
     q.gather_size_volume = pm->kind == RPT_PHOTON_MAP ? uint32_t(gather_size_volume) : 0u;  // only the point-point estimate gathers in the volume
     const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_mesh != 0;
-    const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + size_t(gather_lds) * 256u * 8u + 4u * kBeamCap * 4u + 4u * 256u * 16u;
+    q.region_dwords = uint32_t(std::max<size_t>(size_t(gather_lds) * 64u * 2u, size_t(kBeamCap) + 64u * 16u));
+    const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + 4u * size_t(q.region_dwords) * 4u;
     if (!pm->d_overflow) RPTI_HIP_TRY(hipMalloc((void**)&pm->d_overflow, 64));
     RPTI_HIP_TRY(hipMemsetAsync(pm->d_overflow, 0, 4, st));
     q.overflow = pm->d_overflow;
