@@ -110,6 +110,7 @@ class Shape {
     Vec3 plane_normal{0, 0, 0};
     double plane_value = 0;
     std::vector<double> tris;  // 18 doubles per triangle
+    std::vector<Shape> children;  // RPT_SHAPE_GROUP: KdTree<Box<dyn Bounded>> (kdtree.rs:103-146)
 
     Shape translate(Vec3 v) const { return wrap(Mat4::translation(v)); }
     Shape scale(Vec3 v) const { return wrap(Mat4::scaling(v)); }
@@ -128,10 +129,15 @@ class Shape {
         d.plane_value = plane_value;
         d.tris = tris.empty() ? nullptr : tris.data();
         d.n_tris = tris.size() / 18;
+        child_descs_.clear();
+        for (const Shape& c : children) child_descs_.push_back(c.desc());  // valid while *this is alive and unchanged
+        d.children = child_descs_.empty() ? nullptr : child_descs_.data();
+        d.n_children = child_descs_.size();
         return d;
     }
 
   private:
+    mutable std::vector<rpt_shape_desc> child_descs_;
     Shape wrap(const Mat4& t) const {
         Shape s = *this;
         s.matrix = has_transform ? t * matrix : t;
@@ -159,6 +165,15 @@ inline Shape mesh(const std::vector<Triangle>& ts) {  // Mesh::new
     for (const Triangle& t : ts)
         for (const Vec3* v : {&t.v1, &t.v2, &t.v3, &t.n1, &t.n2, &t.n3})
             for (double c : *v) s.tris.push_back(c);
+    return s;
+}
+inline Shape kdtree(std::vector<Shape> shapes) {  // KdTree::new over bounded shapes (examples/fractal_spheres.rs:45)
+    Shape s;
+    s.kind = RPT_SHAPE_GROUP;
+    for (const Shape& c : shapes)
+        if (c.kind == RPT_SHAPE_PLANE) throw std::invalid_argument("Plane is not Bounded and cannot be put in a KdTree");
+    if (shapes.empty()) throw std::invalid_argument("KdTree needs at least one shape");
+    s.children = std::move(shapes);
     return s;
 }
 inline Shape polygon(const std::vector<Vec3>& verts) {  // shape.rs:308-314

@@ -34,7 +34,9 @@ typedef struct rpt_scene rpt_scene;
 
 /* Shape kinds: the closed set of `impl Shape` on the hot path
  * (src/shape/sphere.rs, cube.rs, plane.rs, mesh.rs; `Mesh = KdTree<Triangle>`). */
-enum { RPT_SHAPE_SPHERE = 0, RPT_SHAPE_CUBE = 1, RPT_SHAPE_PLANE = 2, RPT_SHAPE_MESH = 3 };
+enum { RPT_SHAPE_SPHERE = 0, RPT_SHAPE_CUBE = 1, RPT_SHAPE_PLANE = 2, RPT_SHAPE_MESH = 3,
+       RPT_SHAPE_GROUP = 4 /* KdTree<Box<dyn Bounded>> of other shapes (src/kdtree.rs:103-146,
+                              examples/fractal_spheres.rs:45); children must be Bounded (no planes) */ };
 
 /* One `Box<dyn Shape>`: a unit primitive or mesh, optionally wrapped in `Transformed<T>`
  * (src/shape.rs:102-152).  `transform` is the composed homogeneous matrix M, row-major;
@@ -48,6 +50,8 @@ typedef struct rpt_shape_desc {
     double plane_value;
     const double* tris;      /* n_tris * 18 doubles: v1 v2 v3 n1 n2 n3 (src/shape/mesh.rs:9-23) */
     uint64_t n_tris;
+    const struct rpt_shape_desc* children; /* RPT_SHAPE_GROUP: the kd-tree's objects, each a     */
+    uint64_t n_children;                   /* full shape (own transform, may itself be a group)  */
 } rpt_shape_desc;
 
 /* `enum Material` (src/material.rs:8-23). */
@@ -148,7 +152,9 @@ int rpt_debug_trip_stamps(rpt_scene*, uint64_t out[56]);
  * persistent grid size.  Synchronises on the last recorded event. */
 int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* grid_blocks);
 /* Runtime options (all optional): "counters" 0/1, "chunk_spp" (samples per work item, 0 = auto),
- * "blocks_per_cu" (persistent grid size), "timing" 0/1; returns RPT_ERR_INVALID for unknown names. */
+ * "blocks_per_cu" (persistent grid size), "timing" 0/1, "scene_bvh_min" (read by rpt_scene_commit:
+ * number of bounded primitives + BVH meshes from which one scene-level BVH replaces the linear
+ * object scan, default 64); returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 
 /* ---- photon mapping (next tier: src/photon.rs; config C4 = photon_point_query_beam_render) ----

@@ -13,9 +13,13 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
 class ShapeDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("has_transform", C.c_int32), ("transform", C.c_double * 16),
-                ("plane_normal", C.c_double * 3), ("plane_value", C.c_double),
-                ("tris", C.POINTER(C.c_double)), ("n_tris", C.c_uint64)]
+    pass
+
+
+ShapeDesc._fields_ = [("kind", C.c_int32), ("has_transform", C.c_int32), ("transform", C.c_double * 16),
+                      ("plane_normal", C.c_double * 3), ("plane_value", C.c_double),
+                      ("tris", C.POINTER(C.c_double)), ("n_tris", C.c_uint64),
+                      ("children", C.POINTER(ShapeDesc)), ("n_children", C.c_uint64)]
 
 
 class MaterialDesc(C.Structure):
@@ -102,7 +106,7 @@ def _d3(a):
 
 def _same_shape(a, b):
     """Geometry identity, as the product's flattener defines a light's twin object."""
-    from rpt_amd.api import Mesh, Plane
+    from rpt_amd.api import KdTree, Mesh, Plane
     ba, bb = a.base(), b.base()
     if type(ba) is not type(bb):
         return False
@@ -113,6 +117,8 @@ def _same_shape(a, b):
         return np.array_equal(ba.normal, bb.normal) and ba.value == bb.value
     if isinstance(ba, Mesh):
         return ba.tris.shape == bb.tris.shape and np.array_equal(ba.tris, bb.tris)
+    if isinstance(ba, KdTree):
+        return len(ba.shapes) == len(bb.shapes) and all(_same_shape(x, y) for x, y in zip(ba.shapes, bb.shapes))
     return True
 
 

@@ -258,9 +258,11 @@ struct Shape {  // trait Shape, src/shape.rs:19-26
     virtual bool intersect(const Ray& ray, double t_min, HitRecord& rec) const = 0;
     virtual SurfSample sample(const V3& target, Rng& rng) const = 0;
     virtual bool can_sample() const { return true; }
+    virtual bool bounding_box(BBox&) const { return false; }  // trait Bounded, src/kdtree.rs:12-15
 };
 
-struct Sphere : Shape {  // src/shape/sphere.rs:14-65
+struct Sphere : Shape {  // src/shape/sphere.rs:14-75
+    bool bounding_box(BBox& b) const override { b.p_min = V3(-1, -1, -1); b.p_max = V3(1, 1, 1); return true; }
     bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override {
         double a = dot(ray.dir, ray.dir);
         double b = dot(ray.dir, ray.origin);
@@ -296,7 +298,8 @@ struct Sphere : Shape {  // src/shape/sphere.rs:14-65
     }
 };
 
-struct Cube : Shape {  // src/shape/cube.rs:22-89
+struct Cube : Shape {  // src/shape/cube.rs:12-89
+    bool bounding_box(BBox& b) const override { b.p_min = V3(-0.5, -0.5, -0.5); b.p_max = V3(0.5, 0.5, 0.5); return true; }
     bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override {
         double lo[3], hi[3];
         V3 lon[3], hin[3];
@@ -421,8 +424,8 @@ static double median(const std::vector<double>& s) {  // src/kdtree.rs:350-358
     size_t mid = n / 2;
     return (s[mid] + s[mid - 1]) / 2.0;
 }
-static std::unique_ptr<KdNode> construct(const std::vector<Triangle>& objects, std::vector<size_t> indices) {
-    // src/kdtree.rs:238-348
+static std::unique_ptr<KdNode> construct(const std::vector<BBox>& object_boxes, std::vector<size_t> indices) {
+    // src/kdtree.rs:238-348 (generic over T: Bounded; only the bounding boxes are needed)
     auto node = std::make_unique<KdNode>();
     if (indices.size() < 16) {
         node->indices = std::move(indices);
@@ -431,7 +434,7 @@ static std::unique_ptr<KdNode> construct(const std::vector<Triangle>& objects, s
     std::vector<double> xs, ys, zs;
     std::vector<BBox> bboxs;
     for (size_t index : indices) {
-        BBox b = objects[index].bounding_box();
+        BBox b = object_boxes[index];
         xs.push_back(b.p_min.x); xs.push_back(b.p_max.x);
         ys.push_back(b.p_min.y); ys.push_back(b.p_max.y);
         zs.push_back(b.p_min.z); zs.push_back(b.p_max.z);
@@ -478,8 +481,8 @@ static std::unique_ptr<KdNode> construct(const std::vector<Triangle>& objects, s
     }
     node->axis = split_dir;
     node->value = med[split_dir];
-    node->left = construct(objects, std::move(left));
-    node->right = construct(objects, std::move(right));
+    node->left = construct(object_boxes, std::move(left));
+    node->right = construct(object_boxes, std::move(right));
     return node;
 }
 
@@ -490,9 +493,11 @@ struct Mesh : Shape {  // KdTree<Triangle>, src/kdtree.rs:103-227, src/shape/mes
     explicit Mesh(std::vector<Triangle> tris) : objects(std::move(tris)) {  // :111-124
         std::vector<size_t> idx(objects.size());
         for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
-        for (const Triangle& t : objects) bounds = bounds.merge(t.bounding_box());
-        root = construct(objects, std::move(idx));
+        std::vector<BBox> boxes;
+        for (const Triangle& t : objects) { boxes.push_back(t.bounding_box()); bounds = bounds.merge(boxes.back()); }
+        root = construct(boxes, std::move(idx));
     }
+    bool bounding_box(BBox& b) const override { b = bounds; return true; }
     bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override {  // :132-139
         double b_min, b_max;
         bounds.intersect(ray, b_min, b_max);
@@ -575,6 +580,82 @@ struct Transformed : Shape {  // src/shape.rs:102-152
         return SurfSample{mul(transform, s.v, 1.0), new_normal, s.p / base};
     }
     bool can_sample() const override { return shape->can_sample(); }
+    bool bounding_box(BBox& out) const override {  // :154-176: box of the 8 transformed corners
+        BBox b;
+        if (!shape->bounding_box(b)) return false;
+        out = BBox();
+        for (int k = 0; k < 8; k++) {
+            V3 c((k & 4) ? b.p_max.x : b.p_min.x, (k & 2) ? b.p_max.y : b.p_min.y, (k & 1) ? b.p_max.z : b.p_min.z);
+            V3 w = mul(transform, c, 1.0);
+            out.p_min = vmin(out.p_min, w);
+            out.p_max = vmax(out.p_max, w);
+        }
+        return true;
+    }
+};
+
+// KdTree<Box<dyn Bounded>> (src/kdtree.rs:103-227 over arbitrary bounded shapes, e.g.
+// examples/fractal_spheres.rs:45): same construction and traversal as Mesh, children are shapes.
+struct ShapeKdTree : Shape {
+    std::vector<std::unique_ptr<Shape>> objects;
+    std::unique_ptr<KdNode> root;
+    BBox bounds;
+    explicit ShapeKdTree(std::vector<std::unique_ptr<Shape>> children) : objects(std::move(children)) {
+        std::vector<size_t> idx(objects.size());
+        std::vector<BBox> boxes(objects.size());
+        for (size_t i = 0; i < idx.size(); i++) {
+            idx[i] = i;
+            objects[i]->bounding_box(boxes[i]);
+            bounds = bounds.merge(boxes[i]);
+        }
+        root = construct(boxes, std::move(idx));
+    }
+    bool bounding_box(BBox& b) const override { b = bounds; return true; }
+    bool intersect(const Ray& ray, double t_min, HitRecord& rec) const override {
+        double b_min, b_max;
+        bounds.intersect(ray, b_min, b_max);
+        if (std::fmax(b_min, t_min) > std::fmin(b_max, rec.time)) return false;
+        return subtree(*root, bounds, ray, t_min, rec);
+    }
+    bool subtree(const KdNode& node, const BBox& bbox, const Ray& ray, double t_min, HitRecord& rec) const {
+        CNT(nodes);
+        double b_min, b_max;
+        bbox.intersect(ray, b_min, b_max);
+        if (node.axis < 0) {
+            bool result = false;
+            for (size_t index : node.indices)
+                if (objects[index]->intersect(ray, t_min, rec)) result = true;
+            return result;
+        }
+        int ax = node.axis;
+        double value = node.value;
+        double t_split = (value - ray.origin[ax]) / ray.dir[ax];
+        bool left_first = (ray.origin[ax] < value) || (ray.origin[ax] == value && ray.dir[ax] <= 0.0);
+        BBox bl, br;
+        bbox.split(ax, value, bl, br);
+        const KdNode* first = left_first ? node.left.get() : node.right.get();
+        const KdNode* second = left_first ? node.right.get() : node.left.get();
+        const BBox& b0 = left_first ? bl : br;
+        const BBox& b1 = left_first ? br : bl;
+        if (t_split > std::fmin(b_max, rec.time) || t_split <= 0.0) return subtree(*first, b0, ray, t_min, rec);
+        if (t_split < std::fmax(b_min, t_min)) return subtree(*second, b1, ray, t_min, rec);
+        bool h1 = subtree(*first, b0, ray, t_min, rec);
+        if (h1 && rec.time < t_split) return true;
+        bool h2 = subtree(*second, b1, ray, t_split, rec);
+        return h1 || h2;
+    }
+    SurfSample sample(const V3& target, Rng& rng) const override {  // :141-146
+        size_t num = objects.size();
+        uint32_t index = rng.index(uint32_t(num));
+        SurfSample s = objects[index]->sample(target, rng);
+        s.p = s.p / double(num);
+        return s;
+    }
+    bool can_sample() const override {
+        for (const auto& o : objects)
+            if (!o->can_sample()) return false;
+        return true;
+    }
 };
 
 // ------------------------------------------------------------------ color.rs
@@ -1416,13 +1497,15 @@ using namespace orc;
 extern "C" {
 
 struct orc_shape_desc {
-    int32_t kind;           // 0 sphere, 1 cube, 2 plane, 3 mesh
+    int32_t kind;           // 0 sphere, 1 cube, 2 plane, 3 mesh, 4 kd-tree of bounded shapes
     int32_t has_transform;  // 0: bare shape, 1: Transformed<shape>
     double transform[16];   // row-major 4x4
     double plane_normal[3];
     double plane_value;
     const double* tris;     // n_tris * 18 doubles: v1 v2 v3 n1 n2 n3
     uint64_t n_tris;
+    const struct orc_shape_desc* children;  // kind 4: KdTree<Box<dyn Bounded>> of these shapes
+    uint64_t n_children;
 };
 struct orc_material {
     int32_t kind;
@@ -1465,6 +1548,18 @@ static std::unique_ptr<Shape> make_shape(const orc_shape_desc* d) {
                 tris[i] = Triangle{v3(t), v3(t + 3), v3(t + 6), v3(t + 9), v3(t + 12), v3(t + 15)};
             }
             s.reset(new Mesh(std::move(tris)));
+            break;
+        }
+        case 4: {
+            std::vector<std::unique_ptr<Shape>> kids;
+            for (uint64_t i = 0; i < d->n_children; i++) {
+                auto c = make_shape(d->children + i);
+                BBox b;
+                if (!c || !c->bounding_box(b)) return nullptr;  // only Bounded shapes (no planes)
+                kids.push_back(std::move(c));
+            }
+            if (kids.empty()) return nullptr;
+            s.reset(new ShapeKdTree(std::move(kids)));
             break;
         }
         default: return nullptr;

@@ -16,15 +16,20 @@ class RptError(RuntimeError):
 
 
 class ShapeDesc(C.Structure):
-    _fields_ = [
-        ("kind", C.c_int32),
-        ("has_transform", C.c_int32),
-        ("transform", C.c_double * 16),
-        ("plane_normal", C.c_double * 3),
-        ("plane_value", C.c_double),
-        ("tris", C.POINTER(C.c_double)),
-        ("n_tris", C.c_uint64),
-    ]
+    pass
+
+
+ShapeDesc._fields_ = [
+    ("kind", C.c_int32),
+    ("has_transform", C.c_int32),
+    ("transform", C.c_double * 16),
+    ("plane_normal", C.c_double * 3),
+    ("plane_value", C.c_double),
+    ("tris", C.POINTER(C.c_double)),
+    ("n_tris", C.c_uint64),
+    ("children", C.POINTER(ShapeDesc)),  # kind 4 (KdTree of bounded shapes)
+    ("n_children", C.c_uint64),
+]
 
 
 class MaterialDesc(C.Structure):

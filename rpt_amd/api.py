@@ -40,13 +40,13 @@ def shard_pixels(width, height, rank, count):
 
 
 def set_option(name, value):
-    """rpt_set_option: "counters", "timing", "chunk_spp", "blocks_per_cu"."""
+    """rpt_set_option: "counters", "timing", "chunk_spp", "blocks_per_cu", "scene_bvh_min" (read at commit)."""
     _lib.check(_lib.load().rpt_set_option(name.encode(), int(value)))
 
 
 __all__ = [
     "set_option", "shard_pixels",
-    "vec3", "hex_color", "color_bytes", "Sphere", "Cube", "Plane", "Triangle", "Mesh", "Transformed",
+    "vec3", "hex_color", "color_bytes", "Sphere", "Cube", "Plane", "Triangle", "Mesh", "KdTree", "Transformed",
     "sphere", "cube", "plane", "polygon", "Material", "Object", "Light", "Medium", "Environment",
     "Scene", "Camera", "Filter", "Buffer", "Renderer", "RptError",
 ]
@@ -194,6 +194,24 @@ class Mesh(Shape):
 
     def clone(self):
         return Mesh(self.tris.copy())
+
+
+class KdTree(Shape):
+    """`KdTree<Box<dyn Bounded>>` used as one shape (kdtree.rs:103-146; examples/fractal_spheres.rs:45):
+    a group of bounded shapes (spheres, cubes, meshes, nested groups, transformed or not) sharing
+    one material.  Planes are not `Bounded` and are rejected."""
+    KIND = 4
+
+    def __init__(self, shapes):
+        self.shapes = list(shapes)
+        if not self.shapes:
+            raise ValueError("KdTree needs at least one shape")
+        for s in self.shapes:
+            if isinstance(s.base(), Plane):
+                raise TypeError("Plane is not Bounded and cannot be put in a KdTree")
+
+    def clone(self):
+        return KdTree(self.shapes)
 
 
 class Transformed(Shape):
@@ -465,6 +483,15 @@ def shape_desc(shape, cls):
         keep = np.ascontiguousarray(base.tris, dtype=np.float64)
         d.tris = keep.ctypes.data_as(C.POINTER(C.c_double))
         d.n_tris = keep.shape[0]
+    elif isinstance(base, KdTree):
+        arr = (cls * len(base.shapes))()
+        keep = [arr]
+        for i, child in enumerate(base.shapes):
+            cd, ck = shape_desc(child, cls)
+            C.memmove(C.byref(arr, i * C.sizeof(cls)), C.byref(cd), C.sizeof(cls))
+            keep.append(ck)
+        d.children = C.cast(arr, C.POINTER(cls))
+        d.n_children = len(base.shapes)
     elif not isinstance(base, (Sphere, Cube)):
         raise TypeError(f"unsupported shape {type(base).__name__}")
     d._keep = keep
@@ -693,7 +720,7 @@ class Renderer:
         out = (C.c_uint64 * 16)()
         _lib.check(_lib.load().rpt_scene_stats(self.scene._commit(self.device_), out))
         names = ["spheres", "cubes", "planes", "tris", "aabbs", "rects", "bvh_tris", "bvh_nodes", "scan_bytes_per_ray",
-                 "scene_bytes"]
+                 "scene_bytes", "scene_bvh", "scene_bvh_prims"]
         return dict(zip(names, [int(v) for v in out]))
 
     # ---- photon mapping (src/photon.rs:631-720)

@@ -226,14 +226,45 @@ RPT_DEV void slab2(const float lo[3], const float hi[3], V o, V inv, float& tn, 
     tn = max3(fminf(x1, x2), fminf(y1, y2), fminf(z1, z2));
     tf = min3(fmaxf(x1, x2), fmaxf(y1, y2), fmaxf(z1, z2));
 }
-template <bool COUNT>
-RPT_DEV void bvh_traverse(const SceneView& sc, const MeshRef& m, V o, V d, float tmin, float& tbest,
+// One primitive of a BVH_PRIMS leaf (per lane: kinds may differ between lanes).
+RPT_DEV void hit_prim(const SceneView& sc, uint32_t pc, V o, V d, V inv, float tmin, float& tbest, uint32_t& code) {
+    const uint32_t kind = pc >> 28, i = pc & 0x0FFFFFFFu;
+    float t = -1.f;
+    if (kind == K_SPHERE) {
+        const XfScan x = sc.sph[i];
+        V ol, dl;
+        to_local(x, o, d, ol, dl);
+        t = hit_sphere(ol, dl, tmin);
+    } else if (kind == K_CUBE) {
+        const XfScan x = sc.cub[i];
+        V ol, dl;
+        to_local(x, o, d, ol, dl);
+        uint32_t f;
+        t = hit_cube<false>(ol, dl, tmin, f);
+    } else if (kind == K_AABB) {
+        const AabbScan b = sc.aabb[i];
+        uint32_t f;
+        t = hit_aabb<false>(b.lo, b.hi, o, inv, tmin, f);
+    } else if (kind == K_RECT) {
+        const RectScan r = sc.rect[i];
+        if (i < sc.n_rect_x) t = hit_rect(r.a, r.b.x, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, tbest);
+        else if (i < sc.n_rect_x + sc.n_rect_y) t = hit_rect(r.a, r.b.x, o.y, inv.y, o.z, d.z, o.x, d.x, tmin, tbest);
+        else t = hit_rect(r.a, r.b.x, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, tbest);
+    } else {  // K_TRI
+        const TriScan tr = sc.tri[i];
+        t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
+    }
+    if (t >= 0.f && t < tbest) { tbest = t; code = pc; }
+}
+
+template <bool COUNT, bool PRIMS>
+RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tmin, float& tbest,
                           uint32_t& code, uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
-    const BvhNode* nodes = sc.nodes + m.node_base;
+    const BvhNode* nodes = sc.nodes;
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
-    const uint32_t kDone = 0xFFFFFFFFu;  // a leaf entry with count 32 at the last triangle never occurs
+    const uint32_t kDone = 0xFFFFFFFFu;  // a 32-item prim leaf at the last index never occurs
     uint32_t sp = 0;
-    uint32_t cur = 0;  // root is always an inner node
+    uint32_t cur = root;  // a root is always an inner node
     while (cur != kDone) {
         while (!(cur & BVH_LEAF)) {  // kDone has the leaf bit set, so finished lanes fall through
             const BvhNode nd = nodes[cur];
@@ -257,13 +288,20 @@ RPT_DEV void bvh_traverse(const SceneView& sc, const MeshRef& m, V o, V d, float
             }
         }
         if (cur != kDone) {
-            const uint32_t first = m.tri_base + (cur & 0x03FFFFFFu);
+            const uint32_t first = cur & BVH_INDEX_MASK;
             const uint32_t count = ((cur >> 26) & 31u) + 1u;
-            for (uint32_t i = 0; i < count; i++) {
-                const TriScan tr = sc.btri[first + i];
-                if (COUNT) c_tris++;
-                float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
-                if (t >= 0.f) { tbest = t; code = (K_BVHTRI << 28) | (first + i); }
+            if (PRIMS && (cur & BVH_PRIMS)) {
+                for (uint32_t i = 0; i < count; i++) {
+                    if (COUNT) c_tris++;
+                    hit_prim(sc, sc.pleaf[first + i], o, d, inv, tmin, tbest, code);
+                }
+            } else {
+                for (uint32_t i = 0; i < count; i++) {
+                    const TriScan tr = sc.btri[first + i];
+                    if (COUNT) c_tris++;
+                    float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
+                    if (t >= 0.f) { tbest = t; code = (K_BVHTRI << 28) | (first + i); }
+                }
             }
             if (sp) {
                 sp--;
@@ -275,9 +313,19 @@ RPT_DEV void bvh_traverse(const SceneView& sc, const MeshRef& m, V o, V d, float
     }
 }
 
-template <bool BVH, bool COUNT>
+// BVH: 0 = no tree in the scene, 1 = per-mesh trees only, 2 = scene-level tree possible.
+template <int BVH, bool COUNT>
 RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code,
                          uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
+    if (BVH == 2 && sc.scene_bvh) {  // wave-uniform: planes (unbounded) are scanned, everything else is in the tree
+        for (uint32_t i = 0; i < sc.n_pln; i++) {
+            const F4 nv = uload(&sc.pln[i]).nv;
+            float t = hit_plane(nv, o, d, tmin);
+            if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
+        }
+        bvh_traverse<COUNT, true>(sc, sc.top_root, o, d, tmin, tbest, code, stk, stride, c_nodes, c_tris);
+        return;
+    }
     for (uint32_t i = 0; i < sc.n_sph; i++) {
         const XfScan x = uload(&sc.sph[i]);
         V ol, dl;
@@ -332,7 +380,7 @@ RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest
     if (BVH) {
         for (uint32_t i = 0; i < sc.n_mesh; i++) {
             const MeshRef m = uload(&sc.meshes[i]);
-            bvh_traverse<COUNT>(sc, m, o, d, tmin, tbest, code, stk, stride, c_nodes, c_tris);
+            bvh_traverse<COUNT, false>(sc, m.root, o, d, tmin, tbest, code, stk, stride, c_nodes, c_tris);
         }
     }
 }

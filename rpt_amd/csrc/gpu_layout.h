@@ -67,8 +67,9 @@ struct alignas(16) RectShade {
 };
 // BVH2 node holding BOTH children's boxes (64 B): one dependent load per inner node yields two
 // slab tests, the near child is descended first and leaves are referenced directly.
-// Child entry: bit 31 = leaf; leaf: bits 26..30 = triangle count - 1 (1..32), bits 0..25 = first
-// triangle within the mesh; inner: node index within the mesh.
+// Child entry: bit 31 = leaf; leaf: bits 26..30 = item count - 1 (1..32), bit 25 = BVH_PRIMS,
+// bits 0..24 = first item: an index into `btri` (triangle leaf) or into `pleaf` (BVH_PRIMS: a
+// list of primitive codes kind << 28 | index, scene-level BVH only).  Inner: absolute node index.
 struct alignas(16) BvhNode {
     float lo0[3];
     uint32_t e0;
@@ -80,6 +81,8 @@ struct alignas(16) BvhNode {
     uint32_t pad1;
 };
 static const uint32_t BVH_LEAF = 0x80000000u;
+static const uint32_t BVH_PRIMS = 0x02000000u;
+static const uint32_t BVH_INDEX_MASK = 0x01FFFFFFu;
 enum : uint32_t { M_LAMBERTIAN = 0, M_PHONG = 1, M_MIRROR = 2, M_TRANSMISSIVE = 3 };
 struct alignas(16) Material {
     F4 albedo_emit;  // rgb albedo, emittance
@@ -113,7 +116,7 @@ struct alignas(16) LightXf {
     F4 lin[3];   // linear rows
 };
 struct alignas(16) MeshRef {   // one BVH-accelerated mesh object
-    uint32_t node_base, tri_base, tri_count, object;
+    uint32_t root, tri_base, tri_count, object;   // root: absolute index of the mesh's root node
 };
 
 struct SceneView {
@@ -125,6 +128,10 @@ struct SceneView {
     const RectScan* rect;  const RectShade* rect_sh; uint32_t n_rect_x, n_rect_y, n_rect_z;  // sorted by axis
     const BvhNode* nodes;  const TriScan* btri;     const TriShade* btri_sh;
     const MeshRef* meshes; uint32_t n_mesh;
+    // Scene-level BVH over every bounded primitive and mesh root (built when the scene has many
+    // of them, e.g. KdTree<Box<dyn Bounded>> groups): scene_bvh = 1 replaces the linear scans of
+    // sph/cub/aabb/rect/tri and the per-mesh walks by one walk from `top_root`.
+    const uint32_t* pleaf; uint32_t n_nodes, scene_bvh, top_root;
     const Material* mats;  uint32_t n_obj;   // one material record per scene object
     const Light* lights;   uint32_t n_lights;
     const LightTri* ltris; const LightXf* lxf;

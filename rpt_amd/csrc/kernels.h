@@ -33,7 +33,8 @@ struct KernelInfo {
 
 // Persistent megakernel: grid = n_blocks x 256 threads.
 hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream);
-hipError_t render_occupancy(bool medium, bool bvh, int* blocks_per_cu);
+hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu);  // bvh: bvh_mode()
+int bvh_mode(const SceneView& sc);  // 0 no tree, 1 per-mesh trees, 2 scene-level tree
 // out[pixel] = sum_chunks slab / iterations * scale for owned pixels (others untouched).
 hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipStream_t stream);
 hipError_t launch_intersect(const SceneView& sc, uint64_t n, const float* d_o, const float* d_d, float* d_t,

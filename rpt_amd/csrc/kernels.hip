@@ -51,7 +51,7 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 #ifndef RPT_MIN_WAVES
 #define RPT_MIN_WAVES 4
 #endif
-template <bool MEDIUM, bool BVH, bool COUNT>
+template <bool MEDIUM, int BVH, bool COUNT>
 __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
     extern __shared__ uint32_t dyn_lds[];
     const SceneView& sc = a.sc;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs a, double
     out[o + 2] = b * inv;
 }
 
-template <bool BVH>
+template <int BVH>
 __global__ __launch_bounds__(256) void intersect_kernel(const SceneView sc, uint64_t n, const float* __restrict__ o,
                                                         const float* __restrict__ d, float* __restrict__ t_out,
                                                         int32_t* __restrict__ obj_out, float* __restrict__ n_out) {
@@ -367,24 +367,28 @@ __global__ void debug_camera_kernel(const CameraG cam, uint32_t w, uint32_t h, u
 // ------------------------------------------------------------------ launchers
 static constexpr size_t kStackBytes = 32u * 256u * sizeof(uint32_t);
 
-template <bool M, bool B, bool C>
+template <bool M, int B, bool C>
 static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t stream) {
     hipLaunchKernelGGL((render_kernel<M, B, C>), dim3(n_blocks), dim3(256), B ? kStackBytes : 0, stream, a);
     return hipGetLastError();
 }
-hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream) {
-    bool m = a.sc.has_medium != 0, b = a.sc.n_mesh != 0, c = a.counters != nullptr;
-    if (m) {
-        if (b) return c ? launch_render_t<true, true, true>(a, n_blocks, stream) : launch_render_t<true, true, false>(a, n_blocks, stream);
-        return c ? launch_render_t<true, false, true>(a, n_blocks, stream) : launch_render_t<true, false, false>(a, n_blocks, stream);
-    }
-    if (b) return c ? launch_render_t<false, true, true>(a, n_blocks, stream) : launch_render_t<false, true, false>(a, n_blocks, stream);
-    return c ? launch_render_t<false, false, true>(a, n_blocks, stream) : launch_render_t<false, false, false>(a, n_blocks, stream);
+template <bool M, bool C>
+static hipError_t launch_render_b(const RenderArgs& a, int bvh, int n_blocks, hipStream_t stream) {
+    if (bvh == 2) return launch_render_t<M, 2, C>(a, n_blocks, stream);
+    if (bvh == 1) return launch_render_t<M, 1, C>(a, n_blocks, stream);
+    return launch_render_t<M, 0, C>(a, n_blocks, stream);
 }
-hipError_t render_occupancy(bool medium, bool bvh, int* blocks_per_cu) {
+int bvh_mode(const SceneView& sc) { return sc.scene_bvh ? 2 : (sc.n_nodes ? 1 : 0); }
+hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream) {
+    const bool m = a.sc.has_medium != 0, c = a.counters != nullptr;
+    const int b = bvh_mode(a.sc);
+    if (m) return c ? launch_render_b<true, true>(a, b, n_blocks, stream) : launch_render_b<true, false>(a, b, n_blocks, stream);
+    return c ? launch_render_b<false, true>(a, b, n_blocks, stream) : launch_render_b<false, false>(a, b, n_blocks, stream);
+}
+hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu) {
     const void* f;
-    if (medium) f = bvh ? (const void*)render_kernel<true, true, false> : (const void*)render_kernel<true, false, false>;
-    else f = bvh ? (const void*)render_kernel<false, true, false> : (const void*)render_kernel<false, false, false>;
+    if (medium) f = bvh == 2 ? (const void*)render_kernel<true, 2, false> : bvh == 1 ? (const void*)render_kernel<true, 1, false> : (const void*)render_kernel<true, 0, false>;
+    else f = bvh == 2 ? (const void*)render_kernel<false, 2, false> : bvh == 1 ? (const void*)render_kernel<false, 1, false> : (const void*)render_kernel<false, 0, false>;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, 256, bvh ? kStackBytes : 0);
 }
 hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipStream_t stream) {
@@ -395,8 +399,8 @@ hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipS
 hipError_t launch_intersect(const SceneView& sc, uint64_t n, const float* d_o, const float* d_d, float* d_t,
                             int32_t* d_obj, float* d_n, bool bvh, hipStream_t stream) {
     uint32_t blocks = uint32_t((n + 255) / 256);
-    if (bvh) hipLaunchKernelGGL(intersect_kernel<true>, dim3(blocks), dim3(256), kStackBytes, stream, sc, n, d_o, d_d, d_t, d_obj, d_n);
-    else hipLaunchKernelGGL(intersect_kernel<false>, dim3(blocks), dim3(256), 0, stream, sc, n, d_o, d_d, d_t, d_obj, d_n);
+    if (bvh) hipLaunchKernelGGL(intersect_kernel<2>, dim3(blocks), dim3(256), kStackBytes, stream, sc, n, d_o, d_d, d_t, d_obj, d_n);
+    else hipLaunchKernelGGL(intersect_kernel<0>, dim3(blocks), dim3(256), 0, stream, sc, n, d_o, d_d, d_t, d_obj, d_n);
     return hipGetLastError();
 }
 hipError_t launch_debug_rng(uint64_t seed_mixed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* d_out,

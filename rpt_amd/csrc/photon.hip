@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
             const float tmin = ray_tmin_p(ro);
             float t = kInf;
             uint32_t code = CODE_MISS;
-            closest_hit<BVH, false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
+            closest_hit<(BVH ? 2 : 0), false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
             const bool hit = code != CODE_MISS;
             bool in_volume = false;
             float d = 0.f;
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
             cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
             wo = -normalize(rd);
             tmin = ray_tmin_p(ro);
-            closest_hit<BVH, false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
+            closest_hit<(BVH ? 2 : 0), false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
         }
         const bool hit = code != CODE_MISS;
         V color = mk(0, 0, 0);
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                 float len = len2 * ilen;
                 float ts = kInf;
                 uint32_t cs = CODE_MISS;
-                closest_hit<BVH, false>(sc, po, pd, ray_tmin_p(po), ts, cs, stk, 256, c0, c1);
+                closest_hit<(BVH ? 2 : 0), false>(sc, po, pd, ray_tmin_p(po), ts, cs, stk, 256, c0, c1);
                 // :357-361 "something lies between the photon and the query point".  A hit inside the
                 // query point's own tangent plane is the grazing ray meeting its own surface: fp64 rejects
                 // it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
@@ -996,7 +996,7 @@ int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, doub
     a.kind = uint32_t(kind);
     RPTI_HIP_TRY(tmp.alloc(&a.cnt_s, photon_count));
     RPTI_HIP_TRY(tmp.alloc(&a.cnt_v, photon_count));
-    const bool medium = sd.view.has_medium != 0, bvh = sd.view.n_mesh != 0;
+    const bool medium = sd.view.has_medium != 0, bvh = sd.view.n_nodes != 0;
     int blocks = int(std::min<uint64_t>((photon_count + 255) / 256, uint64_t(sd.n_cus) * 8));
     RPTI_HIP_TRY(hipEventRecord(e0, st));
     RPTI_HIP_TRY(launch_shoot<false>(a, medium, bvh, blocks, st));
@@ -1096,7 +1096,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     q.kind = uint32_t(pm->kind);
     q.gather_size = uint32_t(gather_size);
     q.gather_size_volume = pm->kind == RPT_PHOTON_MAP ? uint32_t(gather_size_volume) : 0u;  // only the point-point estimate gathers in the volume
-    const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_mesh != 0;
+    const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_nodes != 0;
     q.region_dwords = uint32_t(std::max<size_t>(size_t(gather_lds) * 64u * 2u, size_t(kBeamCap) + 64u * 16u));
     const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + 4u * size_t(q.region_dwords) * 4u;
     if (!pm->d_overflow) RPTI_HIP_TRY(hipMalloc((void**)&pm->d_overflow, 64));

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -47,6 +48,7 @@ static int64_t g_opt_counters = 0;
 static int64_t g_opt_chunk_spp = 0;  // 0 = auto: ceil(iterations / 64) clamped to [2, 32]
 static int64_t g_opt_blocks_per_cu = 0;  // 0 = occupancy query
 static int64_t g_opt_timing = 0;
+static int64_t g_opt_scene_bvh_min = 64;  // bounded primitives + BVH meshes from which the scene-level BVH is built
 
 // ---------------------------------------------------------------------------- fp64 helpers
 namespace {
@@ -104,10 +106,27 @@ bool invert4(const double a[4][4], double out[4][4]) {
         for (int j = 0; j < 4; j++) out[i][j] = w[i][4 + j];
     return true;
 }
+bool finish_xf(Xf& x);
 bool make_xf(const rpt_shape_desc& d, Xf& x) {
     x.has = d.has_transform != 0;
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) x.M[i][j] = x.has ? d.transform[i * 4 + j] : (i == j ? 1.0 : 0.0);
+    return finish_xf(x);
+}
+// Transformed<KdTree<..Transformed<T>..>>: the child's matrix under the group's (world = P * C * local).
+bool compose_xf(const Xf& parent, const rpt_shape_desc& d, Xf& x) {
+    Xf c;
+    if (!make_xf(d, c)) return false;
+    x.has = parent.has || c.has;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double a = 0.0;
+            for (int k = 0; k < 4; k++) a += parent.M[i][k] * c.M[k][j];
+            x.M[i][j] = (parent.has && c.has) ? a : (parent.has ? parent.M[i][j] : c.M[i][j]);
+        }
+    return finish_xf(x);
+}
+bool finish_xf(Xf& x) {
     if (!invert4(x.M, x.Minv)) return false;
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) x.L[i][j] = x.M[i][j];
@@ -146,8 +165,9 @@ uint64_t seed_mix(uint64_t seed) { return rpti::seed_mix(seed); }
 
 // ---------------------------------------------------------------------------- host scene
 struct HShape {
-    rpt_shape_desc d;            // tris pointer rewritten to own storage
+    rpt_shape_desc d;            // tris / children pointers rewritten to own storage
     std::vector<double> tris;
+    std::vector<HShape> children;  // RPT_SHAPE_GROUP
 };
 struct HObject {
     HShape shape;
@@ -170,6 +190,11 @@ bool same_shape(const HShape& a, const HShape& b) {
     if (a.d.kind == RPT_SHAPE_MESH)
         return a.tris.size() == b.tris.size() &&
                (a.tris.empty() || std::memcmp(a.tris.data(), b.tris.data(), a.tris.size() * 8) == 0);
+    if (a.d.kind == RPT_SHAPE_GROUP) {
+        if (a.children.size() != b.children.size()) return false;
+        for (size_t i = 0; i < a.children.size(); i++)
+            if (!same_shape(a.children[i], b.children[i])) return false;
+    }
     return true;
 }
 
@@ -189,6 +214,13 @@ struct BvhBuilder {
     std::vector<TmpNode>& nodes;
     static constexpr int kBins = 16, kMaxDepth = 28;
     uint32_t leaf_max = 4;
+    const std::vector<uint8_t>* solo = nullptr;  // by BTri::idx: items that must be alone in their leaf
+    bool can_leaf(uint32_t first, uint32_t count) const {
+        if (!solo || count == 1) return true;
+        for (uint32_t i = first; i < first + count; i++)
+            if ((*solo)[t[i].idx]) return false;
+        return true;
+    }
     void bounds(uint32_t first, uint32_t count, float lo[3], float hi[3], float clo[3], float chi[3]) {
         for (int a = 0; a < 3; a++) {
             lo[a] = clo[a] = std::numeric_limits<float>::infinity();
@@ -219,7 +251,8 @@ struct BvhBuilder {
             nodes[node].left_or_first = first;
             nodes[node].count = count;
         };
-        if (count <= leaf_max || (depth >= kMaxDepth && count <= 32)) return make_leaf();
+        const bool leaf_ok = can_leaf(first, count);
+        if (leaf_ok && (count <= leaf_max || (depth >= kMaxDepth && count <= 32))) return make_leaf();
         int best_axis = -1, best_bin = -1;
         float best_cost = std::numeric_limits<float>::infinity();
         for (int a = 0; a < 3; a++) {
@@ -268,11 +301,11 @@ struct BvhBuilder {
         }
         uint32_t mid;
         if (best_axis < 0 || depth >= kMaxDepth) {
-            if (count <= 16) return make_leaf();
+            if (count <= 16 && leaf_ok) return make_leaf();
             mid = first + count / 2;  // all centroids coincide (or depth cap): split by index
         } else {
             float parent_cost = area(lo, hi) * float(count);
-            if (best_cost >= parent_cost && count <= 8) return make_leaf();
+            if (best_cost >= parent_cost && count <= 8 && leaf_ok) return make_leaf();
             float ext = chi[best_axis] - clo[best_axis];
             float scale = float(kBins) / ext;
             auto it = std::partition(t.begin() + first, t.begin() + first + count, [&](const BTri& x) {
@@ -334,16 +367,27 @@ struct rpt_scene {
     uint32_t tk_w = 0, tk_h = 0, tk_rank = 0, tk_count = 0, n_tiles = 0, tiles_x = 0;
 };
 
-static bool copy_shape(const rpt_shape_desc* d, HShape& out, std::string& why) {
+static bool copy_shape(const rpt_shape_desc* d, HShape& out, std::string& why, int depth = 0) {
     if (!d) { why = "null shape"; return false; }
-    if (d->kind < 0 || d->kind > RPT_SHAPE_MESH) { why = "unknown shape kind"; return false; }
+    if (d->kind < 0 || d->kind > RPT_SHAPE_GROUP) { why = "unknown shape kind"; return false; }
     out.d = *d;
     out.tris.clear();
+    out.children.clear();
     if (d->kind == RPT_SHAPE_MESH) {
         if (d->n_tris == 0 || !d->tris) { why = "mesh without triangles"; return false; }
         out.tris.assign(d->tris, d->tris + d->n_tris * 18);
     }
+    if (d->kind == RPT_SHAPE_GROUP) {
+        if (d->n_children == 0 || !d->children) { why = "group without children"; return false; }
+        if (depth >= 16) { why = "groups nested too deeply"; return false; }
+        out.children.resize(d->n_children);
+        for (uint64_t i = 0; i < d->n_children; i++) {
+            if (d->children[i].kind == RPT_SHAPE_PLANE) { why = "Plane is not Bounded and cannot be a KdTree child (src/kdtree.rs:12)"; return false; }
+            if (!copy_shape(d->children + i, out.children[i], why, depth + 1)) return false;
+        }
+    }
     out.d.tris = nullptr;
+    out.d.children = nullptr;
     Xf x;
     if (!make_xf(*d, x)) { why = "singular transform"; return false; }
     return true;
@@ -386,6 +430,7 @@ int rpt_set_option(const char* name, int64_t value) {
     else if (s == "chunk_spp") { if (value < 0) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 0 (0 = auto)"); g_opt_chunk_spp = value; }
     else if (s == "blocks_per_cu") g_opt_blocks_per_cu = value;
     else if (s == "timing") g_opt_timing = value;
+    else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); g_opt_scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option " + s);
     return RPT_OK;
 }
@@ -447,6 +492,8 @@ int rpt_scene_add_light_object(rpt_scene* s, const rpt_shape_desc* d, const rpt_
     if (!copy_shape(d, l.obj.shape, why) || !check_material(m, why)) return fail(RPT_ERR_INVALID, why);
     if (d->kind == RPT_SHAPE_PLANE)
         return fail(RPT_ERR_INVALID, "a plane cannot be a Light::Object (Plane::sample is unimplemented in rpt)");
+    if (d->kind == RPT_SHAPE_GROUP)
+        return fail(RPT_ERR_UNSUPPORTED, "a KdTree group as a Light::Object is not supported on the device");
     l.obj.mat = *m;
     s->lights.push_back(std::move(l));
     return RPT_OK;
@@ -608,19 +655,45 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     std::vector<LightTri> ltris;
     std::vector<LightXf> lxf;
 
-    for (size_t oi = 0; oi < s->objects.size(); oi++) {
-        const HObject& o = s->objects[oi];
-        Xf x;
-        make_xf(o.shape.d, x);
-        const uint32_t obj = uint32_t(oi);
-        Material gm;
-        gm.albedo_emit = F4{float(o.mat.albedo[0]), float(o.mat.albedo[1]), float(o.mat.albedo[2]), float(o.mat.emittance)};
-        gm.params = F4{bits_f(uint32_t(o.mat.kind)), float(o.mat.shininess), float(o.mat.ior), 0.f};
-        mats.push_back(gm);
-        switch (o.shape.d.kind) {
+    // World-space boxes of the bounded primitives, for the scene-level BVH.
+    struct PBox { float lo[3], hi[3]; };
+    std::vector<PBox> box_sph, box_cub, box_tri, box_mesh;
+    auto xf_box = [](const Xf& x, bool sphere) {  // unit sphere / unit cube under an affine map
+        PBox b;
+        for (int i = 0; i < 3; i++) {
+            double h = 0.0;
+            for (int j = 0; j < 3; j++) h += sphere ? x.M[i][j] * x.M[i][j] : 0.5 * std::fabs(x.M[i][j]);
+            if (sphere) h = std::sqrt(h);
+            h += 1e-5 * (h + std::fabs(x.M[i][3]));
+            b.lo[i] = float(x.M[i][3] - h);
+            b.hi[i] = float(x.M[i][3] + h);
+        }
+        return b;
+    };
+    auto tri_box = [](const double* t, const Xf& x) {
+        PBox b;
+        D3 v[3] = {x.point(d3(t)), x.point(d3(t + 3)), x.point(d3(t + 6))};
+        for (int a = 0; a < 3; a++) {
+            double c0 = (&v[0].x)[a], c1 = (&v[1].x)[a], c2 = (&v[2].x)[a];
+            double lo = std::min(c0, std::min(c1, c2)), hi = std::max(c0, std::max(c1, c2));
+            b.lo[a] = std::nextafter(float(lo), -std::numeric_limits<float>::infinity());
+            b.hi[a] = std::nextafter(float(hi), std::numeric_limits<float>::infinity());
+        }
+        return b;
+    };
+    std::function<void(const HShape&, const Xf&, uint32_t)> emit = [&](const HShape& shape, const Xf& x, uint32_t obj) {
+        switch (shape.d.kind) {
+            case RPT_SHAPE_GROUP: {  // KdTree<Box<dyn Bounded>>: children become primitives of this object
+                for (const HShape& c : shape.children) {
+                    Xf cx;
+                    compose_xf(x, c.d, cx);
+                    emit(c, cx, obj);
+                }
+                break;
+            }
             case RPT_SHAPE_SPHERE:
             case RPT_SHAPE_CUBE: {
-                if (o.shape.d.kind == RPT_SHAPE_CUBE && axis_aligned_positive(x)) {
+                if (shape.d.kind == RPT_SHAPE_CUBE && axis_aligned_positive(x)) {
                     // positive scale + translation only: an axis-aligned box in world space
                     AabbScan b;
                     b.lo = F4{float(x.M[0][3] - 0.5 * x.M[0][0]), float(x.M[1][3] - 0.5 * x.M[1][1]),
@@ -638,14 +711,14 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                 sh.r0 = F4{float(x.N[0][0]), float(x.N[0][1]), float(x.N[0][2]), bits_f(obj)};
                 sh.r1 = F4{float(x.N[1][0]), float(x.N[1][1]), float(x.N[1][2]), x.has ? 1.f : 0.f};
                 sh.r2 = F4{float(x.N[2][0]), float(x.N[2][1]), float(x.N[2][2]), 0.f};
-                if (o.shape.d.kind == RPT_SHAPE_SPHERE) { sph.push_back(sc); sph_sh.push_back(sh); }
-                else { cub.push_back(sc); cub_sh.push_back(sh); }
+                if (shape.d.kind == RPT_SHAPE_SPHERE) { sph.push_back(sc); sph_sh.push_back(sh); box_sph.push_back(xf_box(x, true)); }
+                else { cub.push_back(sc); cub_sh.push_back(sh); box_cub.push_back(xf_box(x, false)); }
                 break;
             }
             case RPT_SHAPE_PLANE: {
                 // world-space plane: (M^-T n) . x = value + (M^-T n) . translation
-                D3 n = d3(o.shape.d.plane_normal);
-                double value = o.shape.d.plane_value;
+                D3 n = d3(shape.d.plane_normal);
+                double value = shape.d.plane_value;
                 if (x.has) {
                     D3 nw = x.normal(n);
                     value = value + dot(nw, D3{x.M[0][3], x.M[1][3], x.M[2][3]});
@@ -657,19 +730,20 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                 break;
             }
             default: {
-                uint64_t nt = o.shape.tris.size() / 18;
+                uint64_t nt = shape.tris.size() / 18;
                 if (nt <= kLinearTriMax) {
                     for (uint64_t i = 0; i < nt; i++) {
                         RectScan rs;
                         RectShade rh;
                         int axis = -1;
-                        if (i + 1 < nt) axis = detect_rect(&o.shape.tris[i * 18], &o.shape.tris[(i + 1) * 18], x, obj, rs, rh);
+                        if (i + 1 < nt) axis = detect_rect(&shape.tris[i * 18], &shape.tris[(i + 1) * 18], x, obj, rs, rh);
                         if (axis >= 0) {
                             rect_axis[axis].push_back(rs);
                             rect_sh_axis[axis].push_back(rh);
                             i++;
                         } else {
-                            push_tri(&o.shape.tris[i * 18], x, obj, tri, tri_sh);
+                            push_tri(&shape.tris[i * 18], x, obj, tri, tri_sh);
+                            box_tri.push_back(tri_box(&shape.tris[i * 18], x));
                         }
                     }
                 } else {
@@ -679,20 +753,18 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                     mh.reserve(nt);
                     std::vector<BTri> bt(nt);
                     for (uint64_t i = 0; i < nt; i++) {
-                        const double* t = &o.shape.tris[i * 18];
+                        const double* t = &shape.tris[i * 18];
                         push_tri(t, x, obj, ms, mh);
-                        D3 v[3] = {x.point(d3(t)), x.point(d3(t + 3)), x.point(d3(t + 6))};
+                        PBox tb = tri_box(t, x);
                         for (int a = 0; a < 3; a++) {
-                            double c0 = (&v[0].x)[a], c1 = (&v[1].x)[a], c2 = (&v[2].x)[a];
-                            double lo = std::min(c0, std::min(c1, c2)), hi = std::max(c0, std::max(c1, c2));
-                            bt[i].lo[a] = std::nextafter(float(lo), -std::numeric_limits<float>::infinity());
-                            bt[i].hi[a] = std::nextafter(float(hi), std::numeric_limits<float>::infinity());
-                            bt[i].c[a] = float(0.5 * (lo + hi));
+                            bt[i].lo[a] = tb.lo[a];
+                            bt[i].hi[a] = tb.hi[a];
+                            bt[i].c[a] = 0.5f * (tb.lo[a] + tb.hi[a]);
                         }
                         bt[i].idx = uint32_t(i);
                     }
                     MeshRef mr;
-                    mr.node_base = uint32_t(nodes.size());
+                    mr.root = uint32_t(nodes.size());  // local node 0 is the root
                     mr.tri_base = uint32_t(btri.size());
                     mr.tri_count = uint32_t(nt);
                     mr.object = obj;
@@ -707,10 +779,10 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                     for (size_t k = 0; k < tmp.size(); k++)
                         if (tmp[k].count == 0) remap[k] = n_inner++;
                     std::vector<BvhNode> local(n_inner);
-                    auto entry = [&](uint32_t k) -> uint32_t {
+                    auto entry = [&](uint32_t k) -> uint32_t {  // absolute node / triangle indices
                         const TmpNode& c = tmp[k];
-                        if (c.count == 0) return remap[k];
-                        return BVH_LEAF | ((c.count - 1u) << 26) | c.left_or_first;
+                        if (c.count == 0) return mr.root + remap[k];
+                        return BVH_LEAF | ((c.count - 1u) << 26) | (mr.tri_base + c.left_or_first);
                     };
                     for (size_t k = 0; k < tmp.size(); k++) {
                         if (tmp[k].count != 0) continue;
@@ -730,11 +802,25 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                     }
                     nodes.insert(nodes.end(), local.begin(), local.end());
                     meshes.push_back(mr);
+                    PBox mb;
+                    for (int a = 0; a < 3; a++) { mb.lo[a] = tmp[0].lo[a]; mb.hi[a] = tmp[0].hi[a]; }
+                    box_mesh.push_back(mb);
                 }
             }
         }
+    };
+    for (size_t oi = 0; oi < s->objects.size(); oi++) {
+        const HObject& o = s->objects[oi];
+        Xf x;
+        make_xf(o.shape.d, x);
+        Material gm;
+        gm.albedo_emit = F4{float(o.mat.albedo[0]), float(o.mat.albedo[1]), float(o.mat.albedo[2]), float(o.mat.emittance)};
+        gm.params = F4{bits_f(uint32_t(o.mat.kind)), float(o.mat.shininess), float(o.mat.ior), 0.f};
+        mats.push_back(gm);
+        emit(o.shape, x, uint32_t(oi));
     }
-    if (tri.size() >= (1u << 28) || btri.size() >= (1u << 28)) return fail(RPT_ERR_UNSUPPORTED, "too many triangles");
+    if (tri.size() >= BVH_INDEX_MASK || btri.size() >= BVH_INDEX_MASK || nodes.size() >= (1u << 30))
+        return fail(RPT_ERR_UNSUPPORTED, "too many triangles");
 
     for (const HLight& hl : s->lights) {
         Light L{};
@@ -809,6 +895,85 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         rect.insert(rect.end(), rect_axis[a].begin(), rect_axis[a].end());
         rect_sh.insert(rect_sh.end(), rect_sh_axis[a].begin(), rect_sh_axis[a].end());
     }
+    // ---- scene-level BVH over bounded primitives and mesh roots (many-primitive scenes only)
+    std::vector<uint32_t> pleaf;
+    uint32_t top_root = 0;
+    bool scene_bvh = false;
+    {
+        std::vector<BTri> items;
+        std::vector<uint32_t> codes;   // by item: primitive code, or K_BVHTRI << 28 | mesh index for a mesh root
+        auto add_item = [&](const float lo[3], const float hi[3], uint32_t code) {
+            BTri it;
+            for (int a = 0; a < 3; a++) { it.lo[a] = lo[a]; it.hi[a] = hi[a]; it.c[a] = 0.5f * (lo[a] + hi[a]); }
+            it.idx = uint32_t(codes.size());
+            items.push_back(it);
+            codes.push_back(code);
+        };
+        for (size_t i = 0; i < sph.size(); i++) add_item(box_sph[i].lo, box_sph[i].hi, (K_SPHERE << 28) | uint32_t(i));
+        for (size_t i = 0; i < cub.size(); i++) add_item(box_cub[i].lo, box_cub[i].hi, (K_CUBE << 28) | uint32_t(i));
+        for (size_t i = 0; i < aabb.size(); i++) {
+            float lo[3] = {aabb[i].lo.x, aabb[i].lo.y, aabb[i].lo.z}, hi[3] = {aabb[i].hi.x, aabb[i].hi.y, aabb[i].hi.z};
+            add_item(lo, hi, (K_AABB << 28) | uint32_t(i));
+        }
+        {
+            size_t i = 0;
+            for (int axis = 0; axis < 3; axis++)
+                for (size_t k = 0; k < rect_axis[axis].size(); k++, i++) {
+                    const RectScan& r = rect[i];
+                    float lo[3], hi[3];
+                    lo[axis] = hi[axis] = r.a.x;
+                    lo[(axis + 1) % 3] = r.a.y; hi[(axis + 1) % 3] = r.a.z;
+                    lo[(axis + 2) % 3] = r.a.w; hi[(axis + 2) % 3] = r.b.x;
+                    add_item(lo, hi, (K_RECT << 28) | uint32_t(i));
+                }
+        }
+        for (size_t i = 0; i < tri.size(); i++) add_item(box_tri[i].lo, box_tri[i].hi, (K_TRI << 28) | uint32_t(i));
+        std::vector<uint8_t> solo(items.size(), 0);
+        for (size_t i = 0; i < meshes.size(); i++) {
+            add_item(box_mesh[i].lo, box_mesh[i].hi, (K_BVHTRI << 28) | uint32_t(i));
+            solo.push_back(1);
+        }
+        if (items.size() >= size_t(std::max<int64_t>(2, g_opt_scene_bvh_min))) {
+            scene_bvh = true;
+            std::vector<TmpNode> tmp;
+            tmp.reserve(2 * items.size());
+            tmp.push_back(TmpNode{});
+            BvhBuilder b{items, tmp};
+            b.leaf_max = 2;
+            b.solo = &solo;
+            b.build(0, 0, uint32_t(items.size()), 0);
+            std::vector<uint32_t> remap(tmp.size(), 0);
+            uint32_t n_inner = 0;
+            for (size_t k = 0; k < tmp.size(); k++)
+                if (tmp[k].count == 0) remap[k] = n_inner++;
+            top_root = uint32_t(nodes.size());
+            std::vector<BvhNode> local(n_inner);
+            auto entry = [&](uint32_t k) -> uint32_t {
+                const TmpNode& c = tmp[k];
+                if (c.count == 0) return top_root + remap[k];
+                const uint32_t c0 = codes[items[c.left_or_first].idx];
+                if ((c0 >> 28) == K_BVHTRI) return meshes[c0 & 0x0FFFFFFFu].root;  // always alone in its leaf
+                const uint32_t first = uint32_t(pleaf.size());
+                for (uint32_t i = 0; i < c.count; i++) pleaf.push_back(codes[items[c.left_or_first + i].idx]);
+                return BVH_LEAF | BVH_PRIMS | ((c.count - 1u) << 26) | first;
+            };
+            for (size_t k = 0; k < tmp.size(); k++) {
+                if (tmp[k].count != 0) continue;
+                BvhNode& w = local[remap[k]];
+                uint32_t l = tmp[k].left_or_first;
+                for (int a = 0; a < 3; a++) {
+                    w.lo0[a] = tmp[l].lo[a]; w.hi0[a] = tmp[l].hi[a];
+                    w.lo1[a] = tmp[l + 1].lo[a]; w.hi1[a] = tmp[l + 1].hi[a];
+                }
+                w.e0 = entry(l);
+                w.e1 = entry(l + 1);
+                w.pad0 = w.pad1 = 0;
+            }
+            nodes.insert(nodes.end(), local.begin(), local.end());
+            if (pleaf.size() >= BVH_INDEX_MASK) return fail(RPT_ERR_UNSUPPORTED, "too many primitives");
+        }
+    }
+    size_t o_pleaf = reserve(pleaf.size() * sizeof(uint32_t));
     size_t o_aabb = reserve(aabb.size() * sizeof(AabbScan));
     size_t o_rect = reserve(rect.size() * sizeof(RectScan)), o_rects = reserve(rect_sh.size() * sizeof(RectShade));
     size_t o_nodes = reserve(nodes.size() * sizeof(BvhNode));
@@ -826,6 +991,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     put(o_pln, pln.data(), pln.size() * sizeof(PlaneScan));    put(o_plns, pln_sh.data(), pln_sh.size() * sizeof(PlaneShade));
     put(o_tri, tri.data(), tri.size() * sizeof(TriScan));      put(o_tris, tri_sh.data(), tri_sh.size() * sizeof(TriShade));
     put(o_aabb, aabb.data(), aabb.size() * sizeof(AabbScan));
+    put(o_pleaf, pleaf.data(), pleaf.size() * sizeof(uint32_t));
     put(o_rect, rect.data(), rect.size() * sizeof(RectScan));  put(o_rects, rect_sh.data(), rect_sh.size() * sizeof(RectShade));
     put(o_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
     put(o_btri, btri.data(), btri.size() * sizeof(TriScan));   put(o_btris, btri_sh.data(), btri_sh.size() * sizeof(TriShade));
@@ -848,6 +1014,8 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     v.n_rect_x = uint32_t(rect_axis[0].size()); v.n_rect_y = uint32_t(rect_axis[1].size()); v.n_rect_z = uint32_t(rect_axis[2].size());
     v.nodes = (const BvhNode*)(base + o_nodes); v.btri = (const TriScan*)(base + o_btri);      v.btri_sh = (const TriShade*)(base + o_btris);
     v.meshes = (const MeshRef*)(base + o_mesh); v.n_mesh = uint32_t(meshes.size());
+    v.pleaf = (const uint32_t*)(base + o_pleaf); v.n_nodes = uint32_t(nodes.size());
+    v.scene_bvh = scene_bvh ? 1u : 0u;          v.top_root = top_root;
     v.mats = (const Material*)(base + o_mats);  v.n_obj = uint32_t(mats.size());
     v.lights = (const Light*)(base + o_lights); v.n_lights = uint32_t(lights.size());
     v.ltris = (const LightTri*)(base + o_ltris); v.lxf = (const LightXf*)(base + o_lxf);
@@ -888,6 +1056,8 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     // scan-record bytes every closest-hit query walks (the uniform part of the algorithmic bytes)
     s->stats[8] = 48 * (sph.size() + cub.size() + tri.size()) + 16 * pln.size() + 32 * (aabb.size() + rect.size());
     s->stats[9] = off;
+    s->stats[10] = scene_bvh ? 1 : 0;
+    s->stats[11] = pleaf.size();
 
     HIP_TRY(hipMalloc((void**)&s->d_queue, 256));
     HIP_TRY(hipMalloc((void**)&s->d_counters, 64 * sizeof(unsigned long long)));
@@ -984,7 +1154,7 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, const rpt_camera* cam, const
     a.slab = s->d_slab;
     a.queue = s->d_queue;
     a.counters = g_opt_counters ? s->d_counters : nullptr;
-    a.lds_stack = s->view.n_mesh ? 1u : 0u;
+    a.lds_stack = s->view.n_nodes ? 1u : 0u;
     return RPT_OK;
 }
 
@@ -1016,7 +1186,7 @@ extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm
 static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st) {
     int bpc = int(g_opt_blocks_per_cu);
     if (bpc <= 0) {
-        HIP_TRY(render_occupancy(a.sc.has_medium != 0, a.sc.n_mesh != 0, &bpc));
+        HIP_TRY(render_occupancy(a.sc.has_medium != 0, bvh_mode(a.sc), &bpc));
         if (bpc < 1) bpc = 1;
     }
     return rpti::run_persistent(s, prm, a, d_out, st, bpc,
@@ -1129,7 +1299,7 @@ int rpt_intersect_batch(rpt_scene* s, uint64_t n, const float* origins, const fl
     HIP_TRY(tmp.alloc(&d_obj, n));
     HIP_TRY(hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_d, dirs, n * 12, hipMemcpyHostToDevice));
-    HIP_TRY(launch_intersect(s->view, n, d_o, d_d, d_t, d_obj, d_n, s->view.n_mesh != 0, nullptr));
+    HIP_TRY(launch_intersect(s->view, n, d_o, d_d, d_t, d_obj, d_n, s->view.n_nodes != 0, nullptr));
     HIP_TRY(hipMemcpy(t, d_t, n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(object, d_obj, n * 4, hipMemcpyDeviceToHost));
     if (normal) HIP_TRY(hipMemcpy(normal, d_n, n * 12, hipMemcpyDeviceToHost));

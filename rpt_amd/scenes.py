@@ -11,7 +11,8 @@ import math
 
 import numpy as np
 
-from .api import (Camera, Light, Material, Medium, Mesh, Object, Scene, cube, hex_color, plane, polygon, sphere, vec3)
+from .api import (Camera, KdTree, Light, Material, Medium, Mesh, Object, Scene, cube, hex_color, plane, polygon, sphere,
+                  vec3)
 
 
 def spheres():
@@ -184,6 +185,37 @@ def lampshade_beamphoton():
     photons = 1_000_000
     cfg = dict(cfg, photons=photons, gather_size=20, gather_size_volume=3, renderer_watts=watts * photons)
     return scene, cam, cfg
+
+
+def fractal_spheres(levels=5):
+    """examples/fractal_spheres.rs: 937 spheres in five `KdTree<Box<dyn Bounded>>` groups (one
+    material per recursion level) over a plane; ambient + directional + point light."""
+    colors = [0x264653, 0x2A9D8F, 0xE9C46A, 0xF4A261, 0xE76F51][:levels]
+    groups = [[] for _ in colors]
+
+    def gen(p, rad, depth, last_dir):
+        groups[depth].append(sphere().scale(vec3(rad, rad, rad)).translate(p))
+        if depth == len(groups) - 1:
+            return
+        disp = rad * 7.0 / 5.0
+        steps = [(disp, 0, 0), (-disp, 0, 0), (0, disp, 0), (0, -disp, 0), (0, 0, disp), (0, 0, -disp)]
+        for i, st in enumerate(steps):
+            if last_dir is None or i != (last_dir ^ 1):
+                gen(p + vec3(*st), rad * 2.0 / 5.0, depth + 1, i)
+
+    gen(vec3(0.0, 0.0, 0.0), 1.0, 0, None)
+    scene = Scene()
+    for i, group in enumerate(groups):
+        scene.add(Object(KdTree(group)).material(Material.specular(hex_color(colors[i]), 0.25)))
+    scene.add(Object(plane(vec3(0.0, 0.0, 1.0), -6.0)).material(Material.diffuse(hex_color(0xFFCCCC))))
+    scene.add(Light.Ambient(vec3(0.02, 0.02, 0.02)))
+    d = vec3(0.0, -0.65, -1.0)
+    scene.add(Light.Directional(vec3(0.6, 0.6, 0.6), d / np.linalg.norm(d)))
+    scene.add(Light.Point(vec3(100.0, 100.0, 100.0), vec3(0.0, 5.0, 5.0)))
+    cd, cu = vec3(-0.285714, -0.5, -1.0), vec3(0.0, 1.0, -0.5)
+    camera = Camera(eye=vec3(2.0, 3.5, 7.0), direction=cd / np.linalg.norm(cd), up=cu / np.linalg.norm(cu),
+                    fov=math.pi / 6.0)
+    return scene, camera, dict(width=800, height=600, spp=100, max_bounces=0, filter=0)
 
 
 CONFIGS = {

@@ -1,0 +1,136 @@
+"""GPU parity for `KdTree<Box<dyn Bounded>>` group shapes (src/kdtree.rs:103-146,
+examples/fractal_spheres.rs) and for the scene-level BVH the library builds over many bounded
+primitives: against the fp64 oracle's kd-tree and against the library's own linear scan."""
+import numpy as np
+import pytest
+
+import rpt_amd
+from rpt_amd import Camera, KdTree, Material, Mesh, Object, Renderer, Scene, cube, plane, scenes, sphere, vec3
+from tests.util import random_rays, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(scene):
+    from oracle.pyoracle import OracleScene
+    return OracleScene(scene)
+
+
+@pytest.fixture
+def scene_bvh_option():
+    """Restores the commit-time option whatever the test sets it to."""
+    yield lambda v: rpt_amd.set_option("scene_bvh_min", v)
+    rpt_amd.set_option("scene_bvh_min", 64)
+
+
+def _mixed_group(rng, n):
+    kids = []
+    for i in range(n):
+        base = sphere() if i % 3 else cube()
+        s = base.scale(rng.uniform(0.05, 0.3, 3))
+        if i % 5 == 0:
+            s = s.rotate_y(rng.uniform(0, 3)).rotate_x(rng.uniform(0, 3))
+        kids.append(s.translate(rng.uniform(-2, 2, 3)))
+    return kids
+
+
+def test_fractal_spheres_closest_hit_matches_oracle_kdtree():
+    scene, cam, cfg = scenes.fractal_spheres()
+    r = Renderer(scene, cam)
+    st = r.scene_stats()
+    assert st["spheres"] == 937 and st["scene_bvh"] == 1 and st["scene_bvh_prims"] == 937
+    o, d = random_rays(np.random.default_rng(5), 40000, np.zeros(3), 4.0)
+    t, obj, nrm = r.get_closest_hit(o, d)
+    te, obje, nrme = _oracle(scene).intersect(o.astype(np.float32), d.astype(np.float32), robust=1)
+    same = obj == obje
+    assert same.mean() > 0.9995                              # silhouette rays may flip in fp32
+    hit = same & (obje >= 0)
+    assert sorted(set(obje[obje >= 0].tolist())) == [0, 1, 2, 3, 4, 5]   # every level and the plane are hit
+    assert np.max(np.abs(t[hit] - te[hit]) / te[hit]) < 2e-4
+    assert np.quantile(np.abs(nrm[hit] - nrme[hit]).max(axis=1), 0.999) < 2e-3
+    assert np.all(np.isinf(t[same & (obje < 0)]))
+
+
+def test_fractal_spheres_render_matches_oracle():
+    scene, cam, cfg = scenes.fractal_spheres()
+    w, h, spp = 160, 120, 16
+    got = Renderer(scene, cam).width(w).height(h).max_bounces(2).seed(4).sample_array(spp)
+    exp = _oracle(scene).render(cam, w, h, spp, 2, seed=4, robust=1)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert rel_rms(got, exp) < 5e-3
+    assert abs(got.mean() - exp.mean()) / exp.mean() < 2e-3
+
+
+def test_transformed_group_of_mixed_shapes_matches_flat_scene_and_oracle():
+    """A rotated/scaled KdTree of spheres, cubes, a small mesh, a BVH mesh and a nested group:
+    (a) equals the oracle's kd-tree, (b) equals the same primitives added as separate objects."""
+    rng = np.random.default_rng(11)
+    kids = _mixed_group(rng, 120)
+    tet = scenes.bumpy_torus(6, 4)                           # 48 triangles -> BVH mesh inside the group
+    kids.append(Mesh(tet).scale(vec3(1.5, 1.5, 1.5)).translate(vec3(0.0, 0.5, 0.0)))
+    kids.append(Mesh(scenes.bumpy_torus(3, 3)).translate(vec3(1.0, -1.0, 0.5)))   # 18 triangles -> linear prims
+    kids.append(KdTree(_mixed_group(rng, 10)).scale(vec3(0.5, 0.5, 0.5)).translate(vec3(0.0, 2.0, 0.0)))
+    white = Material.diffuse(vec3(1, 1, 1))
+
+    def wrap(s):
+        return s.scale(vec3(1.2, 0.8, 1.0)).rotate_z(0.4).translate(vec3(0.3, 0.0, -0.2))
+
+    grouped = Scene()
+    grouped.add(Object(wrap(KdTree(kids))).material(white))
+    grouped.add(Object(plane(vec3(0, 1, 0), -3.0)).material(white))
+    flat = Scene()
+    for k in kids[:-1]:
+        flat.add(Object(wrap(k)).material(white))
+    for k in kids[-1].base().shapes:
+        flat.add(Object(wrap(k.scale(vec3(0.5, 0.5, 0.5)).translate(vec3(0.0, 2.0, 0.0)))).material(white))
+    flat.add(Object(plane(vec3(0, 1, 0), -3.0)).material(white))
+    o, d = random_rays(rng, 30000, np.zeros(3), 5.0)
+    tg, objg, ng = Renderer(grouped, Camera()).get_closest_hit(o, d)
+    te, obje, ne = _oracle(grouped).intersect(o.astype(np.float32), d.astype(np.float32), robust=1)
+    same = objg == obje
+    assert same.mean() > 0.999
+    hit = same & (obje >= 0)
+    assert (obje == 0).sum() > 3000
+    assert np.quantile(np.abs(tg[hit] - te[hit]) / te[hit], 0.999) < 2e-4
+    close = hit & (np.abs(tg - te) <= 2e-4 * te)
+    assert np.quantile(np.abs(ng[close] - ne[close]).max(axis=1), 0.995) < 5e-3
+    # same primitives as separate objects: same distances and normals (ties between overlapping
+    # shapes may pick the other primitive, hence the tolerance on t rather than bit equality)
+    tf, objf, nf = Renderer(flat, Camera()).get_closest_hit(o, d)
+    assert np.array_equal(np.isfinite(tg), np.isfinite(tf))
+    fin = np.isfinite(tg)
+    assert np.max(np.abs(tg[fin] - tf[fin]) / tf[fin]) < 1e-6
+    assert np.array_equal(objg[fin] == 1, objf[fin] == len(flat.objects) - 1)     # the plane
+
+
+@pytest.mark.parametrize("name,size,spp", [("C2", 96, 16), ("C3", 96, 16)])
+def test_forced_scene_bvh_equals_linear_scan(name, size, spp, scene_bvh_option):
+    """The scene-level BVH is an acceleration structure only: forcing it on the Cornell-box
+    configs (whose ~20 primitives are normally scanned) must give the same image as the scan up
+    to exact-tie resolution between coincident surfaces."""
+    imgs = []
+    for force in (False, True):
+        scene_bvh_option(2 if force else 1 << 30)
+        scene, cam, cfg = scenes.CONFIGS[name]()
+        r = Renderer(scene, cam).width(size).height(size).max_bounces(cfg["max_bounces"]).seed(9)
+        assert r.scene_stats()["scene_bvh"] == (1 if force else 0)
+        imgs.append(r.sample_array(spp))
+    lin, bvh = imgs
+    assert np.all(np.isfinite(bvh))
+    differing = np.any(lin != bvh, axis=1).mean()
+    assert differing < 0.02                                  # paths through exactly coincident surfaces only
+    assert rel_rms(bvh, lin) < 2e-2
+    assert abs(bvh.mean() - lin.mean()) / lin.mean() < 2e-3
+
+
+def test_group_errors_are_rejected_at_add():
+    from rpt_amd import Light, RptError
+    with pytest.raises(TypeError):
+        KdTree([plane(vec3(0, 1, 0), 0.0)])
+    with pytest.raises(ValueError):
+        KdTree([])
+    sc = Scene()
+    sc.add(Object(sphere()).material(Material.diffuse(vec3(1, 1, 1))))
+    sc.add(Light.Object(Object(KdTree([sphere(), cube()])).material(Material.light(vec3(1, 1, 1), 5.0))))
+    with pytest.raises(RptError):
+        Renderer(sc, Camera()).width(8).height(8).sample_array(1)

@@ -168,3 +168,27 @@ f -4/1 -3/1 -2
     q = tmp_path / "a.stl"
     q.write_text("solid x\nfacet normal 0 0 0\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\nendloop\nendfacet\nendsolid x\n")
     assert load_stl(str(q)).tris.shape == (1, 6, 3)
+
+
+def test_kdtree_group_lowers_to_a_children_array():
+    """KdTree<Box<dyn Bounded>> (kdtree.rs:103-146): children keep their own transforms, groups nest,
+    planes are rejected (not Bounded), and a transform on the group stays on the group."""
+    import ctypes as C
+    from rpt_amd import KdTree, cube, plane, sphere, vec3
+    from rpt_amd._lib import ShapeDesc
+    from rpt_amd.api import shape_desc
+    inner = KdTree([sphere().translate(vec3(0, 1, 0)), cube()])
+    g = KdTree([sphere().scale(vec3(2, 2, 2)), inner.translate(vec3(5, 0, 0))]).rotate_y(0.5)
+    d, keep = shape_desc(g, ShapeDesc)
+    assert d.kind == 4 and d.has_transform == 1 and d.n_children == 2 and d.n_tris == 0
+    c0, c1 = d.children[0], d.children[1]
+    assert c0.kind == 0 and c0.has_transform == 1 and c0.transform[0] == 2.0
+    assert c1.kind == 4 and c1.n_children == 2 and c1.transform[3] == 5.0
+    assert c1.children[0].kind == 0 and c1.children[0].transform[7] == 1.0 and c1.children[1].kind == 1
+    assert C.sizeof(ShapeDesc) == 200
+    with pytest.raises(TypeError):
+        KdTree([plane(vec3(0, 1, 0), 0.0)])
+    with pytest.raises(ValueError):
+        KdTree([])
+    scene, cam, cfg = scenes.fractal_spheres()
+    assert [len(o.shape.shapes) for o in scene.objects[:5]] == [1, 6, 30, 150, 750]     # fractal_spheres.rs prints these

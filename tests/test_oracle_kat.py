@@ -11,8 +11,8 @@ import pytest
 
 from oracle import pyoracle
 from oracle.pyoracle import CameraDesc, MaterialDesc, OracleScene, ShapeDesc
-from rpt_amd import (Camera, Light, Material, Medium, Mesh, Object, Scene, cube, hex_color, plane, polygon, scenes,
-                     sphere, vec3)
+from rpt_amd import (Camera, KdTree, Light, Material, Medium, Mesh, Object, Scene, cube, hex_color, plane, polygon,
+                     scenes, sphere, vec3)
 from rpt_amd.api import camera_desc, material_desc, shape_desc
 
 
@@ -128,6 +128,44 @@ def test_kdtree_matches_brute_force():
                                  t.ctypes.data_as(C.c_void_p))
     assert bad == 0
     assert 0.2 < np.isfinite(t).mean() < 0.99
+
+
+# ---- KAT 7b: KdTree<Box<dyn Bounded>> (kdtree.rs:103-227 over shapes) == the same shapes as separate objects
+def test_shape_kdtree_matches_a_flat_scene_and_transforms_like_any_shape():
+    rng = np.random.default_rng(1)
+    kids = []
+    for i in range(200):
+        base = sphere() if i % 3 else cube()
+        kids.append(base.scale(rng.uniform(0.05, 0.3, 3)).rotate_y(rng.uniform(0, 3)).translate(rng.uniform(-2, 2, 3)))
+    kids.append(Mesh(scenes.bumpy_torus(8, 6)).translate(vec3(0.0, 0.5, 0.0)))
+    white = Material.diffuse(vec3(1, 1, 1))
+    grouped, flat = Scene(), Scene()
+    grouped.add(Object(KdTree(kids).rotate_x(0.3).translate(vec3(0.1, 0.2, 0.3))).material(white))
+    for k in kids:
+        flat.add(Object(k.rotate_x(0.3).translate(vec3(0.1, 0.2, 0.3))).material(white))
+    n = 20000
+    o = rng.uniform(-3, 3, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tg, objg, ng = OracleScene(grouped).intersect(o, d)
+    tf, objf, nf = OracleScene(flat).intersect(o, d)
+    hit = np.isfinite(tf)
+    assert 0.1 < hit.mean() < 0.9 and np.array_equal(hit, np.isfinite(tg))
+    assert np.all(objg[hit] == 0)
+    # the group composes its transform with each child's (Transformed<KdTree<Transformed<T>>>): two
+    # inverse applications instead of one, so equal to rounding rather than to the bit
+    assert np.max(np.abs(tg[hit] - tf[hit]) / tf[hit]) < 1e-9
+    assert np.max(np.abs(ng[hit] - nf[hit])) < 1e-6
+    # sampling a group picks a child uniformly and divides its pdf by the child count (kdtree.rs:141-146)
+    L = pyoracle.lib()
+    # (a uniformly scaled cube has a position-independent pdf, so the extra index draw does not matter)
+    one, _k1 = shape_desc(cube().scale(vec3(0.5, 0.5, 0.5)), ShapeDesc)
+    grp, _k2 = shape_desc(KdTree([cube().scale(vec3(0.5, 0.5, 0.5))] * 4), ShapeDesc)
+    v1, n1, p1 = D(0, 0, 0), D(0, 0, 0), C.c_double()
+    v4, n4, p4 = D(0, 0, 0), D(0, 0, 0), C.c_double()
+    L.orc_shape_sample(C.byref(one), D(0, 3, 0), C.c_uint64(0), 3, 0, v1, n1, C.byref(p1))
+    L.orc_shape_sample(C.byref(grp), D(0, 3, 0), C.c_uint64(0), 3, 0, v4, n4, C.byref(p4))
+    assert p1.value > 0 and abs(p4.value - p1.value / 4.0) < 1e-15 * p1.value
 
 
 # ---- KAT 8-9: materials
