@@ -154,7 +154,8 @@ int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* g
 /* Runtime options (all optional): "counters" 0/1, "chunk_spp" (samples per work item, 0 = auto),
  * "blocks_per_cu" (persistent grid size), "timing" 0/1, "scene_bvh_min" (read by rpt_scene_commit:
  * number of bounded primitives + BVH meshes from which one scene-level BVH replaces the linear
- * object scan, default 64); returns RPT_ERR_INVALID for unknown names. */
+ * object scan, default 64), "instancing" 0/1 (read by rpt_scene_commit: store a mesh that several
+ * shapes share once and instance it, default 1); returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 
 /* ---- photon mapping (next tier: src/photon.rs; config C4 = photon_point_query_beam_render) ----

@@ -226,10 +226,30 @@ RPT_DEV void slab2(const float lo[3], const float hi[3], V o, V inv, float& tn, 
     tn = max3(fminf(x1, x2), fminf(y1, y2), fminf(z1, z2));
     tf = min3(fmaxf(x1, x2), fmaxf(y1, y2), fmaxf(z1, z2));
 }
-// One primitive of a BVH_PRIMS leaf (per lane: kinds may differ between lanes).
-RPT_DEV void hit_prim(const SceneView& sc, uint32_t pc, V o, V d, V inv, float tmin, float& tbest, uint32_t& code) {
+template <bool COUNT, bool PRIMS>
+RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tmin, float& tbest, uint32_t& code,
+                          uint32_t& inst, uint32_t* stk, uint32_t stride, uint32_t cap, uint32_t& c_nodes,
+                          uint32_t& c_tris);
+
+// One primitive of a BVH_PRIMS leaf (per lane: kinds may differ between lanes).  `stk`/`cap`:
+// the part of the lane's stack column above the caller's entries, for the nested walk of an instance.
+template <bool COUNT>
+RPT_DEV void hit_prim(const SceneView& sc, uint32_t pc, V o, V d, V inv, float tmin, float& tbest, uint32_t& code,
+                      uint32_t& inst, uint32_t* stk, uint32_t stride, uint32_t cap, uint32_t& c_nodes,
+                      uint32_t& c_tris) {
     const uint32_t kind = pc >> 28, i = pc & 0x0FFFFFFFu;
     float t = -1.f;
+    if (kind == K_INST) {
+        const InstRec r = sc.inst[i];
+        const V ol = mk(dot3w(r.r0, o), dot3w(r.r1, o), dot3w(r.r2, o));
+        const V dl = mk(dot3(r.r0, d), dot3(r.r1, d), dot3(r.r2, d));   // not renormalised: t is shared
+        uint32_t c2 = CODE_MISS, unused = 0;
+        float tb = tbest;
+        bvh_traverse<COUNT, false>(sc, __float_as_uint(r.n1.w), ol, dl, tmin, tb, c2, unused, stk, stride, cap, c_nodes,
+                                   c_tris);
+        if (c2 != CODE_MISS) { tbest = tb; code = (K_INSTTRI << 28) | (c2 & 0x0FFFFFFFu); inst = i; }
+        return;
+    }
     if (kind == K_SPHERE) {
         const XfScan x = sc.sph[i];
         V ol, dl;
@@ -258,8 +278,9 @@ RPT_DEV void hit_prim(const SceneView& sc, uint32_t pc, V o, V d, V inv, float t
 }
 
 template <bool COUNT, bool PRIMS>
-RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tmin, float& tbest,
-                          uint32_t& code, uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
+RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tmin, float& tbest, uint32_t& code,
+                          uint32_t& inst, uint32_t* stk, uint32_t stride, uint32_t cap, uint32_t& c_nodes,
+                          uint32_t& c_tris) {
     const BvhNode* nodes = sc.nodes;
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
     const uint32_t kDone = 0xFFFFFFFFu;  // a 32-item prim leaf at the last index never occurs
@@ -276,7 +297,7 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
             const bool h1 = fmaxf(n1, tmin) <= fminf(f1, tbest);
             if (h0 && h1) {
                 const bool first0 = n0 <= n1;
-                if (sp < 32) { stk[sp * stride] = first0 ? nd.e1 : nd.e0; sp++; }
+                if (sp < cap) { stk[sp * stride] = first0 ? nd.e1 : nd.e0; sp++; }
                 cur = first0 ? nd.e0 : nd.e1;
             } else if (h0 || h1) {
                 cur = h0 ? nd.e0 : nd.e1;
@@ -293,7 +314,8 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
             if (PRIMS && (cur & BVH_PRIMS)) {
                 for (uint32_t i = 0; i < count; i++) {
                     if (COUNT) c_tris++;
-                    hit_prim(sc, sc.pleaf[first + i], o, d, inv, tmin, tbest, code);
+                    hit_prim<COUNT>(sc, sc.pleaf[first + i], o, d, inv, tmin, tbest, code, inst, stk + sp * stride, stride,
+                                    cap - sp, c_nodes, c_tris);
                 }
             } else {
                 for (uint32_t i = 0; i < count; i++) {
@@ -315,7 +337,7 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
 
 // BVH: 0 = no tree in the scene, 1 = per-mesh trees only, 2 = scene-level tree possible.
 template <int BVH, bool COUNT>
-RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code,
+RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
                          uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
     if (BVH == 2 && sc.scene_bvh) {  // wave-uniform: planes (unbounded) are scanned, everything else is in the tree
         for (uint32_t i = 0; i < sc.n_pln; i++) {
@@ -323,7 +345,7 @@ RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest
             float t = hit_plane(nv, o, d, tmin);
             if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
         }
-        bvh_traverse<COUNT, true>(sc, sc.top_root, o, d, tmin, tbest, code, stk, stride, c_nodes, c_tris);
+        bvh_traverse<COUNT, true>(sc, sc.top_root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris);
         return;
     }
     for (uint32_t i = 0; i < sc.n_sph; i++) {
@@ -380,14 +402,34 @@ RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest
     if (BVH) {
         for (uint32_t i = 0; i < sc.n_mesh; i++) {
             const MeshRef m = uload(&sc.meshes[i]);
-            bvh_traverse<COUNT, false>(sc, m.root, o, d, tmin, tbest, code, stk, stride, c_nodes, c_tris);
+            bvh_traverse<COUNT, false>(sc, m.root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris);
         }
     }
 }
 
 // Normal and object of the winning primitive (per lane).
-RPT_DEV void finalize_hit(const SceneView& sc, V o, V d, float tmin, float t, uint32_t code, V& n, uint32_t& obj) {
+RPT_DEV void finalize_hit(const SceneView& sc, V o, V d, float tmin, float t, uint32_t code, uint32_t inst, V& n,
+                          uint32_t& obj) {
     uint32_t kind = code >> 28, idx = code & 0x0FFFFFFFu;
+    if (kind == K_INSTTRI) {  // src/shape/mesh.rs:78 in the instance's space, then src/shape.rs:131-134
+        const InstRec r = sc.inst[inst];
+        const TriShade s = sc.btri_sh[idx];
+        V nl;
+        if (s.n2.w != 0.f) {
+            nl = xyz(s.n1);
+        } else {
+            const TriScan tr = sc.btri[idx];
+            const V ol = mk(dot3w(r.r0, o), dot3w(r.r1, o), dot3w(r.r2, o));
+            const V dl = mk(dot3(r.r0, d), dot3(r.r1, d), dot3(r.r2, d));
+            V p = fma3(t, dl, ol);
+            float v = dot3w(tr.A, p), w = dot3w(tr.B, p);
+            float u = 1.f - v - w;
+            nl = normalize(u * xyz(s.n1) + v * xyz(s.n2) + w * xyz(s.n3));
+        }
+        n = normalize(mk(dot3(r.n0, nl), dot3(r.n1, nl), dot3(r.n2, nl)));
+        obj = __float_as_uint(r.n0.w);
+        return;
+    }
     if (kind == K_SPHERE) {  // src/shape/sphere.rs:40-41 then src/shape.rs:131-134
         const XfScan x = sc.sph[idx];
         const XfShade s = sc.sph_sh[idx];

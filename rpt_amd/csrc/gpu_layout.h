@@ -17,7 +17,9 @@ struct alignas(16) F4 {
 };
 
 // Primitive code = (kind << 28) | index-within-kind.  0xFFFFFFFF = miss.
-enum : uint32_t { K_SPHERE = 0, K_CUBE = 1, K_PLANE = 2, K_TRI = 3, K_BVHTRI = 4, K_AABB = 5, K_RECT = 6 };
+enum : uint32_t { K_SPHERE = 0, K_CUBE = 1, K_PLANE = 2, K_TRI = 3, K_BVHTRI = 4, K_AABB = 5, K_RECT = 6,
+                  K_INST = 7,      // scene-BVH leaf item: one instance of a shared local-space mesh
+                  K_INSTTRI = 8 }; // hit code: triangle of an instanced mesh (the instance travels beside the code)
 static const uint32_t CODE_MISS = 0xFFFFFFFFu;
 
 // Sphere / cube scan record: rows of the inverse affine map (world -> unit primitive).
@@ -115,6 +117,13 @@ struct alignas(16) LightXf {
     F4 nrm[3];   // M^-T rows; nrm[0].w = det(linear); nrm[1].w = has_transform
     F4 lin[3];   // linear rows
 };
+// One instance of a mesh that several shapes share (Arc<Mesh> under different transforms,
+// examples/fractal_teapots.rs:17-22): the mesh's triangles and tree are stored once in LOCAL
+// space; the ray is mapped into it exactly as Transformed::intersect does (src/shape.rs:129-138).
+struct alignas(16) InstRec {
+    F4 r0, r1, r2;   // rows of M^-1 (world -> local)
+    F4 n0, n1, n2;   // rows of M^-T (normals local -> world); n0.w = object (bits), n1.w = mesh root node (bits)
+};
 struct alignas(16) MeshRef {   // one BVH-accelerated mesh object
     uint32_t root, tri_base, tri_count, object;   // root: absolute index of the mesh's root node
 };
@@ -132,6 +141,7 @@ struct SceneView {
     // of them, e.g. KdTree<Box<dyn Bounded>> groups): scene_bvh = 1 replaces the linear scans of
     // sph/cub/aabb/rect/tri and the per-mesh walks by one walk from `top_root`.
     const uint32_t* pleaf; uint32_t n_nodes, scene_bvh, top_root;
+    const InstRec* inst;   uint32_t n_inst;
     const Material* mats;  uint32_t n_obj;   // one material record per scene object
     const Light* lights;   uint32_t n_lights;
     const LightTri* ltris; const LightXf* lxf;

@@ -24,10 +24,11 @@ namespace rptg {
 RPT_DEV uint32_t mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
 }
-RPT_DEV uint32_t code_object(const SceneView& sc, uint32_t code) {
+RPT_DEV uint32_t code_object(const SceneView& sc, uint32_t code, uint32_t inst) {
     uint32_t kind = code >> 28, idx = code & 0x0FFFFFFFu;
     float w;
-    if (kind == K_SPHERE) w = sc.sph_sh[idx].r0.w;
+    if (kind == K_INSTTRI) w = sc.inst[inst].n0.w;
+    else if (kind == K_SPHERE) w = sc.sph_sh[idx].r0.w;
     else if (kind == K_CUBE) w = sc.cub_sh[idx].r0.w;
     else if (kind == K_PLANE) w = sc.pln_sh[idx].unit_n_obj.w;
     else if (kind == K_TRI) w = sc.tri_sh[idx].n1.w;
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
         const V wo = -normalize(rd);
         const float tmin = ray_tmin(ro);
         float t = kInf;
-        uint32_t code = CODE_MISS;
-        closest_hit<BVH, COUNT>(sc, ro, rd, tmin, t, code, stk, stride, c_nodes, c_btris);
+        uint32_t code = CODE_MISS, inst = 0;
+        closest_hit<BVH, COUNT>(sc, ro, rd, tmin, t, code, inst, stk, stride, c_nodes, c_btris);
         if (COUNT) c_rays++;
         const bool hit = code != CODE_MISS;
 
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
             E = (depth == 0) ? sc.medium_emission * mcol : mk(0, 0, 0);
         } else {  // src/renderer.rs:207-216, 289-299
             uint32_t obj;
-            finalize_hit(sc, ro, rd, tmin, t, code, n, obj);
+            finalize_hit(sc, ro, rd, tmin, t, code, inst, n, obj);
             mat = load_mat(sc, obj);
             x = fma3(t, rd, ro);
             E = (depth == 0) ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
@@ -207,11 +208,11 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
                     // (|hit - dist| < 1e-12).  fp32 equivalent: the closest hit belongs to the
                     // scene object that IS this light, at the sampled distance (rel. tol 1e-3).
                     float ts = dist * (1.f + 1e-3f);
-                    uint32_t cs = CODE_MISS;
-                    closest_hit<BVH, COUNT>(sc, x, wi, ray_tmin(x), ts, cs, stk, stride, c_nodes, c_btris);
+                    uint32_t cs = CODE_MISS, is = 0;
+                    closest_hit<BVH, COUNT>(sc, x, wi, ray_tmin(x), ts, cs, is, stk, stride, c_nodes, c_btris);
                     if (COUNT) c_rays++;
                     bool vis = cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) &&
-                               code_object(sc, cs) == uint32_t(L.twin_object);
+                               code_object(sc, cs, is) == uint32_t(L.twin_object);
                     if (vis) {
                         if (ev_medium) {
                             E = fma3(albedo_med * sc.medium_phase, I * mcol, E);
@@ -302,11 +303,11 @@ __global__ __launch_bounds__(256) void intersect_kernel(const SceneView sc, uint
     if (i >= n) return;
     V ro = mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     float tmin = ray_tmin(ro), t = kInf;
-    uint32_t code = CODE_MISS, c0 = 0, c1 = 0;
-    closest_hit<BVH, false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
+    uint32_t code = CODE_MISS, inst = 0, c0 = 0, c1 = 0;
+    closest_hit<BVH, false>(sc, ro, rd, tmin, t, code, inst, stk, 256, c0, c1);
     V nn = mk(0, 0, 0);
     uint32_t obj = 0xFFFFFFFFu;
-    if (code != CODE_MISS) finalize_hit(sc, ro, rd, tmin, t, code, nn, obj);
+    if (code != CODE_MISS) finalize_hit(sc, ro, rd, tmin, t, code, inst, nn, obj);
     t_out[i] = t;
     obj_out[i] = int32_t(obj);
     if (n_out) {

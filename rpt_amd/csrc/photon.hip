@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
             const V wo = -normalize(rd);
             const float tmin = ray_tmin_p(ro);
             float t = kInf;
-            uint32_t code = CODE_MISS;
-            closest_hit<(BVH ? 2 : 0), false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
+            uint32_t code = CODE_MISS, inst = 0;
+            closest_hit<(BVH ? 2 : 0), false>(sc, ro, rd, tmin, t, code, inst, stk, 256, c0, c1);
             const bool hit = code != CODE_MISS;
             bool in_volume = false;
             float d = 0.f;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
             // trace_on_surface :811-875, p_d = 0.7
             V n;
             uint32_t obj;
-            finalize_hit(sc, ro, rd, tmin, t, code, n, obj);
+            finalize_hit(sc, ro, rd, tmin, t, code, inst, n, obj);
             const Mat mat = load_mat(sc, obj);
             V x = fma3(t, rd, ro);
             if (!(rng.uniform() < 0.7f)) break;
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
         const bool active = alive;
         V ro = mk(0, 0, 0), rd = mk(0, 0, 1), wo = mk(0, 0, -1);
         float tmin = 0.f, t = kInf;
-        uint32_t code = CODE_MISS;
+        uint32_t code = CODE_MISS, inst = 0;
         Rng rng;
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
         if (active) {
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
             cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
             wo = -normalize(rd);
             tmin = ray_tmin_p(ro);
-            closest_hit<(BVH ? 2 : 0), false>(sc, ro, rd, tmin, t, code, stk, 256, c0, c1);
+            closest_hit<(BVH ? 2 : 0), false>(sc, ro, rd, tmin, t, code, inst, stk, 256, c0, c1);
         }
         const bool hit = code != CODE_MISS;
         V color = mk(0, 0, 0);
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
         if (surface_on) {  // surface estimate, src/photon.rs:327-375
             V n;
             uint32_t obj;
-            finalize_hit(sc, ro, rd, tmin, t, code, n, obj);
+            finalize_hit(sc, ro, rd, tmin, t, code, inst, n, obj);
             const Mat mat = load_mat(sc, obj);
             const V x = fma3(t, rd, ro);
             float max_d2;
@@ -804,8 +804,8 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                 V po = xyz(ph.pos_r);
                 float len = len2 * ilen;
                 float ts = kInf;
-                uint32_t cs = CODE_MISS;
-                closest_hit<(BVH ? 2 : 0), false>(sc, po, pd, ray_tmin_p(po), ts, cs, stk, 256, c0, c1);
+                uint32_t cs = CODE_MISS, is = 0;
+                closest_hit<(BVH ? 2 : 0), false>(sc, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
                 // :357-361 "something lies between the photon and the query point".  A hit inside the
                 // query point's own tangent plane is the grazing ray meeting its own surface: fp64 rejects
                 // it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.

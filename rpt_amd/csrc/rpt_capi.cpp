@@ -8,7 +8,9 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/rpt_hip.h"
@@ -48,6 +50,7 @@ static int64_t g_opt_counters = 0;
 static int64_t g_opt_chunk_spp = 0;  // 0 = auto: ceil(iterations / 64) clamped to [2, 32]
 static int64_t g_opt_blocks_per_cu = 0;  // 0 = occupancy query
 static int64_t g_opt_timing = 0;
+static int64_t g_opt_instancing = 1;     // meshes shared by several shapes are stored once and instanced
 static int64_t g_opt_scene_bvh_min = 64;  // bounded primitives + BVH meshes from which the scene-level BVH is built
 
 // ---------------------------------------------------------------------------- fp64 helpers
@@ -166,7 +169,11 @@ uint64_t seed_mix(uint64_t seed) { return rpti::seed_mix(seed); }
 // ---------------------------------------------------------------------------- host scene
 struct HShape {
     rpt_shape_desc d;            // tris / children pointers rewritten to own storage
-    std::vector<double> tris;
+    std::shared_ptr<const std::vector<double>> mesh;  // interned per scene: shapes sharing a mesh share this
+    const std::vector<double>& T() const {
+        static const std::vector<double> none;
+        return mesh ? *mesh : none;
+    }
     std::vector<HShape> children;  // RPT_SHAPE_GROUP
 };
 struct HObject {
@@ -188,8 +195,8 @@ bool same_shape(const HShape& a, const HShape& b) {
     if (a.d.kind == RPT_SHAPE_PLANE)
         return std::memcmp(a.d.plane_normal, b.d.plane_normal, 24) == 0 && a.d.plane_value == b.d.plane_value;
     if (a.d.kind == RPT_SHAPE_MESH)
-        return a.tris.size() == b.tris.size() &&
-               (a.tris.empty() || std::memcmp(a.tris.data(), b.tris.data(), a.tris.size() * 8) == 0);
+        return a.mesh == b.mesh || (a.T().size() == b.T().size() &&
+                                    (a.T().empty() || std::memcmp(a.T().data(), b.T().data(), a.T().size() * 8) == 0));
     if (a.d.kind == RPT_SHAPE_GROUP) {
         if (a.children.size() != b.children.size()) return false;
         for (size_t i = 0; i < a.children.size(); i++)
@@ -363,19 +370,43 @@ struct rpt_scene {
     uint64_t prims_per_ray = 0;
     uint64_t stats[16] = {0};
     void* photon = nullptr;  // PhotonMapDev*, owned by photon.hip
+    // mesh data interned by content (hash -> candidates), so Arc<Mesh>-style sharing survives the C ABI
+    std::unordered_map<uint64_t, std::vector<std::shared_ptr<const std::vector<double>>>> mesh_pool;
     // tile cache key
     uint32_t tk_w = 0, tk_h = 0, tk_rank = 0, tk_count = 0, n_tiles = 0, tiles_x = 0;
 };
 
-static bool copy_shape(const rpt_shape_desc* d, HShape& out, std::string& why, int depth = 0) {
+using MeshCallCache = std::unordered_map<const double*, std::pair<uint64_t, std::shared_ptr<const std::vector<double>>>>;
+static std::shared_ptr<const std::vector<double>> intern_mesh(rpt_scene* s, const double* p, uint64_t n_tris,
+                                                              MeshCallCache& seen) {
+    auto it = seen.find(p);  // caller memory cannot change during one add call: same pointer, same data
+    if (it != seen.end() && it->second.first == n_tris) return it->second.second;
+    const size_t n = size_t(n_tris) * 18;
+    uint64_t h = 0xCBF29CE484222325ULL ^ n;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0x100000001B3ULL;
+        h ^= h >> 29;
+    }
+    auto& bucket = s->mesh_pool[h];
+    for (auto& c : bucket)
+        if (c->size() == n && std::memcmp(c->data(), p, n * 8) == 0) { seen[p] = {n_tris, c}; return c; }
+    auto m = std::make_shared<const std::vector<double>>(p, p + n);
+    bucket.push_back(m);
+    seen[p] = {n_tris, m};
+    return m;
+}
+static bool copy_shape(rpt_scene* s, MeshCallCache& seen, const rpt_shape_desc* d, HShape& out, std::string& why,
+                       int depth = 0) {
     if (!d) { why = "null shape"; return false; }
     if (d->kind < 0 || d->kind > RPT_SHAPE_GROUP) { why = "unknown shape kind"; return false; }
     out.d = *d;
-    out.tris.clear();
+    out.mesh.reset();
     out.children.clear();
     if (d->kind == RPT_SHAPE_MESH) {
         if (d->n_tris == 0 || !d->tris) { why = "mesh without triangles"; return false; }
-        out.tris.assign(d->tris, d->tris + d->n_tris * 18);
+        out.mesh = intern_mesh(s, d->tris, d->n_tris, seen);
     }
     if (d->kind == RPT_SHAPE_GROUP) {
         if (d->n_children == 0 || !d->children) { why = "group without children"; return false; }
@@ -383,7 +414,7 @@ static bool copy_shape(const rpt_shape_desc* d, HShape& out, std::string& why, i
         out.children.resize(d->n_children);
         for (uint64_t i = 0; i < d->n_children; i++) {
             if (d->children[i].kind == RPT_SHAPE_PLANE) { why = "Plane is not Bounded and cannot be a KdTree child (src/kdtree.rs:12)"; return false; }
-            if (!copy_shape(d->children + i, out.children[i], why, depth + 1)) return false;
+            if (!copy_shape(s, seen, d->children + i, out.children[i], why, depth + 1)) return false;
         }
     }
     out.d.tris = nullptr;
@@ -430,6 +461,7 @@ int rpt_set_option(const char* name, int64_t value) {
     else if (s == "chunk_spp") { if (value < 0) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 0 (0 = auto)"); g_opt_chunk_spp = value; }
     else if (s == "blocks_per_cu") g_opt_blocks_per_cu = value;
     else if (s == "timing") g_opt_timing = value;
+    else if (s == "instancing") g_opt_instancing = value;
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); g_opt_scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option " + s);
     return RPT_OK;
@@ -459,7 +491,8 @@ int rpt_scene_add_object(rpt_scene* s, const rpt_shape_desc* d, const rpt_materi
     if (s->committed) return fail(RPT_ERR_STATE, "scene is immutable after rpt_scene_commit");
     std::string why;
     HObject o;
-    if (!copy_shape(d, o.shape, why) || !check_material(m, why)) return fail(RPT_ERR_INVALID, why);
+    MeshCallCache seen;
+    if (!copy_shape(s, seen, d, o.shape, why) || !check_material(m, why)) return fail(RPT_ERR_INVALID, why);
     o.mat = *m;
     s->objects.push_back(std::move(o));
     return int(s->objects.size()) - 1;
@@ -489,7 +522,8 @@ int rpt_scene_add_light_object(rpt_scene* s, const rpt_shape_desc* d, const rpt_
     std::string why;
     HLight l{};
     l.kind = L_OBJECT;
-    if (!copy_shape(d, l.obj.shape, why) || !check_material(m, why)) return fail(RPT_ERR_INVALID, why);
+    MeshCallCache seen;
+    if (!copy_shape(s, seen, d, l.obj.shape, why) || !check_material(m, why)) return fail(RPT_ERR_INVALID, why);
     if (d->kind == RPT_SHAPE_PLANE)
         return fail(RPT_ERR_INVALID, "a plane cannot be a Light::Object (Plane::sample is unimplemented in rpt)");
     if (d->kind == RPT_SHAPE_GROUP)
@@ -681,6 +715,70 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         }
         return b;
     };
+    std::vector<InstRec> insts;
+    std::vector<PBox> box_inst;
+    std::unordered_map<const std::vector<double>*, uint32_t> mesh_uses;
+    std::unordered_map<const std::vector<double>*, std::pair<MeshRef, PBox>> shared;
+    // Triangles of one mesh under `x` (identity for a shared mesh) + its two-box tree, appended to btri / nodes.
+    auto add_bvh_mesh = [&](const std::vector<double>& mt, const Xf& x, uint32_t obj, PBox& box) {
+        const uint64_t nt = mt.size() / 18;
+        std::vector<TriScan> ms;
+        std::vector<TriShade> mh;
+        ms.reserve(nt);
+        mh.reserve(nt);
+        std::vector<BTri> bt(nt);
+        for (uint64_t i = 0; i < nt; i++) {
+            const double* t = &mt[i * 18];
+            push_tri(t, x, obj, ms, mh);
+            PBox tb = tri_box(t, x);
+            for (int a = 0; a < 3; a++) {
+                bt[i].lo[a] = tb.lo[a];
+                bt[i].hi[a] = tb.hi[a];
+                bt[i].c[a] = 0.5f * (tb.lo[a] + tb.hi[a]);
+            }
+            bt[i].idx = uint32_t(i);
+        }
+        MeshRef mr;
+        mr.root = uint32_t(nodes.size());  // local node 0 is the root
+        mr.tri_base = uint32_t(btri.size());
+        mr.tri_count = uint32_t(nt);
+        mr.object = obj;
+        std::vector<TmpNode> tmp;
+        tmp.reserve(nt);
+        tmp.push_back(TmpNode{});
+        BvhBuilder b{bt, tmp};
+        b.build(0, 0, uint32_t(nt), 0);
+        // convert to two-box nodes: inner tmp node k -> wide node remap[k]
+        std::vector<uint32_t> remap(tmp.size(), 0);
+        uint32_t n_inner = 0;
+        for (size_t k = 0; k < tmp.size(); k++)
+            if (tmp[k].count == 0) remap[k] = n_inner++;
+        std::vector<BvhNode> local(n_inner);
+        auto entry = [&](uint32_t k) -> uint32_t {  // absolute node / triangle indices
+            const TmpNode& c = tmp[k];
+            if (c.count == 0) return mr.root + remap[k];
+            return BVH_LEAF | ((c.count - 1u) << 26) | (mr.tri_base + c.left_or_first);
+        };
+        for (size_t k = 0; k < tmp.size(); k++) {
+            if (tmp[k].count != 0) continue;
+            BvhNode& w = local[remap[k]];
+            uint32_t l = tmp[k].left_or_first;
+            for (int a = 0; a < 3; a++) {
+                w.lo0[a] = tmp[l].lo[a]; w.hi0[a] = tmp[l].hi[a];
+                w.lo1[a] = tmp[l + 1].lo[a]; w.hi1[a] = tmp[l + 1].hi[a];
+            }
+            w.e0 = entry(l);
+            w.e1 = entry(l + 1);
+            w.pad0 = w.pad1 = 0;
+        }
+        for (uint64_t i = 0; i < nt; i++) {
+            btri.push_back(ms[bt[i].idx]);
+            btri_sh.push_back(mh[bt[i].idx]);
+        }
+        nodes.insert(nodes.end(), local.begin(), local.end());
+        for (int a = 0; a < 3; a++) { box.lo[a] = tmp[0].lo[a]; box.hi[a] = tmp[0].hi[a]; }
+        return mr;
+    };
     std::function<void(const HShape&, const Xf&, uint32_t)> emit = [&](const HShape& shape, const Xf& x, uint32_t obj) {
         switch (shape.d.kind) {
             case RPT_SHAPE_GROUP: {  // KdTree<Box<dyn Bounded>>: children become primitives of this object
@@ -730,85 +828,68 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                 break;
             }
             default: {
-                uint64_t nt = shape.tris.size() / 18;
+                uint64_t nt = shape.T().size() / 18;
                 if (nt <= kLinearTriMax) {
                     for (uint64_t i = 0; i < nt; i++) {
                         RectScan rs;
                         RectShade rh;
                         int axis = -1;
-                        if (i + 1 < nt) axis = detect_rect(&shape.tris[i * 18], &shape.tris[(i + 1) * 18], x, obj, rs, rh);
+                        if (i + 1 < nt) axis = detect_rect(&shape.T()[i * 18], &shape.T()[(i + 1) * 18], x, obj, rs, rh);
                         if (axis >= 0) {
                             rect_axis[axis].push_back(rs);
                             rect_sh_axis[axis].push_back(rh);
                             i++;
                         } else {
-                            push_tri(&shape.tris[i * 18], x, obj, tri, tri_sh);
-                            box_tri.push_back(tri_box(&shape.tris[i * 18], x));
+                            push_tri(&shape.T()[i * 18], x, obj, tri, tri_sh);
+                            box_tri.push_back(tri_box(&shape.T()[i * 18], x));
                         }
                     }
+                } else if (g_opt_instancing && mesh_uses[shape.mesh.get()] >= 2) {
+                    // shared mesh: one local-space tree, one InstRec per use
+                    auto it = shared.find(shape.mesh.get());
+                    if (it == shared.end()) {
+                        Xf ident;
+                        rpt_shape_desc none{};
+                        make_xf(none, ident);
+                        PBox lb;
+                        MeshRef mr = add_bvh_mesh(shape.T(), ident, 0xFFFFFFFFu, lb);
+                        it = shared.emplace(shape.mesh.get(), std::make_pair(mr, lb)).first;
+                    }
+                    const PBox& lb = it->second.second;
+                    InstRec r;
+                    r.r0 = F4{float(x.Minv[0][0]), float(x.Minv[0][1]), float(x.Minv[0][2]), float(x.Minv[0][3])};
+                    r.r1 = F4{float(x.Minv[1][0]), float(x.Minv[1][1]), float(x.Minv[1][2]), float(x.Minv[1][3])};
+                    r.r2 = F4{float(x.Minv[2][0]), float(x.Minv[2][1]), float(x.Minv[2][2]), float(x.Minv[2][3])};
+                    r.n0 = F4{float(x.N[0][0]), float(x.N[0][1]), float(x.N[0][2]), bits_f(obj)};
+                    r.n1 = F4{float(x.N[1][0]), float(x.N[1][1]), float(x.N[1][2]), bits_f(it->second.first.root)};
+                    r.n2 = F4{float(x.N[2][0]), float(x.N[2][1]), float(x.N[2][2]), 0.f};
+                    PBox wb;
+                    for (int k = 0; k < 3; k++) { wb.lo[k] = std::numeric_limits<float>::infinity(); wb.hi[k] = -wb.lo[k]; }
+                    for (int c = 0; c < 8; c++) {  // the instance's box: the local box's corners under the affine map
+                        D3 q = x.point(D3{(c & 1) ? lb.hi[0] : lb.lo[0], (c & 2) ? lb.hi[1] : lb.lo[1], (c & 4) ? lb.hi[2] : lb.lo[2]});
+                        const double qq[3] = {q.x, q.y, q.z};
+                        for (int k = 0; k < 3; k++) {
+                            double pad = 1e-5 * (std::fabs(qq[k]) + 1e-30);
+                            wb.lo[k] = std::min(wb.lo[k], float(qq[k] - pad));
+                            wb.hi[k] = std::max(wb.hi[k], float(qq[k] + pad));
+                        }
+                    }
+                    insts.push_back(r);
+                    box_inst.push_back(wb);
                 } else {
-                    std::vector<TriScan> ms;
-                    std::vector<TriShade> mh;
-                    ms.reserve(nt);
-                    mh.reserve(nt);
-                    std::vector<BTri> bt(nt);
-                    for (uint64_t i = 0; i < nt; i++) {
-                        const double* t = &shape.tris[i * 18];
-                        push_tri(t, x, obj, ms, mh);
-                        PBox tb = tri_box(t, x);
-                        for (int a = 0; a < 3; a++) {
-                            bt[i].lo[a] = tb.lo[a];
-                            bt[i].hi[a] = tb.hi[a];
-                            bt[i].c[a] = 0.5f * (tb.lo[a] + tb.hi[a]);
-                        }
-                        bt[i].idx = uint32_t(i);
-                    }
-                    MeshRef mr;
-                    mr.root = uint32_t(nodes.size());  // local node 0 is the root
-                    mr.tri_base = uint32_t(btri.size());
-                    mr.tri_count = uint32_t(nt);
-                    mr.object = obj;
-                    std::vector<TmpNode> tmp;
-                    tmp.reserve(nt);
-                    tmp.push_back(TmpNode{});
-                    BvhBuilder b{bt, tmp};
-                    b.build(0, 0, uint32_t(nt), 0);
-                    // convert to two-box nodes: inner tmp node k -> wide node remap[k]
-                    std::vector<uint32_t> remap(tmp.size(), 0);
-                    uint32_t n_inner = 0;
-                    for (size_t k = 0; k < tmp.size(); k++)
-                        if (tmp[k].count == 0) remap[k] = n_inner++;
-                    std::vector<BvhNode> local(n_inner);
-                    auto entry = [&](uint32_t k) -> uint32_t {  // absolute node / triangle indices
-                        const TmpNode& c = tmp[k];
-                        if (c.count == 0) return mr.root + remap[k];
-                        return BVH_LEAF | ((c.count - 1u) << 26) | (mr.tri_base + c.left_or_first);
-                    };
-                    for (size_t k = 0; k < tmp.size(); k++) {
-                        if (tmp[k].count != 0) continue;
-                        BvhNode& w = local[remap[k]];
-                        uint32_t l = tmp[k].left_or_first;
-                        for (int a = 0; a < 3; a++) {
-                            w.lo0[a] = tmp[l].lo[a]; w.hi0[a] = tmp[l].hi[a];
-                            w.lo1[a] = tmp[l + 1].lo[a]; w.hi1[a] = tmp[l + 1].hi[a];
-                        }
-                        w.e0 = entry(l);
-                        w.e1 = entry(l + 1);
-                        w.pad0 = w.pad1 = 0;
-                    }
-                    for (uint64_t i = 0; i < nt; i++) {
-                        btri.push_back(ms[bt[i].idx]);
-                        btri_sh.push_back(mh[bt[i].idx]);
-                    }
-                    nodes.insert(nodes.end(), local.begin(), local.end());
-                    meshes.push_back(mr);
                     PBox mb;
-                    for (int a = 0; a < 3; a++) { mb.lo[a] = tmp[0].lo[a]; mb.hi[a] = tmp[0].hi[a]; }
+                    meshes.push_back(add_bvh_mesh(shape.T(), x, obj, mb));
                     box_mesh.push_back(mb);
                 }
             }
         }
     };
+    // meshes referenced by more than one shape (Arc<Mesh> in the reference) are instanced
+    std::function<void(const HShape&)> count_uses = [&](const HShape& shape) {
+        if (shape.d.kind == RPT_SHAPE_MESH && shape.T().size() / 18 > kLinearTriMax) mesh_uses[shape.mesh.get()]++;
+        for (const HShape& c : shape.children) count_uses(c);
+    };
+    for (const HObject& o : s->objects) count_uses(o.shape);
     for (size_t oi = 0; oi < s->objects.size(); oi++) {
         const HObject& o = s->objects[oi];
         Xf x;
@@ -854,10 +935,10 @@ int rpt_scene_commit(rpt_scene* s, int device) {
             if (o.shape.d.kind == RPT_SHAPE_MESH) {
                 L.shape = LS_MESH;
                 L.first = uint32_t(ltris.size());
-                uint64_t nt = o.shape.tris.size() / 18;
+                uint64_t nt = o.shape.T().size() / 18;
                 L.count = uint32_t(nt);
                 for (uint64_t i = 0; i < nt; i++) {
-                    const double* t = &o.shape.tris[i * 18];
+                    const double* t = &o.shape.T()[i * 18];
                     D3 a = d3(t), b = d3(t + 3), c = d3(t + 6);
                     D3 cr = cross(b - a, c - a);
                     double area = 0.5 * std::sqrt(dot(cr, cr));  // local-space area (src/shape/mesh.rs:93)
@@ -928,12 +1009,13 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                 }
         }
         for (size_t i = 0; i < tri.size(); i++) add_item(box_tri[i].lo, box_tri[i].hi, (K_TRI << 28) | uint32_t(i));
+        for (size_t i = 0; i < insts.size(); i++) add_item(box_inst[i].lo, box_inst[i].hi, (K_INST << 28) | uint32_t(i));
         std::vector<uint8_t> solo(items.size(), 0);
         for (size_t i = 0; i < meshes.size(); i++) {
             add_item(box_mesh[i].lo, box_mesh[i].hi, (K_BVHTRI << 28) | uint32_t(i));
             solo.push_back(1);
         }
-        if (items.size() >= size_t(std::max<int64_t>(2, g_opt_scene_bvh_min))) {
+        if (items.size() >= size_t(std::max<int64_t>(2, g_opt_scene_bvh_min)) || !insts.empty()) {  // instances live in the tree only
             scene_bvh = true;
             std::vector<TmpNode> tmp;
             tmp.reserve(2 * items.size());
@@ -974,6 +1056,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         }
     }
     size_t o_pleaf = reserve(pleaf.size() * sizeof(uint32_t));
+    size_t o_inst = reserve(insts.size() * sizeof(InstRec));
     size_t o_aabb = reserve(aabb.size() * sizeof(AabbScan));
     size_t o_rect = reserve(rect.size() * sizeof(RectScan)), o_rects = reserve(rect_sh.size() * sizeof(RectShade));
     size_t o_nodes = reserve(nodes.size() * sizeof(BvhNode));
@@ -992,6 +1075,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     put(o_tri, tri.data(), tri.size() * sizeof(TriScan));      put(o_tris, tri_sh.data(), tri_sh.size() * sizeof(TriShade));
     put(o_aabb, aabb.data(), aabb.size() * sizeof(AabbScan));
     put(o_pleaf, pleaf.data(), pleaf.size() * sizeof(uint32_t));
+    put(o_inst, insts.data(), insts.size() * sizeof(InstRec));
     put(o_rect, rect.data(), rect.size() * sizeof(RectScan));  put(o_rects, rect_sh.data(), rect_sh.size() * sizeof(RectShade));
     put(o_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
     put(o_btri, btri.data(), btri.size() * sizeof(TriScan));   put(o_btris, btri_sh.data(), btri_sh.size() * sizeof(TriShade));
@@ -1016,6 +1100,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     v.meshes = (const MeshRef*)(base + o_mesh); v.n_mesh = uint32_t(meshes.size());
     v.pleaf = (const uint32_t*)(base + o_pleaf); v.n_nodes = uint32_t(nodes.size());
     v.scene_bvh = scene_bvh ? 1u : 0u;          v.top_root = top_root;
+    v.inst = (const InstRec*)(base + o_inst);   v.n_inst = uint32_t(insts.size());
     v.mats = (const Material*)(base + o_mats);  v.n_obj = uint32_t(mats.size());
     v.lights = (const Light*)(base + o_lights); v.n_lights = uint32_t(lights.size());
     v.ltris = (const LightTri*)(base + o_ltris); v.lxf = (const LightXf*)(base + o_lxf);
@@ -1058,6 +1143,8 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     s->stats[9] = off;
     s->stats[10] = scene_bvh ? 1 : 0;
     s->stats[11] = pleaf.size();
+    s->stats[12] = insts.size();
+    s->stats[13] = shared.size();
 
     HIP_TRY(hipMalloc((void**)&s->d_queue, 256));
     HIP_TRY(hipMalloc((void**)&s->d_counters, 64 * sizeof(unsigned long long)));

@@ -11,8 +11,8 @@ import math
 
 import numpy as np
 
-from .api import (Camera, KdTree, Light, Material, Medium, Mesh, Object, Scene, cube, hex_color, plane, polygon, sphere,
-                  vec3)
+from .api import (Camera, KdTree, Light, Material, Medium, Mesh, Object, Scene, Transformed, cube, hex_color, plane,
+                  polygon, sphere, vec3)
 
 
 def spheres():
@@ -216,6 +216,24 @@ def fractal_spheres(levels=5):
     camera = Camera(eye=vec3(2.0, 3.5, 7.0), direction=cd / np.linalg.norm(cd), up=cu / np.linalg.norm(cu),
                     fov=math.pi / 6.0)
     return scene, camera, dict(width=800, height=600, spp=100, max_bounces=0, filter=0)
+
+
+def fractal_meshes(levels=5, nu=48, nv=24):
+    """examples/fractal_teapots.rs ("a kd-tree of kd-trees"): the layout of fractal_spheres with one
+    shared mesh (`Arc<Mesh>`) instead of each sphere.  The teapot OBJ is third-party art and does not
+    travel; a 2,304-triangle procedural torus (teapot.obj has 2,256 faces) stands in for it."""
+    scene, camera, cfg = fractal_spheres(levels)
+    mesh = Mesh(bumpy_torus(nu, nv, major=0.62, minor=0.3, bump=0.15))
+    out = Scene()
+    for o in scene.objects:
+        if isinstance(o.shape.base(), KdTree):
+            kids = [Transformed(mesh, k.matrix() @ np.diag([0.5, 0.5, 0.5, 1.0])) for k in o.shape.base().shapes]
+            out.add(Object(KdTree(kids)).material(o.material_))
+        else:
+            out.add(o)
+    for l in scene.lights:
+        out.add(l)
+    return out, camera, cfg
 
 
 CONFIGS = {

@@ -134,3 +134,68 @@ def test_group_errors_are_rejected_at_add():
     sc.add(Light.Object(Object(KdTree([sphere(), cube()])).material(Material.light(vec3(1, 1, 1), 5.0))))
     with pytest.raises(RptError):
         Renderer(sc, Camera()).width(8).height(8).sample_array(1)
+
+
+# ------------------------------------------------------------------ shared meshes (Arc<Mesh>) -> instancing
+@pytest.fixture
+def instancing_option():
+    yield lambda v: rpt_amd.set_option("instancing", v)
+    rpt_amd.set_option("instancing", 1)
+
+
+def test_shared_mesh_is_instanced_and_matches_oracle():
+    """examples/fractal_teapots.rs layout, 4 levels = 187 uses of one 2,304-triangle mesh: stored once
+    (one local-space tree + 187 instance records), closest hits equal the oracle's kd-tree of kd-trees."""
+    scene, cam, cfg = scenes.fractal_meshes(levels=4)
+    r = Renderer(scene, cam)
+    st = r.scene_stats()
+    assert st["instances"] == 187 and st["shared_meshes"] == 1 and st["bvh_tris"] == 2304 and st["scene_bvh"] == 1
+    o, d = random_rays(np.random.default_rng(6), 40000, np.zeros(3), 4.0)
+    t, obj, nrm = r.get_closest_hit(o, d)
+    te, obje, nrme = _oracle(scene).intersect(o.astype(np.float32), d.astype(np.float32), robust=1)
+    same = obj == obje
+    assert same.mean() > 0.999
+    hit = same & (obje >= 0)
+    assert sorted(set(obje[obje >= 0].tolist())) == [0, 1, 2, 3, 4]
+    rel = np.abs(t[hit] - te[hit]) / te[hit]
+    assert np.quantile(rel, 0.999) < 2e-4                    # silhouette edges may pick the neighbouring triangle
+    close = hit & (rel_or_inf(t, te) <= 2e-4)
+    assert np.quantile(np.abs(nrm[close] - nrme[close]).max(axis=1), 0.999) < 5e-3
+
+
+def rel_or_inf(t, te):
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r = np.abs(t - te) / te
+    return np.where(np.isfinite(r), r, np.inf)
+
+
+def test_instanced_render_matches_flattened_render_and_oracle(instancing_option):
+    scene, cam, cfg = scenes.fractal_meshes(levels=3)
+    w, h, spp = 128, 96, 16
+    imgs = {}
+    for inst in (1, 0):
+        instancing_option(inst)
+        scene, cam, cfg = scenes.fractal_meshes(levels=3)
+        r = Renderer(scene, cam).width(w).height(h).max_bounces(2).seed(12)
+        st = r.scene_stats()
+        assert st["instances"] == (37 if inst else 0) and st["bvh_tris"] == (2304 if inst else 37 * 2304)
+        imgs[inst] = r.sample_array(spp)
+    exp = _oracle(scene).render(cam, w, h, spp, 2, seed=12, robust=1)
+    assert exp.mean() > 0 and np.all(np.isfinite(imgs[1]))
+    assert rel_rms(imgs[1], exp) < 1e-2 and rel_rms(imgs[0], exp) < 1e-2
+    assert abs(imgs[1].mean() - exp.mean()) / exp.mean() < 3e-3
+    assert rel_rms(imgs[1], imgs[0]) < 1e-2                  # local-space vs world-space triangles: rounding only
+
+
+def test_full_fractal_of_937_mesh_instances_fits_and_renders():
+    """The whole example: 937 instances of one mesh = 2.16 M triangles if flattened, 2,304 when instanced."""
+    scene, cam, cfg = scenes.fractal_meshes()
+    r = Renderer(scene, cam).width(200).height(150).max_bounces(0).seed(2)
+    st = r.scene_stats()
+    assert st["instances"] == 937 and st["bvh_tris"] == 2304 and st["scene_bytes"] < 1 << 20
+    img = r.sample_array(4)
+    assert np.all(np.isfinite(img)) and img.mean() > 0
+    o, d = random_rays(np.random.default_rng(7), 20000, np.zeros(3), 4.0)
+    t, obj, nrm = r.get_closest_hit(o, d)
+    assert sorted(set(obj[obj >= 0].tolist())) == [0, 1, 2, 3, 4, 5]
+    assert np.allclose(np.linalg.norm(nrm[obj >= 0], axis=1), 1.0, atol=1e-4)

@@ -1,5 +1,7 @@
-"""Times examples/fractal_spheres.rs's workload (937 spheres in 5 KdTree groups, 800x600) with the
-scene-level BVH and with the linear scan forced.  Usage: python tools/fractal_bench.py [spp]"""
+"""Times the two "kd-tree of shapes" examples at their own size (800x600):
+  spheres: examples/fractal_spheres.rs (937 spheres in 5 groups), scene BVH vs forced linear scan
+  meshes : examples/fractal_teapots.rs layout (937 uses of one 2,304-triangle mesh), instanced vs flattened
+Usage: python tools/fractal_bench.py [spp]"""
 import json
 import sys
 import time
@@ -10,16 +12,22 @@ from rpt_amd import Renderer, scenes  # noqa: E402
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 out = {}
-for mode, thresh in (("scene_bvh", 64), ("linear", 1 << 30)):
+cases = [("spheres/scene_bvh", scenes.fractal_spheres, 64, 1), ("spheres/linear", scenes.fractal_spheres, 1 << 30, 1),
+         ("meshes/instanced", scenes.fractal_meshes, 64, 1), ("meshes/flattened", scenes.fractal_meshes, 64, 0)]
+for name, make, thresh, inst in cases:
     rpt_amd.set_option("scene_bvh_min", thresh)
+    rpt_amd.set_option("instancing", inst)
     rpt_amd.set_option("timing", 1)
-    scene, cam, cfg = scenes.fractal_spheres()
+    scene, cam, cfg = make()
     r = Renderer(scene, cam).width(cfg["width"]).height(cfg["height"]).max_bounces(cfg["max_bounces"]).seed(1)
+    t0 = time.time()
     r.sample_array(2)
+    first = time.time() - t0
     t0 = time.time()
     img = r.sample_array(spp)
     wall = time.time() - t0
-    ms = r.timing()
-    out[mode] = dict(wall_s=wall, kernel_ms=ms, msamples_per_s=cfg["width"] * cfg["height"] * spp / wall / 1e6,
-                     mean=float(img.mean()), stats=r.scene_stats())
+    st = r.scene_stats()
+    out[name] = dict(commit_plus_first_s=round(first, 3), wall_s=round(wall, 4), kernel_ms=round(r.timing()[0], 3),
+                     msamples_per_s=round(cfg["width"] * cfg["height"] * spp / wall / 1e6, 1), mean=float(img.mean()),
+                     scene_bytes=st["scene_bytes"], bvh_tris=st["bvh_tris"], instances=st["instances"])
 print(json.dumps(out, indent=1))
