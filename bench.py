@@ -115,6 +115,7 @@ def main():
     import numpy as np
     import rpt_amd
     from rpt_amd import Renderer, scenes
+    from rpt_amd.dist import photon_map_build_sharded
 
     scene, cam, cfg = scenes.CONFIGS[args.workload]()
     width = args.width or cfg["width"]
@@ -137,7 +138,10 @@ def main():
     def step(record=False):
         r._sample_offset = 0
         if photon:
-            r.photon_map_build(n_photons, Renderer.PHOTON_POINT_BEAM)
+            if dist is not None:   # shooting sharded by photon index, records all-gathered over RCCL
+                photon_map_build_sharded(r, n_photons, Renderer.PHOTON_POINT_BEAM, rank, world)
+            else:
+                r.photon_map_build(n_photons, Renderer.PHOTON_POINT_BEAM)
             r.photon_sample_device(spp, d_out.data_ptr(), stream)
         else:
             r.sample_device(spp, d_out.data_ptr(), stream)

@@ -168,6 +168,21 @@ enum { RPT_PHOTON_MAP = 0, RPT_PHOTON_POINT_BEAM = 1, RPT_PHOTON_BEAM_BEAM = 2 }
  * stored in the scene handle and replaced by the next build.  Photon i draws from the RNG stream
  * (seed, i, 0x80000000 + (i >> 32)). */
 int rpt_photon_map_build(rpt_scene*, uint64_t photon_count, int32_t kind, double watts, uint64_t seed);
+/* The same map built by several GPUs (one process each): the "Shooting photons" loop
+ * (src/photon.rs:656-690) is sharded by photon index, the map is needed whole on every GPU.
+ *   1. rpt_photon_shoot: shoot photons [rank*N/count, (rank+1)*N/count) of the N-photon map and keep
+ *      their records on the device; n_out = {surface, volume} record counts of this shard.
+ *   2. rpt_photon_records: device pointer + count of those records (RPT_PHOTON_RECORD_BYTES each,
+ *      shooting order); the caller all-gathers them in rank order (RCCL), which reproduces the
+ *      single-GPU arrays exactly because the blocks are contiguous.
+ *   3. rpt_photon_map_from_records: build the maps of rpt_photon_map_build from device arrays
+ *      (the gathered ones; they are read, not kept).  Invalidates the pointers of step 2. */
+#define RPT_PHOTON_RECORD_BYTES 48
+int rpt_photon_shoot(rpt_scene*, uint64_t photon_count, int32_t kind, double watts, uint64_t seed,
+                     uint32_t shard_rank, uint32_t shard_count, uint64_t n_out[2]);
+int rpt_photon_records(rpt_scene*, int32_t which /* 0 surface, 1 volume */, void** d_records, uint64_t* n);
+int rpt_photon_map_from_records(rpt_scene*, uint64_t photon_count, int32_t kind, const void* d_surface,
+                                uint64_t n_surface, const void* d_volume, uint64_t n_volume);
 /* [0] surface photons, [1] volume photons, [2] photons shot, [3] shooting us, [4] map build us. */
 int rpt_photon_map_stats(rpt_scene*, uint64_t out[8]);
 /* Test hook: which = 0 surface / 1 volume; out = n * 10 floats in shooting order:

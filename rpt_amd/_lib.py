@@ -94,6 +94,10 @@ SYMBOLS = [
     ("rpt_get_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("rpt_set_option", C.c_int, [C.c_char_p, C.c_int64]),
     ("rpt_photon_map_build", C.c_int, [_P, C.c_uint64, C.c_int32, C.c_double, C.c_uint64]),
+    ("rpt_photon_shoot", C.c_int,
+     [_P, C.c_uint64, C.c_int32, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("rpt_photon_records", C.c_int, [_P, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("rpt_photon_map_from_records", C.c_int, [_P, C.c_uint64, C.c_int32, _P, C.c_uint64, _P, C.c_uint64]),
     ("rpt_photon_map_stats", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("rpt_photon_map_download", C.c_int, [_P, C.c_int32, _P, C.c_uint64]),
     ("rpt_photon_render_sample", C.c_int,

@@ -737,6 +737,34 @@ class Renderer:
         return {"surface": int(out[0]), "volume": int(out[1]), "shot": int(out[2]), "shoot_us": int(out[3]),
                 "build_us": int(out[4])}
 
+    def _photon_stats(self):
+        out = (C.c_uint64 * 8)()
+        _lib.check(_lib.load().rpt_photon_map_stats(self.scene._handle, out))
+        return {"surface": int(out[0]), "volume": int(out[1]), "shot": int(out[2]), "shoot_us": int(out[3]),
+                "build_us": int(out[4])}
+
+    def photon_shoot(self, photon_count, kind, shard_rank=0, shard_count=1):
+        """rpt_photon_shoot: this rank's contiguous block of the shooting loop (photon.rs:656-690);
+        returns (surface, volume) record counts.  The records stay on the device (photon_records)."""
+        n = (C.c_uint64 * 2)()
+        h = self.scene._commit(self.device_)
+        _lib.check(_lib.load().rpt_photon_shoot(h, int(photon_count), int(kind), self.watts_, C.c_uint64(self.seed_),
+                                                int(shard_rank), int(shard_count), n))
+        return int(n[0]), int(n[1])
+
+    def photon_records(self, which):
+        """(device pointer, count) of the records of the last photon_shoot; 48 bytes each."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        _lib.check(_lib.load().rpt_photon_records(self.scene._handle, int(which), C.byref(ptr), C.byref(n)))
+        return int(ptr.value or 0), int(n.value)
+
+    def photon_map_from_records(self, photon_count, kind, d_surface, n_surface, d_volume, n_volume):
+        """rpt_photon_map_from_records: build the maps from (gathered) device record arrays."""
+        h = self.scene._commit(self.device_)
+        _lib.check(_lib.load().rpt_photon_map_from_records(h, int(photon_count), int(kind), C.c_void_p(d_surface),
+                                                           int(n_surface), C.c_void_p(d_volume), int(n_volume)))
+        return self._photon_stats()
+
     def photon_map_download(self, which):
         """Test hook: (n, 10) float32 photons in shooting order (position, direction, power, radius)."""
         lib = _lib.load()

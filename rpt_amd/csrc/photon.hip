@@ -31,8 +31,9 @@ RPT_DEV float ray_tmin_p(V o) { return 2e-5f * (1.f + max3(fabsf(o.x), fabsf(o.y
 
 struct ShootArgs {
     SceneView sc;
-    uint64_t n_photons, seed_mixed;
-    float power;  // watts / photon_count
+    uint64_t n_photons, seed_mixed;  // photons of THIS launch
+    uint64_t first_photon;           // global index of its first photon (the RNG stream key)
+    float power;  // watts / photon_count (of the whole map)
     uint32_t light_index;
     uint32_t kind;  // RPT_PHOTON_*: beam-beam thins the volume photons and records each beam's start
     uint32_t* cnt_s;
@@ -55,8 +56,9 @@ __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
     const Light L = uload(&sc.lights[a.light_index]);
     for (uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x; i < a.n_photons; i += uint64_t(gridDim.x) * 256u) {
         Rng rng, thin;
-        rng.seed(a.seed_mixed, uint32_t(i), 0x80000000u + uint32_t(i >> 32));
-        thin.seed(a.seed_mixed, uint32_t(i), 0xC0000000u + uint32_t(i >> 32));  // thinning side stream
+        const uint64_t g = a.first_photon + i;
+        rng.seed(a.seed_mixed, uint32_t(g), 0x80000000u + uint32_t(g >> 32));
+        thin.seed(a.seed_mixed, uint32_t(g), 0xC0000000u + uint32_t(g >> 32));  // thinning side stream
         const bool beams = a.kind == RPT_PHOTON_BEAM_BEAM;
         V ro, n0;
         float p0;
@@ -852,16 +854,27 @@ struct PhotonMapDev {
     int kind = RPT_PHOTON_POINT_BEAM;
     uint64_t photon_count = 0;
     DevLbvh surf, vol;
+    bool built = false;
+    // records of the last shooting pass in shooting order (kept for rpt_photon_records / all-gather)
+    PhotonRec *raw_s = nullptr, *raw_v = nullptr;
+    uint64_t n_raw_s = 0, n_raw_v = 0;
     double build_ms[4] = {0, 0, 0, 0};  // shoot, sort+build, radii, total
     uint32_t* d_overflow = nullptr;
+    void release_raw() {
+        (void)hipFree(raw_s); (void)hipFree(raw_v);
+        raw_s = raw_v = nullptr;
+        n_raw_s = n_raw_v = 0;
+    }
     void release() {
         (void)hipSetDevice(device);
         (void)hipFree(surf.nodes); (void)hipFree(surf.sorted);
         (void)hipFree(vol.nodes); (void)hipFree(vol.sorted);
         (void)hipFree(d_overflow);
+        release_raw();
         d_overflow = nullptr;
         surf = DevLbvh{};
         vol = DevLbvh{};
+        built = false;
     }
 };
 struct Tmp {
@@ -962,7 +975,91 @@ void rpti::photon_release(void* p) {
 
 extern "C" {
 
-int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, double watts, uint64_t seed) {
+// Shooting pass for photons [first, first + n) of a map of `photon_count` photons: count, prefix, write.
+// Leaves the records in pm->raw_s / raw_v in shooting order.
+static int shoot_range(rpt_scene* s, PhotonMapDev* pm, uint64_t photon_count, uint64_t first, uint64_t n, int32_t kind,
+                       double watts, uint64_t seed) {
+    rpti::SceneDev sd = rpti::scene_dev(s);
+    hipStream_t st = nullptr;
+    hipEvent_t e0, e1;
+    RPTI_HIP_TRY(hipEventCreate(&e0));
+    RPTI_HIP_TRY(hipEventCreate(&e1));
+    Tmp tmp;
+    ShootArgs a{};
+    a.sc = sd.view;
+    a.n_photons = n;
+    a.first_photon = first;
+    a.seed_mixed = rpti::seed_mix(seed);
+    a.power = float(watts / double(photon_count));
+    a.light_index = uint32_t(sd.first_object_light);
+    a.kind = uint32_t(kind);
+    pm->release_raw();
+    if (n == 0) return RPT_OK;
+    RPTI_HIP_TRY(tmp.alloc(&a.cnt_s, n));
+    RPTI_HIP_TRY(tmp.alloc(&a.cnt_v, n));
+    const bool medium = sd.view.has_medium != 0, bvh = sd.view.n_nodes != 0;
+    int blocks = int(std::min<uint64_t>((n + 255) / 256, uint64_t(sd.n_cus) * 8));
+    RPTI_HIP_TRY(hipEventRecord(e0, st));
+    RPTI_HIP_TRY(launch_shoot<false>(a, medium, bvh, blocks, st));
+    std::vector<uint32_t> cs(n), cv(n);
+    RPTI_HIP_TRY(hipMemcpy(cs.data(), a.cnt_s, n * 4, hipMemcpyDeviceToHost));
+    RPTI_HIP_TRY(hipMemcpy(cv.data(), a.cnt_v, n * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> os(n), ov(n);
+    uint64_t ts = 0, tv = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        os[i] = ts; ts += cs[i];
+        ov[i] = tv; tv += cv[i];
+    }
+    if (ts >= (1ull << 31) || tv >= (1ull << 31)) return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons");
+    uint64_t *d_os, *d_ov;
+    RPTI_HIP_TRY(tmp.alloc(&d_os, n));
+    RPTI_HIP_TRY(tmp.alloc(&d_ov, n));
+    RPTI_HIP_TRY(hipMalloc((void**)&pm->raw_s, std::max<size_t>(ts * sizeof(PhotonRec), 64)));
+    RPTI_HIP_TRY(hipMalloc((void**)&pm->raw_v, std::max<size_t>(tv * sizeof(PhotonRec), 64)));
+    pm->n_raw_s = ts;
+    pm->n_raw_v = tv;
+    RPTI_HIP_TRY(hipMemcpy(d_os, os.data(), n * 8, hipMemcpyHostToDevice));
+    RPTI_HIP_TRY(hipMemcpy(d_ov, ov.data(), n * 8, hipMemcpyHostToDevice));
+    a.off_s = d_os;
+    a.off_v = d_ov;
+    a.surf = pm->raw_s;
+    a.vol = pm->raw_v;
+    RPTI_HIP_TRY(launch_shoot<true>(a, medium, bvh, blocks, st));
+    RPTI_HIP_TRY(hipEventRecord(e1, st));
+    RPTI_HIP_TRY(hipEventSynchronize(e1));
+    float m0 = 0;
+    (void)hipEventElapsedTime(&m0, e0, e1);
+    pm->build_ms[0] = m0;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return RPT_OK;
+}
+
+// Sort + LBVH (+ radii) over record arrays that live on this scene's device.
+static int build_maps(PhotonMapDev* pm, const PhotonRec* d_s, uint64_t n_s, const PhotonRec* d_v, uint64_t n_v) {
+    if (n_s >= (1ull << 31) || n_v >= (1ull << 31)) return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons");
+    hipStream_t st = nullptr;
+    hipEvent_t e1, e2;
+    RPTI_HIP_TRY(hipEventCreate(&e1));
+    RPTI_HIP_TRY(hipEventCreate(&e2));
+    RPTI_HIP_TRY(hipEventRecord(e1, st));
+    const int kind = pm->kind;
+    int rc = build_lbvh(const_cast<PhotonRec*>(d_s), uint32_t(n_s), 0, pm->surf, st);
+    if (rc == RPT_OK)
+        rc = build_lbvh(const_cast<PhotonRec*>(d_v), uint32_t(n_v),
+                        kind == RPT_PHOTON_POINT_BEAM ? 1 : (kind == RPT_PHOTON_BEAM_BEAM ? 2 : 0), pm->vol, st);
+    if (rc != RPT_OK) return rc;
+    RPTI_HIP_TRY(hipEventRecord(e2, st));
+    RPTI_HIP_TRY(hipEventSynchronize(e2));
+    float m1 = 0;
+    (void)hipEventElapsedTime(&m1, e1, e2);
+    pm->build_ms[1] = m1;
+    pm->build_ms[3] = pm->build_ms[0] + m1;
+    (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    pm->built = true;
+    return RPT_OK;
+}
+
+static int photon_args_ok(rpt_scene* s, uint64_t photon_count, int32_t kind) {
     if (!s) return rpti::fail(RPT_ERR_INVALID, "null scene");
     rpti::SceneDev sd = rpti::scene_dev(s);
     if (!sd.committed) return rpti::fail(RPT_ERR_STATE, "rpt_scene_commit must be called first");
@@ -972,83 +1069,83 @@ int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, doub
     if (sd.first_object_light < 0)
         return rpti::fail(RPT_ERR_INVALID, "Only found non-object lights while photon mapping");  // the reference's panic
     RPTI_HIP_TRY(hipSetDevice(sd.device));
+    return RPT_OK;
+}
+static PhotonMapDev* fresh_map(rpt_scene* s, uint64_t photon_count, int32_t kind) {
     void*& slot = rpti::photon_slot(s);
     if (slot) {
         rpti::photon_release(slot);
         slot = nullptr;
     }
     auto* pm = new PhotonMapDev();
-    pm->device = sd.device;
+    pm->device = rpti::scene_dev(s).device;
     pm->kind = kind;
     pm->photon_count = photon_count;
-    hipStream_t st = nullptr;
-    hipEvent_t e0, e1, e2;
-    RPTI_HIP_TRY(hipEventCreate(&e0));
-    RPTI_HIP_TRY(hipEventCreate(&e1));
-    RPTI_HIP_TRY(hipEventCreate(&e2));
-    Tmp tmp;
-    ShootArgs a{};
-    a.sc = sd.view;
-    a.n_photons = photon_count;
-    a.seed_mixed = rpti::seed_mix(seed);
-    a.power = float(watts / double(photon_count));
-    a.light_index = uint32_t(sd.first_object_light);
-    a.kind = uint32_t(kind);
-    RPTI_HIP_TRY(tmp.alloc(&a.cnt_s, photon_count));
-    RPTI_HIP_TRY(tmp.alloc(&a.cnt_v, photon_count));
-    const bool medium = sd.view.has_medium != 0, bvh = sd.view.n_nodes != 0;
-    int blocks = int(std::min<uint64_t>((photon_count + 255) / 256, uint64_t(sd.n_cus) * 8));
-    RPTI_HIP_TRY(hipEventRecord(e0, st));
-    RPTI_HIP_TRY(launch_shoot<false>(a, medium, bvh, blocks, st));
-    std::vector<uint32_t> cs(photon_count), cv(photon_count);
-    RPTI_HIP_TRY(hipMemcpy(cs.data(), a.cnt_s, photon_count * 4, hipMemcpyDeviceToHost));
-    RPTI_HIP_TRY(hipMemcpy(cv.data(), a.cnt_v, photon_count * 4, hipMemcpyDeviceToHost));
-    std::vector<uint64_t> os(photon_count), ov(photon_count);
-    uint64_t ts = 0, tv = 0;
-    for (uint64_t i = 0; i < photon_count; i++) {
-        os[i] = ts; ts += cs[i];
-        ov[i] = tv; tv += cv[i];
-    }
-    if (ts >= (1ull << 31) || tv >= (1ull << 31)) { delete pm; return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons"); }
-    uint64_t *d_os, *d_ov;
-    PhotonRec *raw_s, *raw_v;
-    RPTI_HIP_TRY(tmp.alloc(&d_os, photon_count));
-    RPTI_HIP_TRY(tmp.alloc(&d_ov, photon_count));
-    RPTI_HIP_TRY(tmp.alloc(&raw_s, ts));
-    RPTI_HIP_TRY(tmp.alloc(&raw_v, tv));
-    RPTI_HIP_TRY(hipMemcpy(d_os, os.data(), photon_count * 8, hipMemcpyHostToDevice));
-    RPTI_HIP_TRY(hipMemcpy(d_ov, ov.data(), photon_count * 8, hipMemcpyHostToDevice));
-    a.off_s = d_os;
-    a.off_v = d_ov;
-    a.surf = raw_s;
-    a.vol = raw_v;
-    RPTI_HIP_TRY(launch_shoot<true>(a, medium, bvh, blocks, st));
-    RPTI_HIP_TRY(hipEventRecord(e1, st));
-    int rc = build_lbvh(raw_s, uint32_t(ts), 0, pm->surf, st);
-    if (rc == RPT_OK)
-        rc = build_lbvh(raw_v, uint32_t(tv), kind == RPT_PHOTON_POINT_BEAM ? 1 : (kind == RPT_PHOTON_BEAM_BEAM ? 2 : 0), pm->vol, st);
-    if (rc != RPT_OK) {
-        pm->release();
-        delete pm;
-        return rc;
-    }
-    RPTI_HIP_TRY(hipEventRecord(e2, st));
-    RPTI_HIP_TRY(hipEventSynchronize(e2));
-    float m0 = 0, m1 = 0;
-    (void)hipEventElapsedTime(&m0, e0, e1);
-    (void)hipEventElapsedTime(&m1, e1, e2);
-    pm->build_ms[0] = m0;
-    pm->build_ms[1] = m1;
-    pm->build_ms[3] = m0 + m1;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     slot = pm;
+    return pm;
+}
+static void drop_map(rpt_scene* s) {
+    void*& slot = rpti::photon_slot(s);
+    rpti::photon_release(slot);
+    slot = nullptr;
+}
+
+int rpt_photon_map_build(rpt_scene* s, uint64_t photon_count, int32_t kind, double watts, uint64_t seed) {
+    int rc = photon_args_ok(s, photon_count, kind);
+    if (rc) return rc;
+    PhotonMapDev* pm = fresh_map(s, photon_count, kind);
+    rc = shoot_range(s, pm, photon_count, 0, photon_count, kind, watts, seed);
+    if (rc == RPT_OK) rc = build_maps(pm, pm->raw_s, pm->n_raw_s, pm->raw_v, pm->n_raw_v);
+    if (rc != RPT_OK) { drop_map(s); return rc; }
+    pm->release_raw();
+    return RPT_OK;
+}
+
+int rpt_photon_shoot(rpt_scene* s, uint64_t photon_count, int32_t kind, double watts, uint64_t seed, uint32_t shard_rank,
+                     uint32_t shard_count, uint64_t n_out[2]) {
+    int rc = photon_args_ok(s, photon_count, kind);
+    if (rc) return rc;
+    if (shard_count == 0) shard_count = 1;
+    if (shard_rank >= shard_count) return rpti::fail(RPT_ERR_INVALID, "shard_rank must be < shard_count");
+    // contiguous blocks, so that the shards concatenated in rank order ARE the single-GPU record arrays
+    const uint64_t first = photon_count * shard_rank / shard_count, last = photon_count * (uint64_t(shard_rank) + 1) / shard_count;
+    PhotonMapDev* pm = fresh_map(s, photon_count, kind);
+    rc = shoot_range(s, pm, photon_count, first, last - first, kind, watts, seed);
+    if (rc != RPT_OK) { drop_map(s); return rc; }
+    if (n_out) { n_out[0] = pm->n_raw_s; n_out[1] = pm->n_raw_v; }
+    return RPT_OK;
+}
+
+int rpt_photon_records(rpt_scene* s, int32_t which, void** d_records, uint64_t* n) {
+    if (!s || !d_records || !n) return rpti::fail(RPT_ERR_INVALID, "null argument");
+    auto* pm = static_cast<PhotonMapDev*>(rpti::photon_slot(s));
+    if (!pm || pm->built) return rpti::fail(RPT_ERR_STATE, "no shot photons: call rpt_photon_shoot first");
+    *d_records = which == 0 ? pm->raw_s : pm->raw_v;
+    *n = which == 0 ? pm->n_raw_s : pm->n_raw_v;
+    return RPT_OK;
+}
+
+int rpt_photon_map_from_records(rpt_scene* s, uint64_t photon_count, int32_t kind, const void* d_surface, uint64_t n_surface,
+                                const void* d_volume, uint64_t n_volume) {
+    int rc = photon_args_ok(s, photon_count, kind);
+    if (rc) return rc;
+    if ((n_surface && !d_surface) || (n_volume && !d_volume)) return rpti::fail(RPT_ERR_INVALID, "null record array");
+    auto* old = static_cast<PhotonMapDev*>(rpti::photon_slot(s));
+    // the arrays may be this scene's own shot records: keep them alive until the maps are built
+    PhotonMapDev keep;
+    if (old) { keep.raw_s = old->raw_s; keep.raw_v = old->raw_v; keep.build_ms[0] = old->build_ms[0]; old->raw_s = old->raw_v = nullptr; }
+    PhotonMapDev* pm = fresh_map(s, photon_count, kind);
+    pm->build_ms[0] = keep.build_ms[0];
+    rc = build_maps(pm, static_cast<const PhotonRec*>(d_surface), n_surface, static_cast<const PhotonRec*>(d_volume), n_volume);
+    (void)hipFree(keep.raw_s); (void)hipFree(keep.raw_v);
+    if (rc != RPT_OK) { drop_map(s); return rc; }
     return RPT_OK;
 }
 
 int rpt_photon_map_stats(rpt_scene* s, uint64_t out[8]) {
     if (!s || !out) return rpti::fail(RPT_ERR_INVALID, "null argument");
     auto* pm = static_cast<PhotonMapDev*>(rpti::photon_slot(s));
-    if (!pm) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
+    if (!pm || !pm->built) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
     out[0] = pm->surf.n;
     out[1] = pm->vol.n;
     out[2] = pm->photon_count;
@@ -1063,7 +1160,7 @@ int rpt_photon_map_stats(rpt_scene* s, uint64_t out[8]) {
 int rpt_photon_map_download(rpt_scene* s, int32_t which, float* out, uint64_t capacity) {
     if (!s || !out) return rpti::fail(RPT_ERR_INVALID, "null argument");
     auto* pm = static_cast<PhotonMapDev*>(rpti::photon_slot(s));
-    if (!pm) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
+    if (!pm || !pm->built) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
     const DevLbvh& l = which == 0 ? pm->surf : pm->vol;
     if (capacity < l.n) return rpti::fail(RPT_ERR_INVALID, "output buffer too small");
     std::vector<PhotonRec> h(l.n);
@@ -1084,7 +1181,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
                               uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed, uint32_t sample_offset,
                               double* d_out, hipStream_t st, bool sync_counters) {
     auto* pm = s ? static_cast<PhotonMapDev*>(rpti::photon_slot(s)) : nullptr;
-    if (!pm) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
+    if (!pm || !pm->built) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
     if (std::max(gather_size, gather_size_volume) > 56)
         return rpti::fail(RPT_ERR_UNSUPPORTED, "gather sizes > 56 do not fit the LDS gather list");
     const uint64_t gather_lds = pm->kind == RPT_PHOTON_MAP ? std::max(gather_size, gather_size_volume) : gather_size;

@@ -1,0 +1,77 @@
+"""One-process-per-GPU plumbing over torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the
+CPU tests).  The path has exactly two exchange steps:
+
+  * frames: every rank renders its 32x32 tile shard into a zero-initialised full frame and the frames
+    are sum-reduced to rank 0 (`reduce_frame`);
+  * photon maps: the shooting loop (src/photon.rs:656-690) is sharded by photon index, every rank
+    needs the whole map, so the shot records are all-gathered in rank order (`gather_records`,
+    `photon_map_build_sharded`).
+
+torch is imported lazily so that `import rpt_amd` stays numpy-only."""
+
+RECORD_BYTES = 48  # RPT_PHOTON_RECORD_BYTES
+
+
+def reduce_frame(frame, group=None):
+    """Sum the per-rank frames onto rank 0 (non-owned pixels are exact zeros, so the sum is the frame)."""
+    import torch.distributed as dist
+    dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, group=group)
+    return frame
+
+
+def gather_records(local, group=None):
+    """All-gather variable-length record arrays in rank order.
+
+    local: (n, RECORD_BYTES) uint8 tensor on this rank's device.  Returns the (sum n, RECORD_BYTES)
+    concatenation, identical on every rank.  Shards are contiguous photon blocks, so this IS the array a
+    single GPU would have produced."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if local.dim() != 2 or local.shape[1] != RECORD_BYTES or local.dtype != torch.uint8:
+        raise ValueError("records must be an (n, 48) uint8 tensor")
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    if world == 1:
+        return local
+    cap = max(max(counts), 1)
+    padded = torch.zeros((cap, RECORD_BYTES), dtype=torch.uint8, device=local.device)
+    padded[:local.shape[0]] = local
+    parts = [torch.empty((cap, RECORD_BYTES), dtype=torch.uint8, device=local.device) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([parts[r][:counts[r]] for r in range(world)], dim=0).contiguous()
+
+
+class _DevicePtr:
+    """Minimal __cuda_array_interface__ carrier so torch can view library-owned device memory."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _view(ptr, n, device):
+    import torch
+    if n == 0:
+        return torch.empty((0, RECORD_BYTES), dtype=torch.uint8, device=device)
+    return torch.as_tensor(_DevicePtr(ptr, n * RECORD_BYTES), device=device).view(n, RECORD_BYTES)
+
+
+def photon_map_build_sharded(renderer, photon_count, kind, rank, world, group=None):
+    """Renderer.photon_map_build across `world` ranks: each rank shoots its block of photons
+    (rpt_photon_shoot), the records are all-gathered over RCCL and every rank builds the full map
+    (rpt_photon_map_from_records).  Returns the stats dict of photon_map_build."""
+    import torch
+    device = torch.device("cuda", renderer.device_)
+    renderer.photon_shoot(photon_count, kind, rank, world)
+    gathered = []
+    for which in (0, 1):
+        ptr, n = renderer.photon_records(which)
+        gathered.append(gather_records(_view(ptr, n, device), group))
+    torch.cuda.current_stream(device).synchronize()   # the library builds on the null stream
+    return renderer.photon_map_from_records(photon_count, kind, gathered[0].data_ptr(), gathered[0].shape[0],
+                                            gathered[1].data_ptr(), gathered[1].shape[0])
+
+
+__all__ = ["RECORD_BYTES", "reduce_frame", "gather_records", "photon_map_build_sharded"]

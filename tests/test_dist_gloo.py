@@ -53,3 +53,31 @@ def test_two_rank_tile_shards_sum_to_the_full_frame(tmp_path):
     full = OracleScene(scene).render(cam, w, h, spp, cfg["max_bounces"], seed=5, threads=2)
     assert np.array_equal(got, full)                        # bit-identical: RNG is keyed by (seed, pixel, sample)
     assert full.max() > 0
+
+
+def _gather_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from rpt_amd.dist import RECORD_BYTES, gather_records
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    for case, counts in enumerate([(5, 3), (0, 4), (7, 0), (0, 0)]):          # ragged and empty shards
+        g = torch.Generator().manual_seed(100 * case + rank)
+        local = torch.randint(0, 256, (counts[rank], RECORD_BYTES), dtype=torch.uint8, generator=g)
+        got = gather_records(local)
+        torch.save((local, got), os.path.join(out_dir, f"c{case}_r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_photon_records_all_gather_in_rank_order(tmp_path):
+    """The photon-map exchange step (rpt_amd.dist.gather_records): variable-length shards are
+    concatenated in rank order on every rank, i.e. the single-GPU record array."""
+    import torch
+    import torch.multiprocessing as mp
+    mp.spawn(_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for case in range(4):
+        l0, g0 = torch.load(tmp_path / f"c{case}_r0.pt")
+        l1, g1 = torch.load(tmp_path / f"c{case}_r1.pt")
+        assert torch.equal(g0, g1) and torch.equal(g0, torch.cat([l0, l1], dim=0))

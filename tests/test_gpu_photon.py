@@ -154,3 +154,38 @@ def test_photon_mapping_errors():
         r2.photon_sample_array(1)                              # no map built yet
     with pytest.raises(RptError):
         r2.photon_map_build(100, 7)                            # unknown PhotonRenderKind
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_sharded_shooting_gathers_to_the_single_gpu_map_bit_for_bit(kind):
+    """SURVEY 8e, photon maps: three ranks' contiguous photon blocks (rpt_photon_shoot), concatenated in
+    rank order the way rpt_amd.dist.gather_records does, rebuilt with rpt_photon_map_from_records:
+    identical photons, radii and camera pass as rpt_photon_map_build on one GPU."""
+    import torch
+    from rpt_amd.dist import RECORD_BYTES, _view
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    n, shards = 6001, 3                                     # not divisible: ragged blocks
+    r = Renderer(scene, cam).width(64).height(64).watts(14.65 * n).seed(11).gather_size(20).gather_size_volume(3)
+    st = r.photon_map_build(n, kind)
+    ref = [r.photon_map_download(0), r.photon_map_download(1)]
+    img_ref = r.photon_sample_array(2)
+    dev = torch.device("cuda", 0)
+    parts = [[], []]
+    for rank in range(shards):
+        ns, nv = r.photon_shoot(n, kind, rank, shards)
+        for which in (0, 1):
+            ptr, cnt = r.photon_records(which)
+            assert cnt == (ns, nv)[which]
+            parts[which].append(_view(ptr, cnt, dev).clone())
+    with pytest.raises(RptError):
+        r.photon_sample_array(1)                            # shot but not built: no map yet
+    surf, vol = torch.cat(parts[0]), torch.cat(parts[1])
+    assert surf.shape == (st["surface"], RECORD_BYTES) and vol.shape == (st["volume"], RECORD_BYTES)
+    torch.cuda.synchronize()
+    st2 = r.photon_map_from_records(n, kind, surf.data_ptr(), surf.shape[0], vol.data_ptr(), vol.shape[0])
+    assert (st2["surface"], st2["volume"], st2["shot"]) == (st["surface"], st["volume"], n)
+    assert np.array_equal(r.photon_map_download(0), ref[0]) and np.array_equal(r.photon_map_download(1), ref[1])
+    r._sample_offset = 0
+    assert np.array_equal(r.photon_sample_array(2), img_ref)
+    with pytest.raises(RptError):
+        r.photon_shoot(n, kind, 3, 3)
