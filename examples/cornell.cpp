@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
             .seed(1)
             .iterative_render(interval, [&](uint32_t iteration, const Buffer& buffer) {
                 last = buffer.image();
-                if (buffer.samples.size() > 1) variance = buffer.variance();
+                if (buffer.batches() > 1) variance = buffer.variance();
                 std::fprintf(stderr, "Finished iteration %u\n", iteration);
             });
         if (argc > 4) {  // optional: photon-mapped render of the same scene (photon.rs:650-652 style entry point)

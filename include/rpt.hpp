@@ -312,53 +312,45 @@ struct RgbImage {
     uint32_t width = 0, height = 0;
     std::vector<uint8_t> data;  // row-major RGB
 };
+// buffer.rs:5-97 on the device (rpt_buffer_*): per-pixel running sums; the box filter, color_bytes
+// and the variance run where the frame is.
 class Buffer {
   public:
-    Buffer(uint32_t w, uint32_t h, Filter f) : width(w), height(h), filter(f) {}
-    void add_samples(const std::vector<double>& s) {
+    Buffer(uint32_t w, uint32_t h, Filter f, int device = 0) : width(w), height(h), filter(f) {
+        h_ = rpt_buffer_create(device, w, h, f.radius);
+        if (!h_) throw Error(rpt_last_error());
+    }
+    Buffer(const Buffer&) = delete;
+    Buffer& operator=(const Buffer&) = delete;
+    Buffer(Buffer&& o) noexcept : width(o.width), height(o.height), filter(o.filter), h_(o.h_) { o.h_ = nullptr; }
+    ~Buffer() {
+        if (h_) rpt_buffer_destroy(h_);
+    }
+    void add_samples(const std::vector<double>& s) {  // buffer.rs:32-40
         if (s.size() != size_t(width) * height * 3) throw Error("Invalid sample dimension");
-        samples.push_back(s);
+        if (rpt_buffer_add_samples(h_, s.data()) != RPT_OK) throw Error(rpt_last_error());
     }
-    Color get_filtered_color(uint32_t x, uint32_t y) const {  // buffer.rs:75-93
-        Color c{0, 0, 0};
-        size_t count = 0;
-        uint32_t r = filter.radius;
-        for (uint32_t i = x > r ? x - r : 0; i <= x + r; i++)
-            for (uint32_t j = y > r ? y - r : 0; j <= y + r; j++)
-                if (i < width && j < height) {
-                    size_t idx = (size_t(j) * width + i) * 3;
-                    for (const auto& s : samples)
-                        for (int k = 0; k < 3; k++) c[k] += s[idx + k];
-                    count += samples.size();
-                }
-        if (count == 0) throw Error("Pixel found with no samples");
-        return {c[0] / double(count), c[1] / double(count), c[2] / double(count)};
-    }
-    RgbImage image() const {
-        RgbImage img{width, height, {}};
-        img.data.reserve(size_t(width) * height * 3);
-        for (uint32_t y = 0; y < height; y++)
-            for (uint32_t x = 0; x < width; x++)
-                for (uint8_t b : color_bytes(get_filtered_color(x, y))) img.data.push_back(b);
+    RgbImage image() const {  // buffer.rs:43-56
+        RgbImage img{width, height, std::vector<uint8_t>(size_t(width) * height * 3)};
+        if (rpt_buffer_image(h_, img.data.data()) != RPT_OK) throw Error(rpt_last_error());
         return img;
     }
     double variance() const {  // buffer.rs:59-73
-        double variance = 0;
-        size_t n = samples.size(), px = size_t(width) * height;
-        for (size_t p = 0; p < px; p++) {
-            Color mean{0, 0, 0};
-            for (const auto& s : samples)
-                for (int k = 0; k < 3; k++) mean[k] += s[p * 3 + k] / double(n);
-            double ss = 0;
-            for (const auto& s : samples)
-                for (int k = 0; k < 3; k++) ss += (s[p * 3 + k] - mean[k]) * (s[p * 3 + k] - mean[k]);
-            variance += ss / (double(n) - 1.0);
-        }
-        return variance / double(px);
+        double v = 0;
+        if (rpt_buffer_variance(h_, &v) != RPT_OK) throw Error(rpt_last_error());
+        return v;
     }
+    uint32_t batches() const {  // samples[i].len() of the reference (equal for every pixel)
+        uint32_t n = 0;
+        if (rpt_buffer_batches(h_, &n) != RPT_OK) throw Error(rpt_last_error());
+        return n;
+    }
+    rpt_buffer* raw() const { return h_; }
     uint32_t width, height;
-    std::vector<std::vector<double>> samples;
     Filter filter;
+
+  private:
+    rpt_buffer* h_ = nullptr;
 };
 
 // ---- renderer.rs
@@ -406,13 +398,13 @@ class Renderer {
     const Params& params() const { return p_; }
 
     RgbImage render() {  // renderer.rs:137-141
-        Buffer buffer(p_.width, p_.height, p_.filter);
+        Buffer buffer(p_.width, p_.height, p_.filter, p_.device);
         sample_offset_ = 0;
         sample(p_.num_samples, buffer);
         return buffer.image();
     }
     void iterative_render(uint32_t callback_interval, const std::function<void(uint32_t, const Buffer&)>& cb) {
-        Buffer buffer(p_.width, p_.height, p_.filter);  // renderer.rs:144-156
+        Buffer buffer(p_.width, p_.height, p_.filter, p_.device);  // renderer.rs:144-156
         sample_offset_ = 0;
         uint32_t iteration = 0;
         while (iteration < p_.num_samples) {
@@ -427,7 +419,7 @@ class Renderer {
     RgbImage photon_render(size_t photon_count, PhotonRenderKind kind) {  // photon.rs:655-720
         commit();
         check(rpt_photon_map_build(handle_, photon_count, int32_t(kind), p_.watts, p_.seed));
-        Buffer buffer(p_.width, p_.height, p_.filter);
+        Buffer buffer(p_.width, p_.height, p_.filter, p_.device);
         std::vector<double> out(size_t(p_.width) * p_.height * 3);
         rpt_camera cam = camera_.desc();
         rpt_render_params rp{p_.width, p_.height, p_.exposure_value, p_.max_bounces, p_.shard_rank, p_.shard_count};
@@ -441,14 +433,12 @@ class Renderer {
     RgbImage photon_map_render(size_t n) { return photon_render(n, PhotonMap); }                     // :650-652
 
     // Renderer::sample (renderer.rs:158-171): the call that crosses the C ABI.
-    void sample(uint32_t iterations, Buffer& buffer) {
+    void sample(uint32_t iterations, Buffer& buffer) {  // renderer.rs:158-171; the batch stays on the device
         commit();
-        std::vector<double> out(size_t(p_.width) * p_.height * 3);
         rpt_camera cam = camera_.desc();
         rpt_render_params rp{p_.width, p_.height, p_.exposure_value, p_.max_bounces, p_.shard_rank, p_.shard_count};
-        check(rpt_render_sample(handle_, &cam, &rp, iterations, p_.seed, sample_offset_, out.data()));
+        check(rpt_render_into_buffer(handle_, &cam, &rp, iterations, p_.seed, sample_offset_, buffer.raw()));
         sample_offset_ += iterations;
-        buffer.add_samples(out);
     }
 
   private:

@@ -158,6 +158,22 @@ int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* g
  * shapes share once and instance it, default 1); returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 
+/* ---- Buffer on the device (src/buffer.rs:5-97): the samples of each pixel are kept as running
+ * sums, so image() = box filter (Filter::Box(radius), :76-97) + color_bytes (src/color.rs:18-24)
+ * and variance() (:60-74) run where the frame is and only width*height*3 bytes come back. */
+typedef struct rpt_buffer rpt_buffer;
+rpt_buffer* rpt_buffer_create(int device, uint32_t width, uint32_t height, uint32_t filter_radius); /* Buffer::new */
+void rpt_buffer_destroy(rpt_buffer*);
+int rpt_buffer_add_samples(rpt_buffer*, const double* rgb /* host, width*height*3 */);           /* Buffer::add_samples */
+int rpt_buffer_add_samples_device(rpt_buffer*, const void* d_rgb, void* hip_stream);
+int rpt_buffer_image(rpt_buffer*, uint8_t* out_rgb8 /* host, width*height*3 */);                 /* Buffer::image */
+int rpt_buffer_variance(rpt_buffer*, double* out);                                               /* Buffer::variance */
+int rpt_buffer_batches(rpt_buffer*, uint32_t* n);
+/* Renderer::sample(&self, iterations, &mut Buffer) itself (src/renderer.rs:158-171): render one
+ * batch and push its means into the buffer without leaving the device. */
+int rpt_render_into_buffer(rpt_scene*, const rpt_camera*, const rpt_render_params*, uint32_t iterations,
+                           uint64_t seed, uint32_t sample_offset, rpt_buffer*);
+
 /* ---- photon mapping (next tier: src/photon.rs; config C4 = photon_point_query_beam_render) ----
  * `enum PhotonRenderKind` (src/photon.rs:631-639): point-point (photon_map_render), beam-point
  * (photon_point_query_beam_render, config C4) and beam-beam (photon_beam_query_beam_render). */

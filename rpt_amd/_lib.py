@@ -93,6 +93,15 @@ SYMBOLS = [
     ("rpt_debug_trip_stamps", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("rpt_get_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("rpt_set_option", C.c_int, [C.c_char_p, C.c_int64]),
+    ("rpt_buffer_create", _P, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("rpt_buffer_destroy", None, [_P]),
+    ("rpt_buffer_add_samples", C.c_int, [_P, _P]),
+    ("rpt_buffer_add_samples_device", C.c_int, [_P, _P, _P]),
+    ("rpt_buffer_image", C.c_int, [_P, _P]),
+    ("rpt_buffer_variance", C.c_int, [_P, C.POINTER(C.c_double)]),
+    ("rpt_buffer_batches", C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    ("rpt_render_into_buffer", C.c_int,
+     [_P, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_uint32, C.c_uint64, C.c_uint32, _P]),
     ("rpt_photon_map_build", C.c_int, [_P, C.c_uint64, C.c_int32, C.c_double, C.c_uint64]),
     ("rpt_photon_shoot", C.c_int,
      [_P, C.c_uint64, C.c_int32, C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),

@@ -49,7 +49,7 @@ __all__ = [
     "set_option", "shard_pixels",
     "vec3", "hex_color", "color_bytes", "Sphere", "Cube", "Plane", "Triangle", "Mesh", "KdTree", "Transformed",
     "sphere", "cube", "plane", "polygon", "Material", "Object", "Light", "Medium", "Environment",
-    "Scene", "Camera", "Filter", "Buffer", "Renderer", "RptError",
+    "Scene", "Camera", "Filter", "Buffer", "DeviceBuffer", "Renderer", "RptError",
 ]
 
 
@@ -601,6 +601,55 @@ class Buffer:
             return float(np.mean(ss / (n - 1.0)))
 
 
+class DeviceBuffer:
+    """The same Buffer kept on the GPU (rpt_buffer_*): per-pixel running sums, box filter +
+    color_bytes and variance computed where the frame is.  What Renderer.render() and
+    iterative_render() use; `Buffer` above is the host restatement."""
+
+    def __init__(self, width, height, filter=None, device=0):
+        self.width, self.height = int(width), int(height)
+        self.filter = filter or Filter.default()
+        self.device = int(device)
+        self._h = _lib.load().rpt_buffer_create(self.device, self.width, self.height, int(self.filter.radius))
+        if not self._h:
+            _lib.check(-1)
+
+    def add_samples(self, samples):
+        samples = np.ascontiguousarray(samples, dtype=np.float64).reshape(-1, 3)
+        assert samples.shape[0] == self.width * self.height, "Invalid sample dimension"
+        _lib.check(_lib.load().rpt_buffer_add_samples(self._h, samples.ctypes.data_as(C.c_void_p)))
+
+    def add_samples_device(self, d_rgb_ptr, stream_ptr=0):
+        _lib.check(_lib.load().rpt_buffer_add_samples_device(self._h, C.c_void_p(d_rgb_ptr), C.c_void_p(stream_ptr)))
+
+    @property
+    def batches(self):
+        n = C.c_uint32()
+        _lib.check(_lib.load().rpt_buffer_batches(self._h, C.byref(n)))
+        return int(n.value)
+
+    def image(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.uint8)
+        _lib.check(_lib.load().rpt_buffer_image(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def variance(self):
+        v = C.c_double()
+        _lib.check(_lib.load().rpt_buffer_variance(self._h, C.byref(v)))
+        return float(v.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().rpt_buffer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------ renderer.rs
 class Renderer:
     def __init__(self, scene, camera):
@@ -690,18 +739,25 @@ class Renderer:
         self._sample_offset += int(iterations)
 
     def sample(self, iterations, buffer):
-        buffer.add_samples(self.sample_array(iterations))
+        """Renderer::sample (renderer.rs:158-171).  A DeviceBuffer receives the batch on the GPU."""
+        if isinstance(buffer, DeviceBuffer) and self.shard_count_ == 1:
+            _lib.check(_lib.load().rpt_render_into_buffer(
+                self.scene._commit(self.device_), C.byref(camera_desc(self.camera, _lib.CameraDesc)),
+                C.byref(self._params()), int(iterations), C.c_uint64(self.seed_), self._sample_offset, buffer._h))
+            self._sample_offset += int(iterations)
+        else:
+            buffer.add_samples(self.sample_array(iterations))
 
     def render(self):
         """renderer.rs:137-141 -> (h, w, 3) uint8 image."""
-        buffer = Buffer(self.width_, self.height_, self.filter_)
+        buffer = DeviceBuffer(self.width_, self.height_, self.filter_, self.device_)
         self._sample_offset = 0
         self.sample(self.num_samples_, buffer)
         return buffer.image()
 
     def iterative_render(self, callback_interval, callback):
         """renderer.rs:144-156."""
-        buffer = Buffer(self.width_, self.height_, self.filter_)
+        buffer = DeviceBuffer(self.width_, self.height_, self.filter_, self.device_)
         self._sample_offset = 0
         iteration = 0
         while iteration < self.num_samples_:

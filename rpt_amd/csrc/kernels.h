@@ -36,6 +36,11 @@ hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream);
 hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu);  // bvh: bvh_mode()
 int bvh_mode(const SceneView& sc);  // 0 no tree, 1 per-mesh trees, 2 scene-level tree
 // out[pixel] = sum_chunks slab / iterations * scale for owned pixels (others untouched).
+hipError_t launch_buffer_add(uint32_t n_pixels, const double* d_batch, double* d_sum, double* d_sumsq, hipStream_t st);
+hipError_t launch_buffer_image(uint32_t w, uint32_t h, uint32_t radius, uint32_t n_batches, const double* d_sum, uint8_t* d_out,
+                               hipStream_t st);
+hipError_t launch_buffer_variance(uint32_t n_pixels, uint32_t n_batches, const double* d_sum, const double* d_sumsq, double* d_out,
+                                  hipStream_t st);
 hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipStream_t stream);
 hipError_t launch_intersect(const SceneView& sc, uint64_t n, const float* d_o, const float* d_d, float* d_t,
                             int32_t* d_obj, float* d_n, bool bvh, hipStream_t stream);

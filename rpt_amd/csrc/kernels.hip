@@ -293,6 +293,55 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs a, double
     out[o + 2] = b * inv;
 }
 
+// ------------------------------------------------------------------ Buffer (src/buffer.rs)
+// add_samples (:32-40): one mean per pixel per batch.  The per-pixel Vec<Color> is kept as its
+// running sum (in push order, as `iter().sum()` adds it) and the sum of squared magnitudes.
+__global__ __launch_bounds__(256) void buffer_add_kernel(uint32_t n_pixels, const double* __restrict__ batch,
+                                                         double* __restrict__ sum, double* __restrict__ sumsq) {
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_pixels) return;
+    double r = batch[3 * size_t(p)], g = batch[3 * size_t(p) + 1], b = batch[3 * size_t(p) + 2];
+    sum[3 * size_t(p)] += r;
+    sum[3 * size_t(p) + 1] += g;
+    sum[3 * size_t(p) + 2] += b;
+    sumsq[p] += r * r + g * g + b * b;
+}
+// image() (:42-57) = get_filtered_color (:76-97, window summed x-outer / y-inner over the clipped
+// (2r+1)^2 pixels, divided by the number of samples in it) then color_bytes (src/color.rs:18-24).
+__global__ __launch_bounds__(256) void buffer_image_kernel(uint32_t width, uint32_t height, uint32_t radius, uint32_t n_batches,
+                                                           const double* __restrict__ sum, uint8_t* __restrict__ out) {
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= width * height) return;
+    uint32_t x = p % width, y = p / width;
+    double r = 0.0, g = 0.0, b = 0.0;
+    uint64_t count = 0;
+    uint32_t x0 = x >= radius ? x - radius : 0u, y0 = y >= radius ? y - radius : 0u;
+    for (uint32_t i = x0; i <= x + radius; i++)
+        for (uint32_t j = y0; j <= y + radius; j++)
+            if (i < width && j < height) {
+                size_t q = size_t(j) * width + i;
+                r += sum[3 * q];
+                g += sum[3 * q + 1];
+                b += sum[3 * q + 2];
+                count += n_batches;
+            }
+    double c[3] = {r / double(count), g / double(count), b / double(count)};
+    for (int k = 0; k < 3; k++) {
+        double v = fmin(fmax(c[k], 0.0), 1.0);               // NaN clamps to 0 like f64::clamp + `as u8`
+        out[3 * size_t(p) + k] = uint8_t(pow(v, 1.0 / 2.2) * 255.0);
+    }
+}
+// variance() (:60-74), per pixel: sum |s - mean|^2 / (n - 1) from the running sums.
+__global__ __launch_bounds__(256) void buffer_variance_kernel(uint32_t n_pixels, uint32_t n_batches, const double* __restrict__ sum,
+                                                              const double* __restrict__ sumsq, double* __restrict__ out) {
+    uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_pixels) return;
+    double n = double(n_batches);
+    double mr = sum[3 * size_t(p)] / n, mg = sum[3 * size_t(p) + 1] / n, mb = sum[3 * size_t(p) + 2] / n;
+    double ss = sumsq[p] - n * (mr * mr + mg * mg + mb * mb);
+    out[p] = fmax(ss, 0.0) / (n - 1.0);
+}
+
 template <int BVH>
 __global__ __launch_bounds__(256) void intersect_kernel(const SceneView sc, uint64_t n, const float* __restrict__ o,
                                                         const float* __restrict__ d, float* __restrict__ t_out,
@@ -395,6 +444,21 @@ hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu) {
 hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipStream_t stream) {
     uint32_t blocks = (a.n_owned + 255u) / 256u;
     hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, stream, a, scale, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_buffer_add(uint32_t n_pixels, const double* d_batch, double* d_sum, double* d_sumsq, hipStream_t st) {
+    hipLaunchKernelGGL(buffer_add_kernel, dim3((n_pixels + 255) / 256), dim3(256), 0, st, n_pixels, d_batch, d_sum, d_sumsq);
+    return hipGetLastError();
+}
+hipError_t launch_buffer_image(uint32_t w, uint32_t h, uint32_t radius, uint32_t n_batches, const double* d_sum, uint8_t* d_out,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(buffer_image_kernel, dim3((w * h + 255) / 256), dim3(256), 0, st, w, h, radius, n_batches, d_sum, d_out);
+    return hipGetLastError();
+}
+hipError_t launch_buffer_variance(uint32_t n_pixels, uint32_t n_batches, const double* d_sum, const double* d_sumsq, double* d_out,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL(buffer_variance_kernel, dim3((n_pixels + 255) / 256), dim3(256), 0, st, n_pixels, n_batches, d_sum, d_sumsq,
+                       d_out);
     return hipGetLastError();
 }
 hipError_t launch_intersect(const SceneView& sc, uint64_t n, const float* d_o, const float* d_d, float* d_t,

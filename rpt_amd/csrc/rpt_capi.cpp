@@ -1338,6 +1338,104 @@ int rpt_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_para
     return rpti::fetch_counters(s, a);
 }
 
+// ---------------------------------------------------------------------------- Buffer on the device
+struct rpt_buffer {
+    int device = 0;
+    uint32_t width = 0, height = 0, radius = 0, n_batches = 0;
+    double *d_sum = nullptr, *d_sumsq = nullptr, *d_stage = nullptr;  // stage: one batch / per-pixel variances
+    uint8_t* d_img = nullptr;
+};
+rpt_buffer* rpt_buffer_create(int device, uint32_t width, uint32_t height, uint32_t filter_radius) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { fail(RPT_ERR_INVALID, "device index out of range"); return nullptr; }
+    if (width == 0 || height == 0 || uint64_t(width) * height >= (1ull << 31)) { fail(RPT_ERR_INVALID, "bad buffer size"); return nullptr; }
+    auto* b = new rpt_buffer();
+    b->device = device;
+    b->width = width;
+    b->height = height;
+    b->radius = filter_radius;
+    const size_t n = size_t(width) * height;
+    bool ok = hipSetDevice(device) == hipSuccess && hipMalloc((void**)&b->d_sum, n * 24) == hipSuccess &&
+              hipMalloc((void**)&b->d_sumsq, n * 8) == hipSuccess && hipMalloc((void**)&b->d_stage, n * 24) == hipSuccess &&
+              hipMalloc((void**)&b->d_img, n * 3) == hipSuccess && hipMemset(b->d_sum, 0, n * 24) == hipSuccess &&
+              hipMemset(b->d_sumsq, 0, n * 8) == hipSuccess;
+    if (!ok) {
+        fail(RPT_ERR_DEVICE, "rpt_buffer_create: device allocation failed");
+        rpt_buffer_destroy(b);
+        return nullptr;
+    }
+    return b;
+}
+void rpt_buffer_destroy(rpt_buffer* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    (void)hipFree(b->d_sum); (void)hipFree(b->d_sumsq); (void)hipFree(b->d_stage); (void)hipFree(b->d_img);
+    delete b;
+}
+int rpt_buffer_add_samples_device(rpt_buffer* b, const void* d_rgb, void* hip_stream) {
+    if (!b || !d_rgb) return fail(RPT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(launch_buffer_add(b->width * b->height, static_cast<const double*>(d_rgb), b->d_sum, b->d_sumsq,
+                              static_cast<hipStream_t>(hip_stream)));
+    b->n_batches++;
+    return RPT_OK;
+}
+int rpt_buffer_add_samples(rpt_buffer* b, const double* rgb) {
+    if (!b || !rgb) return fail(RPT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpy(b->d_stage, rgb, size_t(b->width) * b->height * 24, hipMemcpyHostToDevice));
+    return rpt_buffer_add_samples_device(b, b->d_stage, nullptr);
+}
+int rpt_buffer_image(rpt_buffer* b, uint8_t* out_rgb8) {
+    if (!b || !out_rgb8) return fail(RPT_ERR_INVALID, "null argument");
+    if (b->n_batches == 0) return fail(RPT_ERR_STATE, "Pixel found with no samples");  // the reference's assert (buffer.rs:89)
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());  // batches may have been added on other streams
+    HIP_TRY(launch_buffer_image(b->width, b->height, b->radius, b->n_batches, b->d_sum, b->d_img, nullptr));
+    HIP_TRY(hipMemcpy(out_rgb8, b->d_img, size_t(b->width) * b->height * 3, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+int rpt_buffer_variance(rpt_buffer* b, double* out) {
+    if (!b || !out) return fail(RPT_ERR_INVALID, "null argument");
+    if (b->n_batches < 2) { *out = std::numeric_limits<double>::quiet_NaN(); return RPT_OK; }  // 0/0 in the reference too
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = size_t(b->width) * b->height;
+    HIP_TRY(launch_buffer_variance(uint32_t(n), b->n_batches, b->d_sum, b->d_sumsq, b->d_stage, nullptr));
+    std::vector<double> v(n);
+    HIP_TRY(hipMemcpy(v.data(), b->d_stage, n * 8, hipMemcpyDeviceToHost));
+    double acc = 0.0;
+    for (double x : v) acc += x;  // pixel order, as buffer.rs:63-72
+    *out = acc / double(n);
+    return RPT_OK;
+}
+int rpt_buffer_batches(rpt_buffer* b, uint32_t* n) {
+    if (!b || !n) return fail(RPT_ERR_INVALID, "null argument");
+    *n = b->n_batches;
+    return RPT_OK;
+}
+// Renderer::sample(&self, iterations, &mut Buffer), src/renderer.rs:158-171: the frame never leaves the device.
+int rpt_render_into_buffer(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
+                           uint64_t seed, uint32_t sample_offset, rpt_buffer* b) {
+    if (!b) return fail(RPT_ERR_INVALID, "null buffer");
+    if (!s || !prm) return fail(RPT_ERR_INVALID, "null argument");
+    if (prm->width != b->width || prm->height != b->height) return fail(RPT_ERR_INVALID, "Invalid sample dimension");  // buffer.rs:33-36
+    if (s->committed && s->device != b->device) return fail(RPT_ERR_INVALID, "buffer and scene live on different devices");
+    RenderArgs a{};
+    int rc = rpti::prepare_render(s, cam, prm, iterations, seed, sample_offset, a);
+    if (rc) return rc;
+    if (prm->shard_count > 1) HIP_TRY(hipMemsetAsync(b->d_stage, 0, size_t(b->width) * b->height * 24, nullptr));
+    rc = run_render(s, prm, a, b->d_stage, nullptr);
+    if (rc) return rc;
+    rc = rpt_buffer_add_samples_device(b, b->d_stage, nullptr);
+    if (rc) return rc;
+    if (a.counters) {
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return rpti::fetch_counters(s, a);
+    }
+    return RPT_OK;
+}
+
 int rpt_get_timing(rpt_scene* s, double* render_ms, double* resolve_ms, int32_t* grid_blocks) {
     if (!s) return fail(RPT_ERR_INVALID, "null scene");
     if (!s->ev_valid) return fail(RPT_ERR_STATE, "no timed render: rpt_set_option(\"timing\", 1) first");
