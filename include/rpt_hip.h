@@ -144,9 +144,10 @@ int rpt_scene_stats(rpt_scene*, uint64_t out[16]);
  * [6] BVH triangle tests.  Filled only when the library is built with RPT_COUNTERS or
  * rpt_set_option("counters", 1) was called before the render; otherwise zeros. */
 int rpt_get_counters(rpt_scene*, uint64_t out[8]);
-/* Diagnostic (counters on): 100 MHz wall-clock stamps taken by wave 0 of block 0 every 32 loop trips
- * of the last path-traced render (0 where not reached). */
-int rpt_debug_trip_stamps(rpt_scene*, uint64_t out[56]);
+/* Diagnostic (counters on): for section k of the megakernel's loop body (kernels.hip, SECT(k)),
+ * out[2k] = wave-level executions and out[2k+1] = lanes active in them during the last path-traced
+ * render: the lane utilisation of each divergent piece of code. */
+int rpt_debug_section_counters(rpt_scene*, uint64_t out[56]);
 /* HIP-event timing of the last render on this scene (needs rpt_set_option("timing", 1)):
  * milliseconds of the megakernel and of the resolve kernel on the stream they ran on, and the
  * persistent grid size.  Synchronises on the last recorded event. */

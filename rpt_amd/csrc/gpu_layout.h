@@ -100,7 +100,7 @@ struct alignas(16) Light {
     uint32_t first;       // LS_MESH: first LightTri
     uint32_t count;       // LS_MESH: triangle count
     uint32_t xf;          // index into lxf (every object light has one)
-    uint32_t _pad[2];
+    uint32_t twin_lo, twin_hi;  // hit codes of the twin object's primitives when they form one range (lo <= hi)
     F4 color;             // Ambient: colour;  Object: material.color() * material.emittance()
     F4 albedo;            // Object: material.color() (photon power, src/photon.rs:757)
 };

@@ -52,6 +52,25 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 #ifndef RPT_MIN_WAVES
 #define RPT_MIN_WAVES 4
 #endif
+// Diagnostic sections of the megakernel (COUNT build): per section, counters[8 + 2k] counts wave-level
+// executions and counters[9 + 2k] the lanes active in them (lane utilisation of divergent code).
+// -DRPT_MARKERS additionally drops "; SECT k" comments into the ISA for static instruction counts.
+#ifdef RPT_MARKERS
+#define RPT_MARK(k) asm volatile("; SECT " #k ::: "memory")
+#else
+#define RPT_MARK(k)
+#endif
+#define SECT(k)                                                                                  \
+    do {                                                                                         \
+        RPT_MARK(k);                                                                             \
+        if (COUNT) {                                                                             \
+            const uint64_t m_ = __ballot(true);                                                  \
+            if (mbcnt64(m_) == 0) {                                                              \
+                atomicAdd(&a.counters[8 + 2 * (k)], 1ull);                                       \
+                atomicAdd(&a.counters[9 + 2 * (k)], (unsigned long long)__popcll(m_));           \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
 template <bool MEDIUM, int BVH, bool COUNT>
 __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
     extern __shared__ uint32_t dyn_lds[];
@@ -73,6 +92,7 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
     bool alive = true, have_item = false, need_path = true;
     bool drained = false;  // wave-uniform: the global queue is exhausted
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform cursor into the current batch of work items
+    uint32_t pool_chunk = 0, pool_x0 = 0, pool_y0 = 0;  // wave-uniform: the batch's chunk and 8x8 block origin
 
     uint32_t c_samples = 0, c_rays = 0, c_vertices = 0, c_trips = 0, c_nodes = 0, c_btris = 0;
 
@@ -83,6 +103,7 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
         // (One atomic per lane-pull saturated the counter at ~80 M dequeues/s: profiles/r01.)
         bool want = alive && need_path && s >= s_end;
         if (__any(want)) {
+            SECT(0);
             if (want && have_item) {
                 reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(acc.x, acc.y, acc.z, 0.f);
                 have_item = false;
@@ -105,6 +126,15 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
                     }
                     pool_next = lo;
                     pool_end = min(lo + 64u, a.n_items);
+                    // a batch is 64-aligned and n_owned is a multiple of 1024: its 64 items are one 8x8 pixel
+                    // block of one chunk, so the decode (two divisions, a table load) is done once, wave-uniformly
+                    pool_chunk = lo / a.n_owned;
+                    const uint32_t p0 = lo - pool_chunk * a.n_owned;
+                    const uint32_t tile = a.tiles[p0 >> 10], sb = (p0 & 1023u) >> 6;
+                    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+                    pool_x0 = __builtin_amdgcn_readfirstlane(tx * 32u + (sb & 3u) * 8u);
+                    pool_y0 = __builtin_amdgcn_readfirstlane(ty * 32u + (sb >> 2) * 8u);
+                    pool_chunk = __builtin_amdgcn_readfirstlane(pool_chunk);
                 }
                 const uint32_t take = min(uint32_t(__popcll(m)), pool_end - pool_next);
                 const uint32_t rank = mbcnt64(m);
@@ -112,9 +142,8 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
                 const bool got = want && rank < take;
                 pool_next += take;
                 if (got) {
-                    uint32_t chunk = item / a.n_owned, p = item - chunk * a.n_owned;
-                    uint32_t x, y;
-                    item_pixel(a, p, x, y);
+                    const uint32_t chunk = pool_chunk, l = item & 63u;
+                    const uint32_t x = pool_x0 + (l & 7u), y = pool_y0 + (l >> 3);
                     if (x < a.width && y < a.height) {  // slots of clipped tiles lie outside the image
                         want = false;
                         have_item = true;
@@ -132,6 +161,7 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
         }
         if (need_path && alive) {
             if (alive) {  // src/renderer.rs:179-181
+                SECT(1);
                 rng.seed(a.seed_mixed, pix, a.sample_offset + s);
                 float dx = rng.range(-a.inv_dim, a.inv_dim);
                 float dy = rng.range(-a.inv_dim, a.inv_dim);
@@ -146,16 +176,12 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
             }
         }
         if (!__any(alive)) break;
-        if (COUNT && (threadIdx.x & 63u) == 0) {
-            // diagnostic: wave 0 of block 0 stamps the 100 MHz wall clock every 32 trips (slots 8..63)
-            if (blockIdx.x == 0 && threadIdx.x == 0 && (c_trips & 31u) == 0 && (c_trips >> 5) < 56u)
-                a.counters[8u + (c_trips >> 5)] = wall_clock64();
-            c_trips++;
-        }
+        if (COUNT && (threadIdx.x & 63u) == 0) c_trips++;
         if (!alive) continue;
 
         // ---- one path vertex (one trace_ray invocation, src/renderer.rs:187-322)
         if (COUNT) c_vertices++;
+        SECT(2);
         float dmed = kInf;
         if (MEDIUM) {  // Medium::sample_d, src/medium.rs:133-146
             float xi = rng.range(0.f, 1.f);
@@ -167,11 +193,13 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
         uint32_t code = CODE_MISS, inst = 0;
         closest_hit<BVH, COUNT>(sc, ro, rd, tmin, t, code, inst, stk, stride, c_nodes, c_btris);
         if (COUNT) c_rays++;
+        SECT(3);
         const bool hit = code != CODE_MISS;
 
         const bool ev_medium = MEDIUM && (dmed < (hit ? t : 400.f));  // src/renderer.rs:197-243
         const bool ev_surface = !ev_medium && hit;
         if (!ev_medium && !ev_surface) {  // miss: environment (src/renderer.rs:198-206, 288)
+            SECT(4);
             acc = acc + vmin(fma3(Q, env_color(sc, rd), P), Rc);
             need_path = true;
             continue;
@@ -180,6 +208,7 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
         V x, n = mk(0, 1, 0), mcol = mk(0, 0, 0), E;
         Mat mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
         if (ev_medium) {  // src/renderer.rs:243-255
+            SECT(5);
             x = fma3(dmed, rd, ro);
             bool hi = sc.medium_kind == 1u && x.y > 250.f;
             mcol = hi ? mk(sc.medium_color_hi[0], sc.medium_color_hi[1], sc.medium_color_hi[2])
@@ -187,6 +216,7 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
             E = (depth == 0) ? sc.medium_emission * mcol : mk(0, 0, 0);
         } else {  // src/renderer.rs:207-216, 289-299
             uint32_t obj;
+            SECT(6);
             finalize_hit(sc, ro, rd, tmin, t, code, inst, n, obj);
             mat = load_mat(sc, obj);
             x = fma3(t, rd, ro);
@@ -202,8 +232,10 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
             } else if (L.kind == L_OBJECT) {
                 V I, wi;
                 float dist;
+                SECT(7);
                 illuminate_object(sc, L, x, rng, I, wi, dist);
                 if (L.twin_object >= 0) {
+                    SECT(8);
                     // Reference: contributes iff the closest hit along wi lies at dist_to_light
                     // (|hit - dist| < 1e-12).  fp32 equivalent: the closest hit belongs to the
                     // scene object that IS this light, at the sampled distance (rel. tol 1e-3).
@@ -211,8 +243,10 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
                     uint32_t cs = CODE_MISS, is = 0;
                     closest_hit<BVH, COUNT>(sc, x, wi, ray_tmin(x), ts, cs, is, stk, stride, c_nodes, c_btris);
                     if (COUNT) c_rays++;
-                    bool vis = cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) &&
-                               code_object(sc, cs, is) == uint32_t(L.twin_object);
+                    SECT(9);
+                    const bool twin = (L.twin_lo <= L.twin_hi) ? (cs >= L.twin_lo && cs <= L.twin_hi)   // wave-uniform choice
+                                                               : (cs != CODE_MISS && code_object(sc, cs, is) == uint32_t(L.twin_object));
+                    bool vis = cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) && twin;
                     if (vis) {
                         if (ev_medium) {
                             E = fma3(albedo_med * sc.medium_phase, I * mcol, E);
@@ -230,7 +264,9 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
         // ---- continue or end the path
         bool bounce;
         V wi = mk(0, 0, 1), k = mk(0, 0, 0);
+        SECT(10);
         if (ev_medium) {  // src/renderer.rs:262-281
+            SECT(11);
             bounce = rng.uniform() < 0.8f;
             if (bounce) {
                 float ax = rng.range(-1.f, 1.f), ay = rng.range(-1.f, 1.f), az = rng.range(-1.f, 1.f);
@@ -238,9 +274,11 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
                 k = (albedo_med * 1.25f) * mcol;       // (scat/ext) / ph_p * phase / rr_p, ph_p == phase
             }
         } else {
+            SECT(12);
             bounce = MEDIUM ? (rng.uniform() < 0.8f) : (depth < a.max_bounces);  // :222 / :301
             if (bounce) {
                 float pdf;
+                SECT(13);
                 bounce = sample_f(mat, n, wo, rng, wi, pdf);
                 if (bounce) {
                     V f = bsdf(mat, n, wo, wi);
@@ -249,6 +287,7 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const Render
                 }
             }
         }
+        SECT(14);
         P = fma3(Q, E, P);
         if (bounce && !is_zero(k)) {
             if (!MEDIUM) Rc = vmin(Rc, fma3(100.f, Q, P));  // FIREFLY_CLAMP, src/renderer.rs:311-313

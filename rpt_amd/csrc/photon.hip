@@ -625,6 +625,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
     bool alive = true, have_item = false;
     bool drained = false;  // wave-uniform: the global queue is exhausted
     uint32_t pool_next = 0, pool_end = 0;
+    uint32_t pool_chunk = 0, pool_x0 = 0, pool_y0 = 0;  // wave-uniform: the batch's chunk and 8x8 block origin
     uint32_t c0 = 0, c1 = 0;
     unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
     for (;;) {
@@ -652,6 +653,14 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                     }
                     pool_next = lo;
                     pool_end = min(lo + 64u, a.n_items);
+                    // one batch = one 8x8 pixel block of one chunk: decoded once, wave-uniformly (see kernels.hip)
+                    pool_chunk = lo / a.n_owned;
+                    const uint32_t p0 = lo - pool_chunk * a.n_owned;
+                    const uint32_t tile = a.tiles[p0 >> 10], sb = (p0 & 1023u) >> 6;
+                    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+                    pool_x0 = __builtin_amdgcn_readfirstlane(tx * 32u + (sb & 3u) * 8u);
+                    pool_y0 = __builtin_amdgcn_readfirstlane(ty * 32u + (sb >> 2) * 8u);
+                    pool_chunk = __builtin_amdgcn_readfirstlane(pool_chunk);
                 }
                 const uint32_t take = min(uint32_t(__popcll(m)), pool_end - pool_next);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
@@ -659,11 +668,8 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                 const bool got = want && rank < take;
                 pool_next += take;
                 if (got) {
-                    uint32_t chunk = item / a.n_owned, p = item - chunk * a.n_owned;
-                    uint32_t tl = p >> 10, within = p & 1023u, sb = within >> 6, l = within & 63u;
-                    uint32_t tile = a.tiles[tl];
-                    uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-                    uint32_t x = tx * 32u + (sb & 3u) * 8u + (l & 7u), y = ty * 32u + (sb >> 2) * 8u + (l >> 3);
+                    const uint32_t chunk = pool_chunk, l = item & 63u;
+                    const uint32_t x = pool_x0 + (l & 7u), y = pool_y0 + (l >> 3);
                     if (x < a.width && y < a.height) {
                         want = false;
                         have_item = true;

@@ -74,6 +74,11 @@ inline float bits_f(uint32_t u) {
     std::memcpy(&f, &u, 4);
     return f;
 }
+inline uint32_t bits_u(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
 
 // Derived matrices of Transformed::new (src/shape.rs:112-125), fp64.
 struct Xf {
@@ -976,6 +981,30 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         rect.insert(rect.end(), rect_axis[a].begin(), rect_axis[a].end());
         rect_sh.insert(rect_sh.end(), rect_sh_axis[a].begin(), rect_sh_axis[a].end());
     }
+    // ---- shadow test shortcut: when the primitives of a light's twin object form one contiguous range of
+    // hit codes, "the closest hit belongs to the twin" is a range compare instead of a shade-record load
+    for (Light& L : lights) {
+        L.twin_lo = 1u;
+        L.twin_hi = 0u;
+        if (L.kind != L_OBJECT || L.twin_object < 0) continue;
+        const uint32_t tw = uint32_t(L.twin_object);
+        std::vector<uint32_t> codes;
+        bool other = false;  // pieces a range cannot describe
+        auto same = [&](float w) { return bits_u(w) == tw; };
+        for (size_t i = 0; i < sph_sh.size(); i++) if (same(sph_sh[i].r0.w)) codes.push_back((K_SPHERE << 28) | uint32_t(i));
+        for (size_t i = 0; i < cub_sh.size(); i++) if (same(cub_sh[i].r0.w)) codes.push_back((K_CUBE << 28) | uint32_t(i));
+        for (size_t i = 0; i < pln_sh.size(); i++) if (same(pln_sh[i].unit_n_obj.w)) codes.push_back((K_PLANE << 28) | uint32_t(i));
+        for (size_t i = 0; i < tri_sh.size(); i++) if (same(tri_sh[i].n1.w)) codes.push_back((K_TRI << 28) | uint32_t(i));
+        for (size_t i = 0; i < aabb.size(); i++) if (same(aabb[i].lo.w)) codes.push_back((K_AABB << 28) | uint32_t(i));
+        for (size_t i = 0; i < rect_sh.size(); i++) if (same(rect_sh[i].n_obj.w)) codes.push_back((K_RECT << 28) | uint32_t(i));
+        for (const MeshRef& m : meshes) if (m.object == tw) other = true;
+        for (const InstRec& r : insts) if (same(r.n0.w)) other = true;
+        if (other || codes.empty()) continue;
+        bool contiguous = true;
+        for (size_t i = 1; i < codes.size(); i++) contiguous = contiguous && codes[i] == codes[i - 1] + 1u;
+        if (contiguous) { L.twin_lo = codes.front(); L.twin_hi = codes.back(); }
+    }
+
     // ---- scene-level BVH over bounded primitives and mesh roots (many-primitive scenes only)
     std::vector<uint32_t> pleaf;
     uint32_t top_root = 0;
@@ -1461,7 +1490,7 @@ int rpt_get_counters(rpt_scene* s, uint64_t out[8]) {
     std::memcpy(out, s->last_counters, 64);
     return RPT_OK;
 }
-int rpt_debug_trip_stamps(rpt_scene* s, uint64_t out[56]) {
+int rpt_debug_section_counters(rpt_scene* s, uint64_t out[56]) {
     if (!s || !out) return fail(RPT_ERR_INVALID, "null argument");
     std::memcpy(out, s->last_counters + 8, 56 * 8);
     return RPT_OK;

@@ -1,16 +1,27 @@
-import sys, ctypes as C
-sys.path.insert(0, '.')
-import numpy as np
-import rpt_amd
-from rpt_amd import Renderer, scenes, _lib
-sc, cam, cfg = scenes.CONFIGS["C3"]()
+"""Lane utilisation per section of the megakernel's loop body (COUNT build, SECT(k) in kernels.hip).
+Usage: python tools/trips.py [workload] [spp]"""
+import ctypes as C
+import sys
+
+sys.path.insert(0, ".")
+import rpt_amd  # noqa: E402
+from rpt_amd import Renderer, _lib, scenes  # noqa: E402
+
+NAMES = ["0 work pull", "1 regenerate camera ray", "2 vertex start (medium d, wo)", "3 after primary scan", "4 miss/env",
+         "5 medium event setup", "6 surface finalize + material", "7 light sample", "8 shadow scan start",
+         "9 after shadow scan (visibility, NEE shading)", "10 bounce start", "11 medium bounce", "12 surface RR",
+         "13 surface sample_f + bsdf", "14 path update"]
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+scene, cam, cfg = scenes.CONFIGS[name]()
+r = Renderer(scene, cam).width(cfg["width"]).height(cfg["height"]).max_bounces(cfg["max_bounces"]).seed(0)
 rpt_amd.set_option("counters", 1)
-for count in (1, 8):
-    r = Renderer(sc, cam).width(1024).height(1024).max_bounces(10).seed(0).shard(0, count)
-    r.sample_array(256)
-    out = (C.c_uint64 * 56)()
-    _lib.check(_lib.load().rpt_debug_trip_stamps(r.scene._handle, out))
-    st = np.array([int(v) for v in out], dtype=np.float64)
-    st = st[st > 0]
-    d = np.diff(st) / 100.0 / 32.0   # us per trip
-    print("shards", count, "us/trip over successive 32-trip windows:", np.round(d[:40], 1))
+r.sample_array(spp)
+c = r.counters()
+out = (C.c_uint64 * 56)()
+_lib.check(_lib.load().rpt_debug_section_counters(r.scene._handle, out))
+print(f"{name} {spp} spp: wave trips {c['wave_trips']}, rays/sample {c['rays'] / c['samples']:.3f}")
+for k, nm in enumerate(NAMES):
+    w, l = int(out[2 * k]), int(out[2 * k + 1])
+    if w:
+        print(f"  {nm:48s} execs/trip {w / c['wave_trips']:.3f}   lanes {l / w:5.1f} / 64")
