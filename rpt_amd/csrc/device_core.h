@@ -591,7 +591,7 @@ RPT_DEV V bsdf(const Mat& m, V n, V wo, V wi) {
 // Shape::sample of the light's shape: point v, normal n, pdf p (per world area).
 RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng& rng, V& v, V& n, float& p) {
     V vl, nl;
-    const LightXf x = sc.lxf[L.xf];
+    const LightXf x = uload(&sc.lxf[L.xf]);  // wave-uniform (the light record is): scalar loads, scalar `xf`
     const bool xf = x.nrm[1].w != 0.f;
     const bool mesh = L.shape == LS_MESH;
     if (mesh) {

@@ -50,7 +50,10 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 }
 
 #ifndef RPT_MIN_WAVES
-#define RPT_MIN_WAVES 4
+#define RPT_MIN_WAVES 4       // waves per SIMD the BVH instantiations are compiled for (128 VGPRs)
+#endif
+#ifndef RPT_MIN_WAVES_SCAN
+#define RPT_MIN_WAVES_SCAN 5  // linear-scan instantiations (BVH = 0): 96 VGPRs; the kernel is latency-bound
 #endif
 // Diagnostic sections of the megakernel (COUNT build): per section, counters[8 + 2k] counts wave-level
 // executions and counters[9 + 2k] the lanes active in them (lane utilisation of divergent code).
@@ -72,7 +75,7 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
         }                                                                                        \
     } while (0)
 template <bool MEDIUM, int BVH, bool COUNT>
-__global__ __launch_bounds__(256, RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
     extern __shared__ uint32_t dyn_lds[];
     const SceneView& sc = a.sc;
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
