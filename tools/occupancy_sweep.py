@@ -10,7 +10,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 scene, cam, cfg = scenes.CONFIGS[name]()
 rpt_amd.set_option("timing", 1)
-for bpc in (1, 2, 3, 4):
+for bpc in ([int(v) for v in sys.argv[3:]] or [1, 2, 3, 4]):
     rpt_amd.set_option("blocks_per_cu", bpc)
     r = Renderer(scene, cam).width(cfg["width"]).height(cfg["height"]).max_bounces(cfg["max_bounces"]).seed(0)
     r.sample_array(8)
