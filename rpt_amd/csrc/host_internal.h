@@ -29,6 +29,7 @@ int run_persistent(rpt_scene* s, const rpt_render_params* prm, const rptg::Rende
                    int blocks_per_cu, const std::function<hipError_t(const rptg::RenderArgs&, int, hipStream_t)>& launch);
 int fetch_counters(rpt_scene* s, const rptg::RenderArgs& a);  // after the stream has been synchronised
 double* scratch_out(rpt_scene* s, size_t bytes);  // cached device frame for the host-buffer entry points
+int64_t option_photon_skip();  // rpt_set_option("photon_skip"): diagnostic bit mask for the camera pass
 }  // namespace rpti
 
 #define RPTI_HIP_TRY(expr)                                                                          \

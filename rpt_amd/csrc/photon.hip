@@ -27,6 +27,11 @@ struct alignas(16) PhotonRec {
     F4 pow;    // power
 };
 
+// Photon-tree leaf entry: BVH_LEAF | (count - 1) << 26 | first photon (sorted order).  The trees the beam
+// walkers use are packed with one photon per leaf; the k-NN trees with up to kKnnLeaf.
+static constexpr uint32_t PH_LEAF_INDEX = 0x03FFFFFFu;
+static constexpr uint32_t kKnnLeaf = 8;
+
 RPT_DEV float ray_tmin_p(V o) { return 2e-5f * (1.f + max3(fabsf(o.x), fabsf(o.y), fabsf(o.z))); }
 
 struct ShootArgs {
@@ -229,8 +234,9 @@ RPT_DEV int lcp(const uint64_t* keys, int n, int i, int j) {  // Karras' delta w
     return 64 + __clz(uint32_t(i) ^ uint32_t(j));
 }
 // One thread per internal node (Karras 2012).  child < 0x80000000: internal index; else leaf | index.
+// range_lo/hi: the contiguous run of sorted photons under each internal node (its Karras interval).
 __global__ void karras_kernel(const uint64_t* keys, int n, uint32_t* left, uint32_t* right, uint32_t* parent_int,
-                              uint32_t* parent_leaf) {
+                              uint32_t* parent_leaf, uint32_t* range_lo, uint32_t* range_hi) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     int d = (lcp(keys, n, i, i + 1) - lcp(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -255,6 +261,8 @@ __global__ void karras_kernel(const uint64_t* keys, int n, uint32_t* left, uint3
     else { rc = uint32_t(gamma + 1); parent_int[gamma + 1] = uint32_t(i); }
     left[i] = lc;
     right[i] = rc;
+    range_lo[i] = uint32_t(min(i, j));
+    range_hi[i] = uint32_t(max(i, j));
     if (i == 0) parent_int[0] = 0xFFFFFFFFu;
 }
 // Bottom-up boxes: the second thread to reach a node computes it.  box = 6 floats per internal node.
@@ -272,7 +280,7 @@ __global__ void refit_kernel(const PhotonRec* p, int n, const uint32_t* left, co
         for (int c = 0; c < 2; c++) {
             if (ch[c] & BVH_LEAF) {
                 float l[3], h[3];
-                leaf_box(p[ch[c] & 0x7FFFFFFFu], use_radius, l, h);
+                leaf_box(p[ch[c] & PH_LEAF_INDEX], use_radius, l, h);
                 for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], l[k]); hi[k] = fmaxf(hi[k], h[k]); }
             } else {
                 const volatile float* b = box + size_t(ch[c]) * 6;
@@ -287,8 +295,12 @@ __global__ void refit_kernel(const PhotonRec* p, int n, const uint32_t* left, co
         node = par;
     }
 }
+// leaf_max > 1 collapses every subtree of at most leaf_max photons into one leaf entry (its photons are a
+// contiguous run of the sorted array): fewer dependent node loads per k-NN query.  The internal nodes
+// below a collapsed entry stay in the array, unreferenced.
 __global__ void pack_kernel(const PhotonRec* p, int n, const uint32_t* left, const uint32_t* right, const float* box,
-                            BvhNode* nodes, int use_radius) {
+                            const uint32_t* range_lo, const uint32_t* range_hi, BvhNode* nodes, int use_radius,
+                            uint32_t leaf_max) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     BvhNode w;
@@ -296,10 +308,12 @@ __global__ void pack_kernel(const PhotonRec* p, int n, const uint32_t* left, con
     float lo[2][3], hi[2][3];
     for (int c = 0; c < 2; c++) {
         if (ch[c] & BVH_LEAF) {
-            leaf_box(p[ch[c] & 0x7FFFFFFFu], use_radius, lo[c], hi[c]);
+            leaf_box(p[ch[c] & PH_LEAF_INDEX], use_radius, lo[c], hi[c]);
         } else {
             const float* b = box + size_t(ch[c]) * 6;
             for (int k = 0; k < 3; k++) { lo[c][k] = b[k]; hi[c][k] = b[3 + k]; }
+            const uint32_t first = range_lo[ch[c]], count = range_hi[ch[c]] - first + 1u;
+            if (count <= leaf_max) ch[c] = BVH_LEAF | ((count - 1u) << 26) | first;
         }
     }
     for (int k = 0; k < 3; k++) { w.lo0[k] = lo[0][k]; w.hi0[k] = hi[0][k]; w.lo1[k] = lo[1][k]; w.hi1[k] = hi[1][k]; }
@@ -329,9 +343,11 @@ RPT_DEV void knn_walk(const BvhNode* nodes, const PhotonRec* p, uint32_t n, V q,
     uint32_t cur = 0;
     for (;;) {
         if (cur & BVH_LEAF) {
-            uint32_t idx = cur & 0x7FFFFFFFu;
-            V d = xyz(p[idx].pos_r) - q;
-            bound = visit(idx, dot(d, d));
+            const uint32_t first = cur & PH_LEAF_INDEX, count = ((cur >> 26) & 31u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                V d = xyz(p[first + k].pos_r) - q;
+                bound = visit(first + k, dot(d, d));
+            }
         } else {
             const BvhNode nd = nodes[cur];
             float d0 = box_dist2(nd.lo0, nd.hi0, q), d1 = box_dist2(nd.lo1, nd.hi1, q);
@@ -390,6 +406,7 @@ struct QueryArgs {
     uint32_t kind, gather_size, gather_size_volume;
     uint32_t* overflow;  // set to 1 if a beam-walk stack overflowed (the render is then rejected)
     uint32_t region_dwords;  // LDS dwords per wave: max(gather lists, beam stack + staging)
+    uint32_t skip;           // diagnostic (rpt_set_option "photon_skip"): 1 = no volume estimate, 2 = no surface estimate
 };
 
 // Batched wave-cooperative walk (used when the rays of a wave do not form a packet).  Walking one
@@ -416,7 +433,7 @@ RPT_DEV void beam_walk_batch(const BvhNode* nodes, const PhotonRec* photons, uin
         if (lane < b) {
             e = wstack[count - b + lane];
             if (e & BVH_LEAF) {
-                const PhotonRec ph = photons[e & 0x7FFFFFFFu];
+                const PhotonRec ph = photons[e & PH_LEAF_INDEX];
                 stage[lane * 4u + 0u] = ph.pos_r;
                 stage[lane * 4u + 1u] = ph.dir;
                 stage[lane * 4u + 2u] = ph.pow;
@@ -522,7 +539,7 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
             e = wstack[count - b + lane];
             leaf = (e & BVH_LEAF) != 0u;
             if (leaf) {
-                const PhotonRec ph = photons[e & 0x7FFFFFFFu];
+                const PhotonRec ph = photons[e & PH_LEAF_INDEX];
                 stage[lane * 4u + 0u] = ph.pos_r;
                 stage[lane * 4u + 1u] = ph.dir;
                 stage[lane * 4u + 2u] = ph.pow;
@@ -567,18 +584,21 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
 // kd-tree `nearests(q, K)`: the K photons of least squared distance, kept unsorted in the lane's LDS
 // column of its wave's region (gd[k * 64] = squared distances, gi[k * 64] = sorted-array indices).
 // Returns the number found.
+// `guess`: squared radius the search starts with instead of +inf.  If fewer than K photons lie inside it
+// the caller repeats the search unbounded, so the result is always the exact K nearest.
 RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, V x, uint32_t K, float* gd,
-                            uint32_t* gi, float& max_d2) {
+                            uint32_t* gi, float& max_d2, float guess = kInf) {
     uint32_t found = 0;
-    float bound = kInf, worst = 0.f;
+    float bound = guess, worst = 0.f;
     uint32_t worst_slot = 0;
     if (K > 0) {
         knn_walk(nodes, photons, n, x, bound, [&](uint32_t idx, float d2) {
             if (found < K) {
+                if (d2 > guess) return guess;
                 gd[found * 64u] = d2;
                 gi[found * 64u] = idx;
                 found++;
-                if (found < K) return kInf;
+                if (found < K) return guess;
             } else if (d2 < worst) {
                 gd[worst_slot * 64u] = d2;
                 gi[worst_slot * 64u] = idx;
@@ -627,6 +647,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
     uint32_t pool_next = 0, pool_end = 0;
     uint32_t pool_chunk = 0, pool_x0 = 0, pool_y0 = 0;  // wave-uniform: the batch's chunk and 8x8 block origin
     uint32_t c0 = 0, c1 = 0;
+    float prev_r2 = 0.f;  // squared radius of this lane's previous surface gather
     unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
     for (;;) {
         bool want = alive && s >= s_end;
@@ -729,7 +750,7 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                     surface_scale = __expf(-sigma_t * t) * rcp(tr_d);   // transmittance(t) / (1 - cdf), 1 - cdf = T(d)
                 }
             }
-        } else if (MEDIUM) {  // beam x point volume estimate, src/photon.rs:439-502
+        } else if (MEDIUM && !(q.skip & 1u)) {  // beam x point volume estimate, src/photon.rs:439-502
             V vc = mk(0, 0, 0);
             const float phase = sc.medium_phase;
             auto visit = [&](const PhotonRec& ph) {
@@ -794,14 +815,20 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
             acc = acc + env_color(sc, rd);  // src/photon.rs:597
             continue;
         }
-        if (surface_on) {  // surface estimate, src/photon.rs:327-375
+        if (surface_on && !(q.skip & 2u)) {  // surface estimate, src/photon.rs:327-375
             V n;
             uint32_t obj;
             finalize_hit(sc, ro, rd, tmin, t, code, inst, n, obj);
             const Mat mat = load_mat(sc, obj);
             const V x = fma3(t, rd, ro);
+            // Consecutive samples of a lane fall within a pixel of each other: the previous gather radius
+            // (squared, doubled) bounds this search from its first node; the rare miss is searched again.
             float max_d2;
-            const uint32_t found = gather_knn(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2);
+            const uint32_t want_k = min(q.gather_size, q.n_s);
+            uint32_t found = 0;
+            if (prev_r2 > 0.f) found = gather_knn(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2, 2.f * prev_r2);
+            if (found < want_k || !(prev_r2 > 0.f)) found = gather_knn(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2);
+            prev_r2 = max_d2;
             V sc_col = mat_emit(mat) * mat_color(mat);
             for (uint32_t k = 0; k < found; k++) {
                 const PhotonRec ph = q.s_ph[gi[k * 64u]];
@@ -908,7 +935,7 @@ int build_lbvh(PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t s
     Tmp tmp;
     float* lohi;
     uint64_t *keys, *keys2;
-    uint32_t *vals, *vals2, *left, *right, *par_i, *par_l, *flags;
+    uint32_t *vals, *vals2, *left, *right, *par_i, *par_l, *flags, *rlo, *rhi;
     float* box;
     RPTI_HIP_TRY(tmp.alloc(&lohi, 6));
     RPTI_HIP_TRY(tmp.alloc(&keys, n));
@@ -920,6 +947,8 @@ int build_lbvh(PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t s
     RPTI_HIP_TRY(tmp.alloc(&par_i, n));
     RPTI_HIP_TRY(tmp.alloc(&par_l, n));
     RPTI_HIP_TRY(tmp.alloc(&flags, n));
+    RPTI_HIP_TRY(tmp.alloc(&rlo, n));
+    RPTI_HIP_TRY(tmp.alloc(&rhi, n));
     RPTI_HIP_TRY(tmp.alloc(&box, size_t(n) * 6));
     const float inf = std::numeric_limits<float>::infinity();
     float init[6] = {inf, inf, inf, -inf, -inf, -inf};
@@ -936,10 +965,12 @@ int build_lbvh(PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t s
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, raw, vals2, n, out.sorted);
     if (n >= 2) {
         RPTI_HIP_TRY(hipMalloc((void**)&out.nodes, size_t(n - 1) * sizeof(BvhNode)));
-        hipLaunchKernelGGL(karras_kernel, dim3(blocks), dim3(256), 0, st, keys2, int(n), left, right, par_i, par_l);
+        hipLaunchKernelGGL(karras_kernel, dim3(blocks), dim3(256), 0, st, keys2, int(n), left, right, par_i, par_l, rlo, rhi);
         RPTI_HIP_TRY(hipMemsetAsync(flags, 0, size_t(n) * 4, st));
         hipLaunchKernelGGL(refit_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, par_i, par_l, flags, box, first_mode);
-        hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, out.nodes, first_mode);
+        // point trees are walked by the k-NN search only (radii, gathers): collapsed leaves
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, rlo, rhi, out.nodes,
+                           first_mode, first_mode == 0 ? kKnnLeaf : 1u);
     }
     if (with_radius) {
         float* radius;
@@ -949,7 +980,8 @@ int build_lbvh(PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t s
         if (n >= 2) {
             RPTI_HIP_TRY(hipMemsetAsync(flags, 0, size_t(n) * 4, st));
             hipLaunchKernelGGL(refit_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, par_i, par_l, flags, box, 1);
-            hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, out.nodes, 1);
+            hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, rlo, rhi, out.nodes, 1,
+                               1u);  // sphere tree for the beam walkers: one photon per leaf
         }
     }
     RPTI_HIP_TRY(hipGetLastError());
@@ -1016,7 +1048,7 @@ static int shoot_range(rpt_scene* s, PhotonMapDev* pm, uint64_t photon_count, ui
         os[i] = ts; ts += cs[i];
         ov[i] = tv; tv += cv[i];
     }
-    if (ts >= (1ull << 31) || tv >= (1ull << 31)) return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons");
+    if (ts >= (1ull << 26) || tv >= (1ull << 26)) return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons (2^26 records per map)");
     uint64_t *d_os, *d_ov;
     RPTI_HIP_TRY(tmp.alloc(&d_os, n));
     RPTI_HIP_TRY(tmp.alloc(&d_ov, n));
@@ -1042,7 +1074,7 @@ static int shoot_range(rpt_scene* s, PhotonMapDev* pm, uint64_t photon_count, ui
 
 // Sort + LBVH (+ radii) over record arrays that live on this scene's device.
 static int build_maps(PhotonMapDev* pm, const PhotonRec* d_s, uint64_t n_s, const PhotonRec* d_v, uint64_t n_v) {
-    if (n_s >= (1ull << 31) || n_v >= (1ull << 31)) return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons");
+    if (n_s >= (1ull << 26) || n_v >= (1ull << 26)) return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons (2^26 records per map)");
     hipStream_t st = nullptr;
     hipEvent_t e1, e2;
     RPTI_HIP_TRY(hipEventCreate(&e1));
@@ -1197,6 +1229,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     q.s_nodes = pm->surf.nodes; q.s_ph = pm->surf.sorted; q.n_s = pm->surf.n;
     q.v_nodes = pm->vol.nodes; q.v_ph = pm->vol.sorted; q.n_v = pm->vol.n;
     q.kind = uint32_t(pm->kind);
+    q.skip = uint32_t(rpti::option_photon_skip());
     q.gather_size = uint32_t(gather_size);
     q.gather_size_volume = pm->kind == RPT_PHOTON_MAP ? uint32_t(gather_size_volume) : 0u;  // only the point-point estimate gathers in the volume
     const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_nodes != 0;

@@ -50,6 +50,10 @@ static int64_t g_opt_counters = 0;
 static int64_t g_opt_chunk_spp = 0;  // 0 = auto: ceil(iterations / 64) clamped to [2, 32]
 static int64_t g_opt_blocks_per_cu = 0;  // 0 = occupancy query
 static int64_t g_opt_timing = 0;
+static int64_t g_opt_photon_skip = 0;
+namespace rpti {
+int64_t option_photon_skip() { return g_opt_photon_skip; }
+}
 static int64_t g_opt_instancing = 1;     // meshes shared by several shapes are stored once and instanced
 static int64_t g_opt_scene_bvh_min = 64;  // bounded primitives + BVH meshes from which the scene-level BVH is built
 
@@ -466,6 +470,7 @@ int rpt_set_option(const char* name, int64_t value) {
     else if (s == "chunk_spp") { if (value < 0) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 0 (0 = auto)"); g_opt_chunk_spp = value; }
     else if (s == "blocks_per_cu") g_opt_blocks_per_cu = value;
     else if (s == "timing") g_opt_timing = value;
+    else if (s == "photon_skip") g_opt_photon_skip = value;
     else if (s == "instancing") g_opt_instancing = value;
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); g_opt_scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option " + s);
