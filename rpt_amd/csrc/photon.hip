@@ -419,9 +419,9 @@ struct QueryArgs {
 // wave-private LDS stack of kBeamCap entries; near the cap the walk degrades to depth-first (batch
 // of 1), whose extra footprint is bounded by the tree depth.  *overflow is set if even that fails.
 static constexpr uint32_t kBeamCap = 1024;
-template <class F>
+template <class G, class F>
 RPT_DEV void beam_walk_batch(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
-                             uint32_t* wstack, F4* stage, uint32_t* overflow, F&& visit) {
+                             uint32_t* wstack, F4* stage, uint32_t* overflow, G&& prep, F&& visit) {
     if (n == 0) return;
     const uint32_t lane = threadIdx.x & 63u;
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
@@ -433,7 +433,7 @@ RPT_DEV void beam_walk_batch(const BvhNode* nodes, const PhotonRec* photons, uin
         if (lane < b) {
             e = wstack[count - b + lane];
             if (e & BVH_LEAF) {
-                const PhotonRec ph = photons[e & PH_LEAF_INDEX];
+                const PhotonRec ph = prep(photons[e & PH_LEAF_INDEX]);
                 stage[lane * 4u + 0u] = ph.pos_r;
                 stage[lane * 4u + 1u] = ph.dir;
                 stage[lane * 4u + 2u] = ph.pow;
@@ -501,9 +501,11 @@ RPT_DEV bool box_outside(const float lo[3], const float hi[3], V o, V nrm) {
     float reach = fabsf(nrm.x) * h.x + fabsf(nrm.y) * h.y + fabsf(nrm.z) * h.z;
     return dot(nrm, c) + reach < 0.f;
 }
-template <class F>
+// SPHERES: the leaves are photon spheres (pos_r = centre, radius): a leaf is staged only if the sphere
+// itself reaches into the frustum (its box, which is all the parent node knows, is ~1.5x looser).
+template <bool SPHERES, class G, class F>
 RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
-                              uint32_t* wstack, F4* stage, uint32_t* overflow, F&& visit) {
+                              uint32_t* wstack, F4* stage, uint32_t* overflow, G&& prep, F&& visit) {
     if (n == 0) return true;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t act = __ballot(active);
@@ -526,6 +528,9 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
     const float umin = wave_min(active ? pu : kInf) - pad, umax = wave_max(active ? pu : -kInf) + pad;
     const float vmin = wave_min(active ? pv : kInf) - pad, vmax = wave_max(active ? pv : -kInf) + pad;
     const V nl = fma3(-umin, m, u), nr = fma3(umax, m, -u), nb = fma3(-vmin, m, v), nt = fma3(vmax, m, -v);
+    // u, v, m are orthonormal: |n| = sqrt(1 + bound^2)
+    const float ll = __builtin_sqrtf(fmaf(umin, umin, 1.f)), lr = __builtin_sqrtf(fmaf(umax, umax, 1.f));
+    const float lb = __builtin_sqrtf(fmaf(vmin, vmin, 1.f)), lt = __builtin_sqrtf(fmaf(vmax, vmax, 1.f));
 
     uint32_t count = 1;  // wave-uniform
     if (lane == 0) wstack[0] = (n == 1) ? BVH_LEAF : 0u;
@@ -535,14 +540,19 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
         uint32_t e = 0u;
         bool s0 = false, s1 = false, leaf = false;
         uint32_t c0 = 0u, c1 = 0u;
+        PhotonRec staged{};
         if (mine) {
             e = wstack[count - b + lane];
             leaf = (e & BVH_LEAF) != 0u;
             if (leaf) {
-                const PhotonRec ph = photons[e & PH_LEAF_INDEX];
-                stage[lane * 4u + 0u] = ph.pos_r;
-                stage[lane * 4u + 1u] = ph.dir;
-                stage[lane * 4u + 2u] = ph.pow;
+                const PhotonRec raw = photons[e & PH_LEAF_INDEX];
+                if (SPHERES) {
+                    const V c = xyz(raw.pos_r) - o0;
+                    const float r = raw.pos_r.w;
+                    leaf = !(dot(m, c) < -r || dot(nl, c) < -r * ll || dot(nr, c) < -r * lr || dot(nb, c) < -r * lb ||
+                             dot(nt, c) < -r * lt);
+                }
+                if (leaf) staged = prep(raw, o0);
             } else {
                 const BvhNode nd = nodes[e];
                 c0 = nd.e0;
@@ -564,12 +574,20 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
             if (s1) wstack[count + n0 + __builtin_amdgcn_mbcnt_hi(uint32_t(m1 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m1), 0u))] = c1;
             count += n0 + n1;
         }
+        // the surviving leaves are staged densely (ballot prefix), so the test loop below is a plain counted
+        // loop the compiler can unroll: several photons' LDS reads are in flight before the first test
+        const uint64_t lm = __ballot(leaf);
+        const uint32_t n_leaf = uint32_t(__popcll(lm));
+        if (leaf) {
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi(uint32_t(lm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(lm), 0u));
+            stage[slot * 4u + 0u] = staged.pos_r;
+            stage[slot * 4u + 1u] = staged.dir;
+            stage[slot * 4u + 2u] = staged.pow;
+        }
         __builtin_amdgcn_wave_barrier();
         // exact per-ray test of the staged photons
-        uint64_t lm = __ballot(leaf);
-        while (lm) {
-            const uint32_t j = uint32_t(__ffsll((unsigned long long)lm)) - 1u;
-            lm &= lm - 1;
+#pragma unroll 4
+        for (uint32_t j = 0; j < n_leaf; j++) {
             PhotonRec ph;
             ph.pos_r = stage[j * 4u + 0u];
             ph.dir = stage[j * 4u + 1u];
@@ -753,18 +771,55 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
         } else if (MEDIUM && !(q.skip & 1u)) {  // beam x point volume estimate, src/photon.rs:439-502
             V vc = mk(0, 0, 0);
             const float phase = sc.medium_phase;
+            // The staging lane pre-computes what depends on the photon only: pos_r.w = r^2, pow = power *
+            // 3/pi * phase / r^2, pow.w = 1/r^2 (src/photon.rs:474-493: k2(d^2/r^2)/r^2 with k2(x) = 3/pi (1-x)^2).
+            auto prep_point = [&](PhotonRec ph) {
+                const float r2 = ph.pos_r.w * ph.pos_r.w, ir2 = rcp(r2), kk = (3.f * kInvPi) * phase * ir2;
+                ph.pos_r.w = r2;
+                ph.pow = F4{ph.pow.x * kk, ph.pow.y * kk, ph.pow.z * kk, ir2};
+                return ph;
+            };
             auto visit = [&](const PhotonRec& ph) {
                 c_leaf++;
                 V otc = xyz(ph.pos_r) - ro;
-                float r2 = ph.pos_r.w * ph.pos_r.w;
                 float disk = dot(otc, rd);
                 V dv = fma3(disk, rd, ro) - xyz(ph.pos_r);
                 float dist2 = dot(dv, dv);
-                bool ok = disk > 0.f && dist2 < r2 && !(hit && dot(otc, otc) > t * t);
+                bool ok = disk > 0.f && dist2 < ph.pos_r.w && !(hit && dot(otc, otc) > t * t);
                 if (ok) {
                     c_acc++;
-                    float tmp = 1.f - dist2 * rcp(r2);
-                    float w = (3.f * kInvPi) * tmp * tmp * rcp(r2) * __expf(-sigma_t * disk) * phase;
+                    float tmp = 1.f - dist2 * ph.pow.w;
+                    float w = tmp * tmp * __expf(-sigma_t * disk);
+                    vc = fma3(w, xyz(ph.pow), vc);
+                }
+            };
+            auto prep_none = [](const PhotonRec& ph) { return ph; };
+            // Packet form (every ray of the wave starts at o0): what depends on the photon and the common origin
+            // is computed once by the staging lane -- c = centre - o0, |c|^2, |c|, and the power pre-multiplied by
+            // 3/pi * phase / r^2 * exp(-sigma_t |c|); per ray exp(-sigma_t s) = exp(-sigma_t |c|) * exp(sigma_t (|c| - s))
+            // with sigma_t (|c| - s) <= sigma_t r^2 / |c| ~ 1e-5, so the second factor is 1 + x to fp32 precision.
+            const float t2 = hit ? t * t : kInf;
+            auto prep_packet = [&](PhotonRec ph, const V& o0) {
+                const V c = xyz(ph.pos_r) - o0;
+                const float r2 = ph.pos_r.w * ph.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = __builtin_sqrtf(c2);
+                const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
+                ph.pos_r = F4{c.x, c.y, c.z, r2};
+                ph.dir = F4{c2, len, ir2, 0.f};
+                ph.pow = F4{ph.pow.x * kk, ph.pow.y * kk, ph.pow.z * kk, 0.f};
+                return ph;
+            };
+            auto visit_packet = [&](const PhotonRec& ph) {
+                if (q.skip & 4u) return;  // diagnostic: tree walk and staging only
+                c_leaf++;
+                const V c = xyz(ph.pos_r);
+                const float disk = dot(c, rd);
+                const V dv = fma3(disk, rd, -c);
+                const float dist2 = dot(dv, dv);
+                const bool ok = disk > 0.f && dist2 < ph.pos_r.w && ph.dir.x <= t2;
+                if (ok) {
+                    c_acc++;
+                    const float tmp = 1.f - dist2 * ph.dir.z;
+                    const float w = tmp * tmp * fmaf(sigma_t, ph.dir.y - disk, 1.f);
                     vc = fma3(w, xyz(ph.pow), vc);
                 }
             };
@@ -802,11 +857,12 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                 }
             };
             if (q.kind == RPT_PHOTON_BEAM_BEAM) {
-                if (!beam_walk_packet(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit_beam))
-                    beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit_beam);
+                if (!beam_walk_packet<false>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow,
+                                             [](const PhotonRec& ph, const V&) { return ph; }, visit_beam))
+                    beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_none, visit_beam);
             } else {
-                if (!beam_walk_packet(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit))
-                    beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, visit);
+                if (!beam_walk_packet<true>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_packet, visit_packet))
+                    beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_point, visit);
             }
             color = vc * mcol0;
         }
