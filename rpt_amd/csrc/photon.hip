@@ -407,6 +407,8 @@ struct QueryArgs {
     uint32_t* overflow;  // set to 1 if a beam-walk stack overflowed (the render is then rejected)
     uint32_t region_dwords;  // LDS dwords per wave: max(gather lists, beam stack + staging)
     uint32_t skip;           // diagnostic (rpt_set_option "photon_skip"): 1 = no volume estimate, 2 = no surface estimate
+    uint32_t* cand;          // [waves of the grid][cand_cap] candidate photons of each wave's current pixel block
+    uint32_t cand_cap;       // 0: no candidate lists (every sample walks the tree)
 };
 
 // Batched wave-cooperative walk (used when the rays of a wave do not form a packet).  Walking one
@@ -419,6 +421,7 @@ struct QueryArgs {
 // wave-private LDS stack of kBeamCap entries; near the cap the walk degrades to depth-first (batch
 // of 1), whose extra footprint is bounded by the tree depth.  *overflow is set if even that fails.
 static constexpr uint32_t kBeamCap = 1024;
+static constexpr uint32_t kCandCap = 4096;  // candidate photons one wave keeps per 8x8 pixel block (global memory)
 template <class G, class F>
 RPT_DEV void beam_walk_batch(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
                              uint32_t* wstack, F4* stage, uint32_t* overflow, G&& prep, F&& visit) {
@@ -479,13 +482,7 @@ RPT_DEV void beam_walk_batch(const BvhNode* nodes, const PhotonRec* photons, uin
     }
 }
 
-// Packet walk: when the live lanes' rays share one origin (pinhole camera, one pixel tile per wave)
-// the inner nodes are not tested per ray at all.  The wave bounds its 64 directions by a four-plane
-// frustum through the common origin; each lane then culls a DIFFERENT pending node's two child boxes
-// against that frustum (64 nodes per instruction stream instead of one), survivors are pushed with a
-// ballot/mbcnt prefix, and only photon records reach the per-ray test (staged in LDS, broadcast to
-// all lanes).  Culling is conservative, the per-photon test is the exact one, so the sum equals the
-// brute-force sum over all photons.  Returns false (nothing done) if the rays do not form a packet.
+// ---- ray packets: the wave bounds its directions by a four-plane frustum through the common origin
 RPT_DEV float wave_min(float v) {
     for (int off = 32; off; off >>= 1) v = fminf(v, __shfl_xor(v, off));
     return v;
@@ -501,37 +498,69 @@ RPT_DEV bool box_outside(const float lo[3], const float hi[3], V o, V nrm) {
     float reach = fabsf(nrm.x) * h.x + fabsf(nrm.y) * h.y + fabsf(nrm.z) * h.z;
     return dot(nrm, c) + reach < 0.f;
 }
-// SPHERES: the leaves are photon spheres (pos_r = centre, radius): a leaf is staged only if the sphere
-// itself reaches into the frustum (its box, which is all the parent node knows, is ~1.5x looser).
-template <bool SPHERES, class G, class F>
-RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
-                              uint32_t* wstack, F4* stage, uint32_t* overflow, G&& prep, F&& visit) {
-    if (n == 0) return true;
-    const uint32_t lane = threadIdx.x & 63u;
+// The frustum of a ray packet: common origin o0, central axis m and four side planes through o0 with
+// inward normals (not normalised; ll..lt are their lengths).
+struct Frustum {
+    V o0, m, nl, nr, nb, nt;
+    float ll, lr, lb, lt;
+};
+// Bounds `nd` directions per live lane (all from one origin).  false if the lanes do not share an origin or
+// a direction is more than 60 degrees off the first lane's.
+RPT_DEV bool frustum_from_dirs(bool active, V o, const V* dirs, int nd, Frustum& fr) {
     const uint64_t act = __ballot(active);
-    if (act == 0) return true;
-    // common origin?
+    if (act == 0) return false;
     const uint32_t first = uint32_t(__ffsll((unsigned long long)act)) - 1u;
     auto bcast = [&](float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), first)); };
     const V o0 = mk(bcast(o.x), bcast(o.y), bcast(o.z));
-    const V m = normalize(mk(bcast(d.x), bcast(d.y), bcast(d.z)));
-    const float dm = dot(d, m);
-    const bool fits = !active || (o.x == o0.x && o.y == o0.y && o.z == o0.z && dm > 0.5f);
-    if (__ballot(!fits) != 0) return false;
+    const V m = normalize(mk(bcast(dirs[0].x), bcast(dirs[0].y), bcast(dirs[0].z)));
     // orthonormal basis around m (Duff et al.), perspective coordinates of every live direction
     const float sg = __builtin_copysignf(1.f, m.z);
     const float aa = -1.f / (sg + m.z), bb = m.x * m.y * aa;
     const V u = mk(1.f + sg * m.x * m.x * aa, sg * bb, -sg * m.x), v = mk(bb, sg + m.y * m.y * aa, -m.y);
-    const float idm = rcp(dm);
-    const float pu = active ? dot(d, u) * idm : 0.f, pv = active ? dot(d, v) * idm : 0.f;
+    bool fits = !active || (o.x == o0.x && o.y == o0.y && o.z == o0.z);
+    float ulo = kInf, uhi = -kInf, vlo = kInf, vhi = -kInf;
+    for (int k = 0; k < nd; k++) {
+        const float dm = dot(dirs[k], m);
+        fits = fits && (!active || dm > 0.5f * __builtin_sqrtf(dot(dirs[k], dirs[k])));
+        const float idm = rcp(dm);
+        const float pu = dot(dirs[k], u) * idm, pv = dot(dirs[k], v) * idm;
+        if (active) {
+            ulo = fminf(ulo, pu); uhi = fmaxf(uhi, pu);
+            vlo = fminf(vlo, pv); vhi = fmaxf(vhi, pv);
+        }
+    }
+    if (__ballot(!fits) != 0) return false;
     const float pad = 1e-5f;
-    const float umin = wave_min(active ? pu : kInf) - pad, umax = wave_max(active ? pu : -kInf) + pad;
-    const float vmin = wave_min(active ? pv : kInf) - pad, vmax = wave_max(active ? pv : -kInf) + pad;
-    const V nl = fma3(-umin, m, u), nr = fma3(umax, m, -u), nb = fma3(-vmin, m, v), nt = fma3(vmax, m, -v);
+    const float umin = wave_min(ulo) - pad, umax = wave_max(uhi) + pad;
+    const float vmin = wave_min(vlo) - pad, vmax = wave_max(vhi) + pad;
+    // every field is wave-uniform: moved to scalar registers (22 VGPRs per frustum otherwise)
+    auto uni = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+    auto uni3 = [&](V x) { return mk(uni(x.x), uni(x.y), uni(x.z)); };
+    fr.o0 = uni3(o0);
+    fr.m = uni3(m);
+    fr.nl = uni3(fma3(-umin, m, u)); fr.nr = uni3(fma3(umax, m, -u));
+    fr.nb = uni3(fma3(-vmin, m, v)); fr.nt = uni3(fma3(vmax, m, -v));
     // u, v, m are orthonormal: |n| = sqrt(1 + bound^2)
-    const float ll = __builtin_sqrtf(fmaf(umin, umin, 1.f)), lr = __builtin_sqrtf(fmaf(umax, umax, 1.f));
-    const float lb = __builtin_sqrtf(fmaf(vmin, vmin, 1.f)), lt = __builtin_sqrtf(fmaf(vmax, vmax, 1.f));
-
+    fr.ll = uni(__builtin_sqrtf(fmaf(umin, umin, 1.f))); fr.lr = uni(__builtin_sqrtf(fmaf(umax, umax, 1.f)));
+    fr.lb = uni(__builtin_sqrtf(fmaf(vmin, vmin, 1.f))); fr.lt = uni(__builtin_sqrtf(fmaf(vmax, vmax, 1.f)));
+    return true;
+}
+RPT_DEV bool sphere_outside(const Frustum& fr, const F4& pos_r) {
+    const V c = xyz(pos_r) - fr.o0;
+    const float r = pos_r.w;
+    return dot(fr.m, c) < -r || dot(fr.nl, c) < -r * fr.ll || dot(fr.nr, c) < -r * fr.lr || dot(fr.nb, c) < -r * fr.lb ||
+           dot(fr.nt, c) < -r * fr.lt;
+}
+// Walk of the photon tree against a frustum: each lane culls a DIFFERENT pending node's two child boxes (64
+// nodes per instruction stream), survivors are pushed with a ballot prefix onto the wave-private LDS stack.
+// `leaves(is_leaf, entry, record)` is called wave-convergently once per batch of up to 64 popped entries;
+// SPHERES: a leaf counts only if the photon sphere itself (pos_r = centre, radius) reaches into the frustum
+// (its box, which is all the parent node knows, is ~1.5x looser).
+template <bool SPHERES, class L>
+RPT_DEV void frustum_walk(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, const Frustum& fr, uint32_t* wstack,
+                          uint32_t* overflow, L&& leaves) {
+    if (n == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t count = 1;  // wave-uniform
     if (lane == 0) wstack[0] = (n == 1) ? BVH_LEAF : 0u;
     while (count != 0) {
@@ -540,27 +569,23 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
         uint32_t e = 0u;
         bool s0 = false, s1 = false, leaf = false;
         uint32_t c0 = 0u, c1 = 0u;
-        PhotonRec staged{};
+        PhotonRec raw{};
         if (mine) {
             e = wstack[count - b + lane];
             leaf = (e & BVH_LEAF) != 0u;
             if (leaf) {
-                const PhotonRec raw = photons[e & PH_LEAF_INDEX];
-                if (SPHERES) {
-                    const V c = xyz(raw.pos_r) - o0;
-                    const float r = raw.pos_r.w;
-                    leaf = !(dot(m, c) < -r || dot(nl, c) < -r * ll || dot(nr, c) < -r * lr || dot(nb, c) < -r * lb ||
-                             dot(nt, c) < -r * lt);
-                }
-                if (leaf) staged = prep(raw, o0);
+                raw = photons[e & PH_LEAF_INDEX];
+                if (SPHERES) leaf = !sphere_outside(fr, raw.pos_r);
             } else {
                 const BvhNode nd = nodes[e];
                 c0 = nd.e0;
                 c1 = nd.e1;
-                s0 = !(box_outside(nd.lo0, nd.hi0, o0, m) || box_outside(nd.lo0, nd.hi0, o0, nl) || box_outside(nd.lo0, nd.hi0, o0, nr) ||
-                       box_outside(nd.lo0, nd.hi0, o0, nb) || box_outside(nd.lo0, nd.hi0, o0, nt));
-                s1 = !(box_outside(nd.lo1, nd.hi1, o0, m) || box_outside(nd.lo1, nd.hi1, o0, nl) || box_outside(nd.lo1, nd.hi1, o0, nr) ||
-                       box_outside(nd.lo1, nd.hi1, o0, nb) || box_outside(nd.lo1, nd.hi1, o0, nt));
+                s0 = !(box_outside(nd.lo0, nd.hi0, fr.o0, fr.m) || box_outside(nd.lo0, nd.hi0, fr.o0, fr.nl) ||
+                       box_outside(nd.lo0, nd.hi0, fr.o0, fr.nr) || box_outside(nd.lo0, nd.hi0, fr.o0, fr.nb) ||
+                       box_outside(nd.lo0, nd.hi0, fr.o0, fr.nt));
+                s1 = !(box_outside(nd.lo1, nd.hi1, fr.o0, fr.m) || box_outside(nd.lo1, nd.hi1, fr.o0, fr.nl) ||
+                       box_outside(nd.lo1, nd.hi1, fr.o0, fr.nr) || box_outside(nd.lo1, nd.hi1, fr.o0, fr.nb) ||
+                       box_outside(nd.lo1, nd.hi1, fr.o0, fr.nt));
             }
         }
         count -= b;
@@ -574,34 +599,52 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
             if (s1) wstack[count + n0 + __builtin_amdgcn_mbcnt_hi(uint32_t(m1 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m1), 0u))] = c1;
             count += n0 + n1;
         }
-        // the surviving leaves are staged densely (ballot prefix), so the test loop below is a plain counted
-        // loop the compiler can unroll: several photons' LDS reads are in flight before the first test
-        const uint64_t lm = __ballot(leaf);
-        const uint32_t n_leaf = uint32_t(__popcll(lm));
-        if (leaf) {
-            const uint32_t slot = __builtin_amdgcn_mbcnt_hi(uint32_t(lm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(lm), 0u));
-            stage[slot * 4u + 0u] = staged.pos_r;
-            stage[slot * 4u + 1u] = staged.dir;
-            stage[slot * 4u + 2u] = staged.pow;
-        }
         __builtin_amdgcn_wave_barrier();
-        // exact per-ray test of the staged photons
-#pragma unroll 4
-        for (uint32_t j = 0; j < n_leaf; j++) {
-            PhotonRec ph;
-            ph.pos_r = stage[j * 4u + 0u];
-            ph.dir = stage[j * 4u + 1u];
-            ph.pow = stage[j * 4u + 2u];
-            if (active) visit(ph);
-        }
+        leaves(leaf, e & PH_LEAF_INDEX, raw);
         __builtin_amdgcn_wave_barrier();
     }
+}
+// The lanes flagged `take` store their prepared record densely in the staging slots (ballot prefix), then
+// every live ray tests every staged record: a counted loop, so several records' LDS reads are in flight.
+template <class F>
+RPT_DEV void stage_and_test(bool take, const PhotonRec& staged, F4* stage, bool active, F&& visit) {
+    const uint64_t lm = __ballot(take);
+    const uint32_t n_leaf = uint32_t(__popcll(lm));
+    __builtin_amdgcn_wave_barrier();
+    if (take) {
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi(uint32_t(lm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(lm), 0u));
+        stage[slot * 4u + 0u] = staged.pos_r;
+        stage[slot * 4u + 1u] = staged.dir;
+        stage[slot * 4u + 2u] = staged.pow;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+    for (uint32_t j = 0; j < n_leaf; j++) {
+        PhotonRec ph;
+        ph.pos_r = stage[j * 4u + 0u];
+        ph.dir = stage[j * 4u + 1u];
+        ph.pow = stage[j * 4u + 2u];
+        if (active) visit(ph);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// Packet walk: when the live lanes' rays share one origin (pinhole camera, one pixel tile per wave) the
+// inner nodes are not tested per ray at all.  Conservative culling + exact per-ray test of every staged
+// photon => the sum equals the brute-force sum.  Returns false if the rays do not form a packet.
+template <bool SPHERES, class G, class F>
+RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
+                              uint32_t* wstack, F4* stage, uint32_t* overflow, G&& prep, F&& visit) {
+    if (n == 0) return true;
+    if (__ballot(active) == 0) return true;
+    Frustum fr;
+    if (!frustum_from_dirs(active, o, &d, 1, fr)) return false;
+    frustum_walk<SPHERES>(nodes, photons, n, fr, wstack, overflow, [&](bool leaf, uint32_t, const PhotonRec& raw) {
+        PhotonRec staged{};
+        if (leaf) staged = prep(raw, fr.o0);
+        stage_and_test(leaf, staged, stage, active, visit);
+    });
     return true;
 }
-
-// kd-tree `nearests(q, K)`: the K photons of least squared distance, kept unsorted in the lane's LDS
-// column of its wave's region (gd[k * 64] = squared distances, gi[k * 64] = sorted-array indices).
-// Returns the number found.
 // `guess`: squared radius the search starts with instead of +inf.  If fewer than K photons lie inside it
 // the caller repeats the search unbounded, so the result is always the exact K nearest.
 RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, V x, uint32_t K, float* gd,
@@ -639,7 +682,7 @@ RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
 template <bool MEDIUM, bool BVH>
-__global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
+__global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q) {
     extern __shared__ uint32_t dyn_lds[];
     const RenderArgs& a = q.r;
     const SceneView& sc = a.sc;
@@ -667,9 +710,20 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
     uint32_t c0 = 0, c1 = 0;
     float prev_r2 = 0.f;  // squared radius of this lane's previous surface gather
     unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
+    // Beam x point estimate with a pinhole camera: the lanes of a wave work through one 8x8 pixel block of
+    // one chunk in lockstep, and all samples of a pixel stay inside its footprint.  The photon spheres that
+    // reach into the block's frustum are therefore found ONCE per work batch (one tree walk) and kept in a
+    // per-wave list in global memory; every sample then only stages and tests those candidates.
+    uint32_t* const cand = q.cand_cap ? q.cand + size_t(blockIdx.x * 4u + wave_) * q.cand_cap : nullptr;
+    const bool cand_mode = MEDIUM && q.kind == RPT_PHOTON_POINT_BEAM && q.cand_cap != 0u && a.cam.aperture <= 0.f && !(q.skip & 1u);
+    uint32_t cand_n = 0;       // wave-uniform
+    bool cand_valid = false;   // wave-uniform: the list describes the block every live lane is working on
+    bool cand_fresh = false;   // wave-uniform: a full batch was just handed out, build its list
     for (;;) {
         bool want = alive && s >= s_end;
         if (__any(want)) {
+            cand_valid = false;
+            cand_fresh = false;
             if (want && have_item) {
                 reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(acc.x, acc.y, acc.z, 0.f);
                 have_item = false;
@@ -705,6 +759,8 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
                 const uint32_t item = pool_next + rank;
                 const bool got = want && rank < take;
+                // all 64 lanes take one whole, unclipped batch: they will sample the same 8x8 block in lockstep
+                cand_fresh = cand_mode && m == ~0ull && take == 64u && pool_x0 + 8u <= a.width && pool_y0 + 8u <= a.height;
                 pool_next += take;
                 if (got) {
                     const uint32_t chunk = pool_chunk, l = item & 63u;
@@ -724,6 +780,30 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
             }
         }
         if (!__any(alive)) break;
+        if (cand_mode && cand_fresh) {  // wave-uniform
+            cand_fresh = false;
+            // corner directions of this lane's pixel footprint (jitter is within +-inv_dim of the centre)
+            const V right = mk(a.cam.right[0], a.cam.right[1], a.cam.right[2]), up = mk(a.cam.up[0], a.cam.up[1], a.cam.up[2]);
+            const V eye = mk(a.cam.eye[0], a.cam.eye[1], a.cam.eye[2]);
+            const V centre = mk(a.cam.ddir[0], a.cam.ddir[1], a.cam.ddir[2]) + xn * right + yn * up;
+            const float e = a.inv_dim * 1.0001f;
+            const V corners[4] = {centre + (-e) * right + (-e) * up, centre + e * right + (-e) * up,
+                                  centre + (-e) * right + e * up, centre + e * right + e * up};
+            Frustum fr;
+            if (frustum_from_dirs(true, eye, corners, 4, fr)) {
+                uint32_t n_list = 0;  // wave-uniform
+                frustum_walk<true>(q.v_nodes, q.v_ph, q.n_v, fr, wstack, q.overflow, [&](bool leaf, uint32_t idx, const PhotonRec&) {
+                    const uint64_t lm = __ballot(leaf);
+                    if (leaf) {
+                        const uint32_t slot = n_list + __builtin_amdgcn_mbcnt_hi(uint32_t(lm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(lm), 0u));
+                        if (slot < q.cand_cap) cand[slot] = idx;
+                    }
+                    n_list += uint32_t(__popcll(lm));
+                });
+                cand_n = n_list;
+                cand_valid = n_list <= q.cand_cap;  // an overfull list is dropped: those samples walk the tree
+            }
+        }
 
         // ---- one camera sample per live lane (dead lanes idle but stay in the wave-level votes)
         const bool active = alive;
@@ -860,6 +940,21 @@ __global__ __launch_bounds__(256) void photon_query_kernel(const QueryArgs q) {
                 if (!beam_walk_packet<false>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow,
                                              [](const PhotonRec& ph, const V&) { return ph; }, visit_beam))
                     beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_none, visit_beam);
+            } else if (cand_valid) {
+                // this sample's own (tighter) frustum re-culls the block's candidates while they are staged
+                Frustum fs;
+                const bool have_fs = frustum_from_dirs(active, ro, &rd, 1, fs);
+                for (uint32_t base = 0; base < cand_n; base += 64u) {  // wave-uniform loop
+                    const bool mine = base + lane_ < cand_n;
+                    PhotonRec staged{};
+                    bool take = false;
+                    if (mine) {
+                        const PhotonRec raw = q.v_ph[cand[base + lane_]];
+                        take = !have_fs || !sphere_outside(fs, raw.pos_r);
+                        if (take) staged = prep_packet(raw, ro);
+                    }
+                    stage_and_test(take, staged, stage, active, visit_packet);
+                }
             } else {
                 if (!beam_walk_packet<true>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_packet, visit_packet))
                     beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_point, visit);
@@ -949,6 +1044,8 @@ struct PhotonMapDev {
     uint64_t n_raw_s = 0, n_raw_v = 0;
     double build_ms[4] = {0, 0, 0, 0};  // shoot, sort+build, radii, total
     uint32_t* d_overflow = nullptr;
+    uint32_t* d_cand = nullptr;  // per-wave candidate lists of the camera pass
+    size_t cand_words = 0;
     void release_raw() {
         (void)hipFree(raw_s); (void)hipFree(raw_v);
         raw_s = raw_v = nullptr;
@@ -959,8 +1056,11 @@ struct PhotonMapDev {
         (void)hipFree(surf.nodes); (void)hipFree(surf.sorted);
         (void)hipFree(vol.nodes); (void)hipFree(vol.sorted);
         (void)hipFree(d_overflow);
+        (void)hipFree(d_cand);
         release_raw();
         d_overflow = nullptr;
+        d_cand = nullptr;
+        cand_words = 0;
         surf = DevLbvh{};
         vol = DevLbvh{};
         built = false;
@@ -1280,7 +1380,8 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         return rpti::fail(RPT_ERR_UNSUPPORTED, "gather sizes > 56 do not fit the LDS gather list");
     const uint64_t gather_lds = pm->kind == RPT_PHOTON_MAP ? std::max(gather_size, gather_size_volume) : gather_size;
     QueryArgs q{};
-    int rc = rpti::prepare_render(s, cam, prm, num_samples, seed, sample_offset, q.r);
+    // work items of up to 16 samples: the per-block candidate list of the beam query is built once per item
+    int rc = rpti::prepare_render(s, cam, prm, num_samples, seed, sample_offset, q.r, 16);
     if (rc) return rc;
     q.s_nodes = pm->surf.nodes; q.s_ph = pm->surf.sorted; q.n_s = pm->surf.n;
     q.v_nodes = pm->vol.nodes; q.v_ph = pm->vol.sorted; q.n_v = pm->vol.n;
@@ -1307,6 +1408,18 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         return hipGetLastError();
     };
     int bpc = int(std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / std::max<size_t>(lds, 1))));
+    if (pm->kind == RPT_PHOTON_POINT_BEAM && medium && pm->vol.n) {
+        const size_t words = size_t(rpti::scene_dev(s).n_cus) * size_t(bpc) * 4u * kCandCap;
+        if (words > pm->cand_words) {
+            (void)hipFree(pm->d_cand);
+            pm->d_cand = nullptr;
+            pm->cand_words = 0;
+            RPTI_HIP_TRY(hipMalloc((void**)&pm->d_cand, words * 4u));
+            pm->cand_words = words;
+        }
+        q.cand = pm->d_cand;
+        q.cand_cap = kCandCap;
+    }
     rc = rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch);
     if (rc == RPT_OK && sync_counters) {
         uint32_t ov = 0;
