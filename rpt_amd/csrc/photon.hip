@@ -991,7 +991,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 float len = len2 * ilen;
                 float ts = kInf;
                 uint32_t cs = CODE_MISS, is = 0;
-                closest_hit<(BVH ? 2 : 0), false>(sc, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
+                if (!(q.skip & 8u))  // diagnostic: 8 = no visibility scans
+                    closest_hit<(BVH ? 2 : 0), false>(sc, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
                 // :357-361 "something lies between the photon and the query point".  A hit inside the
                 // query point's own tangent plane is the grazing ray meeting its own surface: fp64 rejects
                 // it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
