@@ -1,0 +1,55 @@
+"""Committed vectors (tests/golden/*.npz, written by tests/golden/make_golden.py from the CPU oracle):
+the oracle must still reproduce them bit for bit (CPU), and the HIP path must match them to the fp32
+tolerance without the oracle being involved (GPU).  They are oracle outputs, not reference outputs --
+see the header of make_golden.py."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from rpt_amd import Renderer
+from tests.golden.make_golden import CASES
+from tests.util import rel_rms
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(HERE, "*.npz")))
+
+
+def test_every_case_has_a_fixture():
+    assert NAMES == sorted(CASES)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_the_golden_vectors_bit_for_bit(name):
+    from oracle.pyoracle import OracleScene
+    g = np.load(os.path.join(HERE, name + ".npz"))
+    scene, cam, cfg = CASES[name][0]()
+    o = OracleScene(scene)
+    t, obj, nrm = o.intersect(g["ray_o"], g["ray_d"], robust=1)
+    assert np.array_equal(t, g["hit_t"]) and np.array_equal(obj, g["hit_obj"]) and np.array_equal(nrm, g["hit_n"])
+    size, spp = int(g["size"]), int(g["spp"])
+    img = o.render(cam, size, size, spp, int(g["max_bounces"]), seed=int(g["seed"]), robust=1)
+    assert np.array_equal(img, g["image"])                  # fp64, fixed summation order, counter-based RNG
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_path_matches_the_golden_vectors(name):
+    g = np.load(os.path.join(HERE, name + ".npz"))
+    scene, cam, cfg = CASES[name][0]()
+    r = Renderer(scene, cam)
+    t, obj, nrm = r.get_closest_hit(g["ray_o"], g["ray_d"])
+    same = obj == g["hit_obj"]
+    coincident = (obj >= 0) & (g["hit_obj"] >= 0) & ~same & (np.abs(t - g["hit_t"]) <= 2e-4 * np.abs(g["hit_t"]))
+    assert (same | coincident).mean() >= 0.99              # 256 rays: at most two silhouette flips
+    hit = same & (g["hit_obj"] >= 0)
+    assert np.max(np.abs(t[hit] - g["hit_t"][hit]) / g["hit_t"][hit]) < 2e-4
+    assert np.quantile(np.abs(nrm[hit] - g["hit_n"][hit]).max(axis=1), 0.99) < 5e-3
+    size, spp = int(g["size"]), int(g["spp"])
+    img = r.width(size).height(size).max_bounces(int(g["max_bounces"])).seed(int(g["seed"])).sample_array(spp)
+    if g["image"].max() == 0.0:
+        assert np.all(img == 0.0)                           # C1 is black (SURVEY KAT 11)
+    else:
+        assert rel_rms(img, g["image"]) < 1e-2              # 32x32x16 spp: one flipped path is visible at this size
+        assert abs(img.mean() - g["image"].mean()) / g["image"].mean() < 5e-3
