@@ -12,7 +12,12 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <functional>
+#include <istream>
+#include <iterator>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -180,6 +185,88 @@ inline Shape polygon(const std::vector<Vec3>& verts) {  // shape.rs:308-314
     std::vector<Triangle> ts;
     for (size_t i = 1; i + 1 < verts.size(); i++) ts.push_back(Triangle::from_vertices(verts[0], verts[i], verts[i + 1]));
     return mesh(ts);
+}
+
+// ---- io.rs: host-only mesh loaders (they only produce the triangle array the hot path consumes)
+namespace io_detail {
+inline bool parse_index(const std::string& v, size_t length, long& out) {  // io.rs:12-20
+    if (v.empty()) return false;
+    char* end = nullptr;
+    long i = std::strtol(v.c_str(), &end, 10);
+    if (end == v.c_str() || *end != '\0') return false;
+    out = i > 0 ? i - 1 : long(length) + i;
+    return true;
+}
+}  // namespace io_detail
+// load_obj (io.rs:28-74, faces :164-201): `v`, `vn`, `f` with a, a/b, a//c, a/b/c indices (1-based, negative =
+// relative to the end), polygons fan-triangulated, face normals when a corner lacks a `vn`; other commands skipped.
+inline Shape load_obj(std::istream& in) {
+    std::vector<Vec3> vertices, normals;
+    std::vector<Triangle> tris;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        std::string cmd;
+        if (!(ls >> cmd) || cmd[0] == '#') continue;
+        if (cmd == "v" || cmd == "vn") {
+            double x, y, z;
+            if (!(ls >> x >> y >> z)) throw Error("Invalid point in .OBJ file");
+            (cmd == "v" ? vertices : normals).push_back({x, y, z});
+        } else if (cmd == "f") {
+            std::vector<long> vi, vni;
+            std::string tok;
+            while (ls >> tok) {
+                std::string part[3];
+                size_t k = 0, start = 0;
+                for (size_t c = 0; c <= tok.size() && k < 3; c++)
+                    if (c == tok.size() || tok[c] == '/') { part[k++] = tok.substr(start, c - start); start = c + 1; }
+                long v = 0, n = -1;
+                if (!io_detail::parse_index(part[0], vertices.size(), v) || v < 0 || size_t(v) >= vertices.size())
+                    throw Error("Invalid vertex index");
+                if (!io_detail::parse_index(part[2], normals.size(), n)) n = -1;
+                vi.push_back(v);
+                vni.push_back(n);
+            }
+            for (size_t i = 1; i + 1 < vi.size(); i++) {
+                const size_t c[3] = {0, i, i + 1};
+                const Vec3 &v1 = vertices[vi[c[0]]], &v2 = vertices[vi[c[1]]], &v3 = vertices[vi[c[2]]];
+                if (vni[c[0]] < 0 || vni[c[1]] < 0 || vni[c[2]] < 0) tris.push_back(Triangle::from_vertices(v1, v2, v3));
+                else tris.push_back({v1, v2, v3, normals.at(vni[c[0]]), normals.at(vni[c[1]]), normals.at(vni[c[2]])});
+            }
+        }
+    }
+    return mesh(tris);
+}
+// load_stl (io.rs:264-364): ASCII or binary STL, face normals recomputed from the vertices.
+inline Shape load_stl(std::istream& in) {
+    std::string data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    std::vector<Triangle> tris;
+    const size_t first = data.find_first_not_of(" \t\r\n");
+    const bool ascii = first != std::string::npos && data.compare(first, 5, "solid") == 0 &&
+                       data.substr(0, std::min<size_t>(data.size(), 2048)).find("facet") != std::string::npos;
+    if (ascii) {
+        std::istringstream ss(data);
+        std::string word;
+        std::vector<Vec3> pts;
+        while (ss >> word)
+            if (word == "vertex") {
+                double x, y, z;
+                if (!(ss >> x >> y >> z)) throw Error("Invalid vertex in .STL file");
+                pts.push_back({x, y, z});
+                if (pts.size() == 3) { tris.push_back(Triangle::from_vertices(pts[0], pts[1], pts[2])); pts.clear(); }
+            }
+    } else {
+        if (data.size() < 84) throw Error("Invalid binary .STL file");
+        uint32_t n;
+        std::memcpy(&n, data.data() + 80, 4);
+        if (data.size() < 84 + size_t(n) * 50) throw Error("Truncated binary .STL file");
+        for (uint32_t i = 0; i < n; i++) {
+            float f[12];
+            std::memcpy(f, data.data() + 84 + size_t(i) * 50, 48);
+            tris.push_back(Triangle::from_vertices({f[3], f[4], f[5]}, {f[6], f[7], f[8]}, {f[9], f[10], f[11]}));
+        }
+    }
+    return mesh(tris);
 }
 
 // ---- material.rs

@@ -168,6 +168,22 @@ f -4/1 -3/1 -2
     q = tmp_path / "a.stl"
     q.write_text("solid x\nfacet normal 0 0 0\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\nendloop\nendfacet\nendsolid x\n")
     assert load_stl(str(q)).tris.shape == (1, 6, 3)
+    # the C++ mirror's loaders (include/rpt.hpp) parse the same files to the same triangles
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mesh_dump")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "mesh_dump.cpp"), "-o", exe])
+    o = tmp_path / "t.obj"
+    o.write_text(text)
+    for path, kind, expect in ((o, "obj", m.tris), (p, "stl", s.tris), (q, "stl", load_stl(str(q)).tris)):
+        out = subprocess.check_output([exe, str(path), kind], text=True).split()
+        assert int(out[0]) == expect.shape[0]
+        assert np.array_equal(np.array(out[1:], dtype=np.float64).reshape(-1, 6, 3), expect)
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nf 1 2 3\n")
+    assert subprocess.run([exe, str(bad), "obj"], capture_output=True).returncode == 1
 
 
 def test_kdtree_group_lowers_to_a_children_array():
