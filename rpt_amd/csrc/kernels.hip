@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
     float xn = 0.f, yn = 0.f;
     bool alive = true, have_item = false, need_path = true;
     bool drained = false;  // wave-uniform: the global queue is exhausted
+    bool first_batch = true;  // wave-uniform
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform cursor into the current batch of work items
     uint32_t pool_chunk = 0, pool_x0 = 0, pool_y0 = 0;  // wave-uniform: the batch's chunk and 8x8 block origin
 
@@ -118,8 +119,17 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
                     // once this wave has seen the queue run dry it never touches the counter again: at the end
                     // of a launch every lane of every wave retires through here, and 4096 waves x 64 atomics on
                     // one address (~88 dequeues/us) used to cost ~1 ms per launch
+                    // The first batch of a wave is its own index (the host starts the counter behind them): no
+                    // 5120-way pile-up on the counter when the grid starts.  (Reading the counter before the
+                    // atomic, to spare the last one per wave, made the launch 2.6x slower: an sc1 load of a
+                    // line under atomic traffic is far more expensive than the atomic it saves.)
                     unsigned long long base = ~0ull;
-                    if (!drained && (threadIdx.x & 63u) == 0) base = atomicAdd(a.queue, 64ull);
+                    if (first_batch) {
+                        base = (unsigned long long)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 64ull;
+                        first_batch = false;
+                    } else if (!drained && (threadIdx.x & 63u) == 0) {
+                        base = atomicAdd(a.queue, 64ull);
+                    }
                     const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(base));
                     const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(base >> 32));
                     if (hi != 0 || lo >= a.n_items) {

@@ -1281,7 +1281,8 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, const rpt_camera* cam, const
 }
 
 extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st,
-                         int blocks_per_cu, const std::function<hipError_t(const RenderArgs&, int, hipStream_t)>& launch) {
+                         int blocks_per_cu, const std::function<hipError_t(const RenderArgs&, int, hipStream_t)>& launch,
+                         bool indexed_start) {
     HIP_TRY(hipMemsetAsync(a.queue, 0, 8, st));
     if (a.counters) HIP_TRY(hipMemsetAsync(a.counters, 0, 512, st));
     uint32_t shard_count = prm->shard_count == 0 ? 1 : prm->shard_count;
@@ -1290,6 +1291,9 @@ extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm
         uint64_t want = (uint64_t(a.n_items) + 255) / 256;
         int n_blocks = int(std::min<uint64_t>(uint64_t(s->n_cus) * std::max(blocks_per_cu, 1), want));
         s->last_blocks = n_blocks;
+        // indexed_start: every wave of the grid takes the batch with its own index first (render_kernel's work
+        // pull), so the counter starts behind those batches
+        if (indexed_start) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.queue, int(uint32_t(n_blocks) * 4u * 64u), 1, st));
         if (g_opt_timing) {
             for (auto& e : s->ev)
                 if (!e) HIP_TRY(hipEventCreate(&e));
@@ -1312,7 +1316,7 @@ static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderAr
         if (bpc < 1) bpc = 1;
     }
     return rpti::run_persistent(s, prm, a, d_out, st, bpc,
-                                [](const RenderArgs& ra, int nb, hipStream_t stream) { return launch_render(ra, nb, stream); });
+                                [](const RenderArgs& ra, int nb, hipStream_t stream) { return launch_render(ra, nb, stream); }, true);
 }
 extern "C++" rpti::SceneDev rpti::scene_dev(rpt_scene* s) {
     int first = -1;
