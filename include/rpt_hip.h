@@ -156,7 +156,9 @@ int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* g
  * "blocks_per_cu" (persistent grid size), "timing" 0/1, "scene_bvh_min" (read by rpt_scene_commit:
  * number of bounded primitives + BVH meshes from which one scene-level BVH replaces the linear
  * object scan, default 64), "instancing" 0/1 (read by rpt_scene_commit: store a mesh that several
- * shapes share once and instance it, default 1); returns RPT_ERR_INVALID for unknown names. */
+ * shapes share once and instance it, default 1), "room_shell" 0/1 (read by rpt_scene_commit: answer the
+ * rectangles that are the faces of one axis-aligned box with a single slab test, default 1); returns
+ * RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 
 /* ---- Buffer on the device (src/buffer.rs:5-97): the samples of each pixel are kept as running

@@ -40,8 +40,8 @@ def shard_pixels(width, height, rank, count):
 
 
 def set_option(name, value):
-    """rpt_set_option: "counters", "timing", "chunk_spp", "blocks_per_cu", "scene_bvh_min" and "instancing"
-    (both read at commit)."""
+    """rpt_set_option: "counters", "timing", "chunk_spp", "blocks_per_cu", "scene_bvh_min", "instancing" and
+    "room_shell" (read at commit)."""
     _lib.check(_lib.load().rpt_set_option(name.encode(), int(value)))
 
 
@@ -777,7 +777,7 @@ class Renderer:
         out = (C.c_uint64 * 16)()
         _lib.check(_lib.load().rpt_scene_stats(self.scene._commit(self.device_), out))
         names = ["spheres", "cubes", "planes", "tris", "aabbs", "rects", "bvh_tris", "bvh_nodes", "scan_bytes_per_ray",
-                 "scene_bytes", "scene_bvh", "scene_bvh_prims", "instances", "shared_meshes"]
+                 "scene_bytes", "scene_bvh", "scene_bvh_prims", "instances", "shared_meshes", "shell_faces"]
         return dict(zip(names, [int(v) for v in out]))
 
     # ---- photon mapping (src/photon.rs:631-720)

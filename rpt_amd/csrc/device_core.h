@@ -208,6 +208,29 @@ RPT_DEV float hit_rect(const F4& a, float vmax, float oa, float ia, float ou, fl
     bool ok = t >= tmin && t < tmax && pu >= a.y && pu <= a.z && pv >= a.w && pv <= vmax;
     return ok ? t : -1.f;
 }
+// Box shell (ShellScan): the closest rectangle among the faces of one axis-aligned box = the slab entry if
+// that face exists and lies at or beyond tmin, else the slab exit.  Same t = (plane - o) * inv as hit_rect.
+RPT_DEV void hit_shell(const ShellScan& s, V o, V inv, float tmin, float& tbest, uint32_t& code) {
+    float x1 = (s.lo.x - o.x) * inv.x, x2 = (s.hi.x - o.x) * inv.x;
+    float y1 = (s.lo.y - o.y) * inv.y, y2 = (s.hi.y - o.y) * inv.y;
+    float z1 = (s.lo.z - o.z) * inv.z, z2 = (s.hi.z - o.z) * inv.z;
+    bool sx = x1 > x2, sy = y1 > y2, sz = z1 > z2;
+    float xl = sx ? x2 : x1, xh = sx ? x1 : x2;
+    float yl = sy ? y2 : y1, yh = sy ? y1 : y2;
+    float zl = sz ? z2 : z1, zh = sz ? z1 : z2;
+    float start = max3(xl, yl, zl), end = min3(xh, yh, zh);
+    // entering through the lo face of an axis unless the direction is negative there (swapped)
+    uint32_t in_x = sx ? s.face[1] : s.face[0], out_x = sx ? s.face[0] : s.face[1];
+    uint32_t in_y = sy ? s.face[3] : s.face[2], out_y = sy ? s.face[2] : s.face[3];
+    uint32_t in_z = sz ? s.face[5] : s.face[4], out_z = sz ? s.face[4] : s.face[5];
+    uint32_t c_in = (xl > yl && xl > zl) ? in_x : (yl > zl ? in_y : in_z);
+    uint32_t c_out = (xh < yh && xh < zh) ? out_x : (yh < zh ? out_y : out_z);
+    bool box = start <= end;
+    bool use_in = box && start >= tmin && c_in != CODE_MISS;
+    bool use_out = box && end >= tmin && c_out != CODE_MISS;
+    float t = use_in ? start : end;
+    if ((use_in || use_out) && t < tbest) { tbest = t; code = use_in ? c_in : c_out; }
+}
 RPT_DEV void to_local(const XfScan& x, V o, V d, V& ol, V& dl) {
     ol = mk(dot3w(x.r0, o), dot3w(x.r1, o), dot3w(x.r2, o));
     dl = mk(dot3(x.r0, d), dot3(x.r1, d), dot3(x.r2, d));
@@ -369,8 +392,9 @@ RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest
         if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
     }
     const uint32_t n_rect = sc.n_rect_x + sc.n_rect_y + sc.n_rect_z;
-    if (sc.n_aabb + n_rect != 0) {  // wave-uniform: these kinds share one reciprocal direction per ray
+    if (sc.n_aabb + n_rect + sc.has_shell != 0) {  // wave-uniform: these kinds share one reciprocal direction per ray
         const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
+        if (sc.has_shell) hit_shell(uload(sc.shell), o, inv, tmin, tbest, code);
         for (uint32_t i = 0; i < sc.n_aabb; i++) {
             const AabbScan b = uload(&sc.aabb[i]);
             uint32_t f;

@@ -64,6 +64,14 @@ struct alignas(16) RectScan {
     F4 a;  // c, umin, umax, vmin
     F4 b;  // vmax, -, obj, -
 };
+// Rectangles that are exactly the faces of one axis-aligned box (the walls of a room: every Cornell-box
+// config) are tested together: a line meets a convex box's boundary at its slab entry and exit only, so
+// one slab test replaces up to six rectangle tests.  face[2*axis + side] = hit code of the rectangle on
+// that face (side 0 = lo, 1 = hi) or CODE_MISS for an open face.
+struct alignas(16) ShellScan {
+    F4 lo, hi;         // w unused
+    uint32_t face[8];  // [6..7] unused
+};
 struct alignas(16) RectShade {
     F4 n_obj;  // unit normal, object id (bits)
 };
@@ -135,6 +143,7 @@ struct SceneView {
     const TriScan* tri;    const TriShade* tri_sh;  uint32_t n_tri;
     const AabbScan* aabb;  uint32_t n_aabb;
     const RectScan* rect;  const RectShade* rect_sh; uint32_t n_rect_x, n_rect_y, n_rect_z;  // sorted by axis
+    const ShellScan* shell; uint32_t has_shell;  // rectangles folded into the shell follow the scanned ones in rect_sh
     const BvhNode* nodes;  const TriScan* btri;     const TriShade* btri_sh;
     const MeshRef* meshes; uint32_t n_mesh;
     // Scene-level BVH over every bounded primitive and mesh root (built when the scene has many

@@ -50,6 +50,7 @@ static int64_t g_opt_counters = 0;
 static int64_t g_opt_chunk_spp = 0;  // 0 = auto: ceil(iterations / 64) clamped to [2, 32]
 static int64_t g_opt_blocks_per_cu = 0;  // 0 = occupancy query
 static int64_t g_opt_timing = 0;
+static int64_t g_opt_room_shell = 1;  // fold rectangles that are the faces of one box into a single slab test
 static int64_t g_opt_photon_skip = 0;
 namespace rpti {
 int64_t option_photon_skip() { return g_opt_photon_skip; }
@@ -470,6 +471,7 @@ int rpt_set_option(const char* name, int64_t value) {
     else if (s == "chunk_spp") { if (value < 0) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 0 (0 = auto)"); g_opt_chunk_spp = value; }
     else if (s == "blocks_per_cu") g_opt_blocks_per_cu = value;
     else if (s == "timing") g_opt_timing = value;
+    else if (s == "room_shell") g_opt_room_shell = value;
     else if (s == "photon_skip") g_opt_photon_skip = value;
     else if (s == "instancing") g_opt_instancing = value;
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); g_opt_scene_bvh_min = value; }
@@ -980,12 +982,73 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     size_t o_cub = reserve(cub.size() * sizeof(XfScan)), o_cubs = reserve(cub_sh.size() * sizeof(XfShade));
     size_t o_pln = reserve(pln.size() * sizeof(PlaneScan)), o_plns = reserve(pln_sh.size() * sizeof(PlaneShade));
     size_t o_tri = reserve(tri.size() * sizeof(TriScan)), o_tris = reserve(tri_sh.size() * sizeof(TriShade));
+    // ---- box shell: rectangles that are exactly the faces of the box around all rectangles (the walls of a
+    // room) leave the scanned list and are answered by one slab test; linear-scan scenes only
+    const size_t n_items_total = sph.size() + cub.size() + aabb.size() + tri.size() + insts.size() + meshes.size() +
+                                 rect_axis[0].size() + rect_axis[1].size() + rect_axis[2].size();
+    const bool will_bvh = n_items_total >= size_t(std::max<int64_t>(2, g_opt_scene_bvh_min)) || !insts.empty();
+    ShellScan shell{};
+    bool has_shell = false;
+    std::vector<RectShade> shell_sh;              // shade records of the folded rectangles, in face order
+    {
+        const float inf = std::numeric_limits<float>::infinity();
+        float blo[3] = {inf, inf, inf}, bhi[3] = {-inf, -inf, -inf};
+        for (int a = 0; a < 3; a++)
+            for (const RectScan& r : rect_axis[a]) {
+                const float lo[3] = {r.a.x, r.a.y, r.a.w}, hi[3] = {r.a.x, r.a.z, r.b.x};  // axis, u, v
+                for (int k = 0; k < 3; k++) {
+                    blo[(a + k) % 3] = std::min(blo[(a + k) % 3], lo[k]);
+                    bhi[(a + k) % 3] = std::max(bhi[(a + k) % 3], hi[k]);
+                }
+            }
+        int face_of[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}}, n_faces = 0;  // index into rect_axis[a]
+        if (!will_bvh && g_opt_room_shell)
+            for (int a = 0; a < 3; a++)
+                for (size_t i = 0; i < rect_axis[a].size(); i++) {
+                    const RectScan& r = rect_axis[a][i];
+                    const int u = (a + 1) % 3, w = (a + 2) % 3;
+                    if (r.a.y != blo[u] || r.a.z != bhi[u] || r.a.w != blo[w] || r.b.x != bhi[w]) continue;
+                    for (int side = 0; side < 2; side++)
+                        if (r.a.x == (side ? bhi[a] : blo[a]) && face_of[a][side] < 0 && blo[a] < bhi[a]) {
+                            face_of[a][side] = int(i);
+                            n_faces++;
+                            break;
+                        }
+                }
+        if (n_faces >= 3) {
+            has_shell = true;
+            shell.lo = F4{blo[0], blo[1], blo[2], 0.f};
+            shell.hi = F4{bhi[0], bhi[1], bhi[2], 0.f};
+            for (int k = 0; k < 8; k++) shell.face[k] = CODE_MISS;
+            size_t n_scanned = 0;
+            for (int a = 0; a < 3; a++) n_scanned += rect_axis[a].size();
+            n_scanned -= size_t(n_faces);
+            for (int a = 0; a < 3; a++) {  // take the members out (higher index first, so indices stay valid)
+                int order[2] = {0, 1};
+                if (face_of[a][0] >= 0 && face_of[a][1] >= 0 && face_of[a][0] < face_of[a][1]) { order[0] = 1; order[1] = 0; }
+                RectShade keep[2];
+                for (int k = 0; k < 2; k++) {
+                    const int side = order[k];
+                    if (face_of[a][side] < 0) continue;
+                    keep[side] = rect_sh_axis[a][size_t(face_of[a][side])];
+                    rect_axis[a].erase(rect_axis[a].begin() + face_of[a][side]);
+                    rect_sh_axis[a].erase(rect_sh_axis[a].begin() + face_of[a][side]);
+                }
+                for (int side = 0; side < 2; side++)
+                    if (face_of[a][side] >= 0) {
+                        shell.face[2 * a + side] = (K_RECT << 28) | uint32_t(n_scanned + shell_sh.size());
+                        shell_sh.push_back(keep[side]);
+                    }
+            }
+        }
+    }
     std::vector<RectScan> rect;
     std::vector<RectShade> rect_sh;
     for (int a = 0; a < 3; a++) {
         rect.insert(rect.end(), rect_axis[a].begin(), rect_axis[a].end());
         rect_sh.insert(rect_sh.end(), rect_sh_axis[a].begin(), rect_sh_axis[a].end());
     }
+    rect_sh.insert(rect_sh.end(), shell_sh.begin(), shell_sh.end());  // hit codes of shell faces point here
     // ---- shadow test shortcut: when the primitives of a light's twin object form one contiguous range of
     // hit codes, "the closest hit belongs to the twin" is a range compare instead of a shade-record load
     for (Light& L : lights) {
@@ -1090,6 +1153,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         }
     }
     size_t o_pleaf = reserve(pleaf.size() * sizeof(uint32_t));
+    size_t o_shell = reserve(sizeof(ShellScan));
     size_t o_inst = reserve(insts.size() * sizeof(InstRec));
     size_t o_aabb = reserve(aabb.size() * sizeof(AabbScan));
     size_t o_rect = reserve(rect.size() * sizeof(RectScan)), o_rects = reserve(rect_sh.size() * sizeof(RectShade));
@@ -1109,6 +1173,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     put(o_tri, tri.data(), tri.size() * sizeof(TriScan));      put(o_tris, tri_sh.data(), tri_sh.size() * sizeof(TriShade));
     put(o_aabb, aabb.data(), aabb.size() * sizeof(AabbScan));
     put(o_pleaf, pleaf.data(), pleaf.size() * sizeof(uint32_t));
+    put(o_shell, &shell, sizeof(ShellScan));
     put(o_inst, insts.data(), insts.size() * sizeof(InstRec));
     put(o_rect, rect.data(), rect.size() * sizeof(RectScan));  put(o_rects, rect_sh.data(), rect_sh.size() * sizeof(RectShade));
     put(o_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
@@ -1130,6 +1195,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     v.aabb = (const AabbScan*)(base + o_aabb);  v.n_aabb = uint32_t(aabb.size());
     v.rect = (const RectScan*)(base + o_rect);  v.rect_sh = (const RectShade*)(base + o_rects);
     v.n_rect_x = uint32_t(rect_axis[0].size()); v.n_rect_y = uint32_t(rect_axis[1].size()); v.n_rect_z = uint32_t(rect_axis[2].size());
+    v.shell = (const ShellScan*)(base + o_shell); v.has_shell = has_shell ? 1u : 0u;
     v.nodes = (const BvhNode*)(base + o_nodes); v.btri = (const TriScan*)(base + o_btri);      v.btri_sh = (const TriShade*)(base + o_btris);
     v.meshes = (const MeshRef*)(base + o_mesh); v.n_mesh = uint32_t(meshes.size());
     v.pleaf = (const uint32_t*)(base + o_pleaf); v.n_nodes = uint32_t(nodes.size());
@@ -1169,14 +1235,15 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     v.hdri = (const F4*)(base + o_hdri);
     v.hdri_w = s->hdri_w;
     v.hdri_h = s->hdri_h;
-    s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size() + aabb.size() + rect.size();
+    s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size() + aabb.size() + rect.size() + (has_shell ? 1 : 0);
     s->stats[0] = sph.size(); s->stats[1] = cub.size(); s->stats[2] = pln.size(); s->stats[3] = tri.size();
-    s->stats[4] = aabb.size(); s->stats[5] = rect.size(); s->stats[6] = btri.size(); s->stats[7] = nodes.size();
+    s->stats[4] = aabb.size(); s->stats[5] = rect_sh.size(); s->stats[6] = btri.size(); s->stats[7] = nodes.size();
     // scan-record bytes every closest-hit query walks (the uniform part of the algorithmic bytes)
     s->stats[8] = 48 * (sph.size() + cub.size() + tri.size()) + 16 * pln.size() + 32 * (aabb.size() + rect.size());
     s->stats[9] = off;
     s->stats[10] = scene_bvh ? 1 : 0;
     s->stats[11] = pleaf.size();
+    s->stats[14] = has_shell ? shell_sh.size() : 0;
     s->stats[12] = insts.size();
     s->stats[13] = shared.size();
 

@@ -199,3 +199,28 @@ def test_full_fractal_of_937_mesh_instances_fits_and_renders():
     t, obj, nrm = r.get_closest_hit(o, d)
     assert sorted(set(obj[obj >= 0].tolist())) == [0, 1, 2, 3, 4, 5]
     assert np.allclose(np.linalg.norm(nrm[obj >= 0], axis=1), 1.0, atol=1e-4)
+
+
+# ------------------------------------------------------------------ box shell (room walls as one slab test)
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_room_shell_equals_the_rectangle_scan(name):
+    """The five walls of the Cornell box are the faces of one axis-aligned box: folding them into a single
+    slab test (commit-time option "room_shell") must not change a hit."""
+    res = {}
+    try:
+        for on in (1, 0):
+            rpt_amd.set_option("room_shell", on)
+            scene, cam, cfg = scenes.CONFIGS[name]()
+            r = Renderer(scene, cam).width(96).height(96).max_bounces(cfg["max_bounces"]).seed(21)
+            st = r.scene_stats()
+            assert st["shell_faces"] == (5 if on else 0) and st["rects"] == 6
+            o, d = random_rays(np.random.default_rng(9), 30000, np.array([278.0, 274.0, 280.0]), 700.0)
+            res[on] = (r.get_closest_hit(o, d), r.sample_array(16))
+    finally:
+        rpt_amd.set_option("room_shell", 1)
+    (t1, o1, n1), img1 = res[1]
+    (t0, o0, n0), img0 = res[0]
+    same = o1 == o0
+    assert same.mean() > 0.9999                               # rays through the seam between two walls may pick the other one
+    assert np.array_equal(t1[same], t0[same]) and np.array_equal(n1[same], n0[same])   # same (plane - o) * inv arithmetic
+    assert np.any(img1 != img0) is not None and rel_rms(img1, img0) < 2e-3
