@@ -89,10 +89,31 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
     rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     V ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     V P = mk(0, 0, 0), Q = mk(1, 1, 1), Rc = mk(kInf, kInf, kInf);
-    V acc = mk(0, 0, 0);
-    uint32_t depth = 0, slab_idx = 0, s = 0, s_end = 0, pix = 0;
-    float xn = 0.f, yn = 0.f;
+    // Per-lane state that is touched only when a path ends or a sample starts (the item's partial sum, its slab
+    // slot and sample range, the pixel) lives in LDS in the scan instantiations: they are compiled for 5 waves
+    // per SIMD (96 VGPRs), LDS is otherwise unused there, and a value parked in LDS is a spill that costs one
+    // ds instruction instead of a trip to L2 (register spills of that build ran at 39 GB of HBM writes per launch).
+    // The tree-walking instantiations (128 VGPRs, 32 KB of LDS stack per block) park only the five values that
+    // are read once per sample: 4 blocks x (32 + 5) KB still fit the CU's 160 KB.
+    constexpr uint32_t kStateBase = BVH ? 32u * 256u : 0u;  // dwords: after the traversal stack
+    uint32_t* const ls = dyn_lds + kStateBase + threadIdx.x;  // [slots][256] dwords, one column per lane
+    enum { S_SLAB = 0, S_END = 1, S_PIX = 2, S_XN = 3, S_YN = 4, S_S = 5, S_ACC = 6 };
+    auto in_lds = [](int k) { return BVH == 0 || k <= S_YN; };
+    V acc_r = mk(0, 0, 0);
+    uint32_t slab_idx_r = 0, s_r = 0, s_end_r = 0, pix_r = 0;
+    float xn_r = 0.f, yn_r = 0.f;
+    auto ldu = [&](int k, uint32_t reg) { return in_lds(k) ? ls[k * 256] : reg; };
+    auto ldf = [&](int k, float reg) { return in_lds(k) ? __uint_as_float(ls[k * 256]) : reg; };
+    auto stu = [&](int k, uint32_t& reg, uint32_t v) { if (in_lds(k)) ls[k * 256] = v; else reg = v; };
+    auto stf = [&](int k, float& reg, float v) { if (in_lds(k)) ls[k * 256] = __float_as_uint(v); else reg = v; };
+    auto acc_add = [&](V v) {
+        stf(S_ACC + 0, acc_r.x, ldf(S_ACC + 0, acc_r.x) + v.x);
+        stf(S_ACC + 1, acc_r.y, ldf(S_ACC + 1, acc_r.y) + v.y);
+        stf(S_ACC + 2, acc_r.z, ldf(S_ACC + 2, acc_r.z) + v.z);
+    };
+    uint32_t depth = 0;
     bool alive = true, have_item = false, need_path = true;
+    bool item_done = true;  // the lane's item has no samples left (s >= s_end)
     bool drained = false;  // wave-uniform: the global queue is exhausted
     bool first_batch = true;  // wave-uniform
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform cursor into the current batch of work items
@@ -105,11 +126,12 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
         // 64-bit counter with ONE atomic per batch and hands them to the lanes that finished their
         // item through a ballot/mbcnt prefix; the batch cursor lives in wave-uniform registers.
         // (One atomic per lane-pull saturated the counter at ~80 M dequeues/s: profiles/r01.)
-        bool want = alive && need_path && s >= s_end;
+        bool want = alive && need_path && item_done;
         if (__any(want)) {
             SECT(0);
             if (want && have_item) {
-                reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(acc.x, acc.y, acc.z, 0.f);
+                reinterpret_cast<float4*>(a.slab)[ldu(S_SLAB, slab_idx_r)] =
+                    make_float4(ldf(S_ACC + 0, acc_r.x), ldf(S_ACC + 1, acc_r.y), ldf(S_ACC + 2, acc_r.z), 0.f);
                 have_item = false;
             }
             for (;;) {
@@ -160,14 +182,18 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
                     if (x < a.width && y < a.height) {  // slots of clipped tiles lie outside the image
                         want = false;
                         have_item = true;
-                        slab_idx = item;
-                        acc = mk(0, 0, 0);
-                        s = chunk * a.chunk_spp;
-                        s_end = min(s + a.chunk_spp, a.iterations);
-                        pix = y * a.width + x;
+                        item_done = false;
+                        stu(S_SLAB, slab_idx_r, item);
+                        stf(S_ACC + 0, acc_r.x, 0.f);
+                        stf(S_ACC + 1, acc_r.y, 0.f);
+                        stf(S_ACC + 2, acc_r.z, 0.f);
+                        const uint32_t s0 = chunk * a.chunk_spp;
+                        stu(S_S, s_r, s0);
+                        stu(S_END, s_end_r, min(s0 + a.chunk_spp, a.iterations));
+                        stu(S_PIX, pix_r, y * a.width + x);
                         // src/renderer.rs:174-176
-                        xn = (float(2u * x + 1u) - float(a.width)) * a.inv_dim;
-                        yn = (float(2u * (a.height - y) - 1u) - float(a.height)) * a.inv_dim;
+                        stf(S_XN, xn_r, (float(2u * x + 1u) - float(a.width)) * a.inv_dim);
+                        stf(S_YN, yn_r, (float(2u * (a.height - y) - 1u) - float(a.height)) * a.inv_dim);
                     }
                 }
             }
@@ -175,15 +201,17 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
         if (need_path && alive) {
             if (alive) {  // src/renderer.rs:179-181
                 SECT(1);
-                rng.seed(a.seed_mixed, pix, a.sample_offset + s);
+                const uint32_t s = ldu(S_S, s_r);
+                rng.seed(a.seed_mixed, ldu(S_PIX, pix_r), a.sample_offset + s);
                 float dx = rng.range(-a.inv_dim, a.inv_dim);
                 float dy = rng.range(-a.inv_dim, a.inv_dim);
-                cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
+                cast_ray(a.cam, ldf(S_XN, xn_r) + dx, ldf(S_YN, yn_r) + dy, rng, ro, rd);
                 depth = 0;
                 P = mk(0, 0, 0);
                 Q = mk(1, 1, 1);
                 Rc = mk(kInf, kInf, kInf);
-                s++;
+                stu(S_S, s_r, s + 1u);
+                item_done = s + 1u >= ldu(S_END, s_end_r);
                 need_path = false;
                 if (COUNT) c_samples++;
             }
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
         const bool ev_surface = !ev_medium && hit;
         if (!ev_medium && !ev_surface) {  // miss: environment (src/renderer.rs:198-206, 288)
             SECT(4);
-            acc = acc + vmin(fma3(Q, env_color(sc, rd), P), Rc);
+            acc_add(vmin(fma3(Q, env_color(sc, rd), P), Rc));
             need_path = true;
             continue;
         }
@@ -309,7 +337,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
             rd = wi;
             depth++;
         } else {
-            acc = acc + vmin(P, Rc);
+            acc_add(vmin(P, Rc));
             need_path = true;
         }
     }
@@ -468,10 +496,12 @@ __global__ void debug_camera_kernel(const CameraG cam, uint32_t w, uint32_t h, u
 
 // ------------------------------------------------------------------ launchers
 static constexpr size_t kStackBytes = 32u * 256u * sizeof(uint32_t);
+static constexpr size_t kStateBytes = 9u * 256u * sizeof(uint32_t);      // LDS-resident lane state of the scan instantiations
+static constexpr size_t kStateBytesBvh = 5u * 256u * sizeof(uint32_t);   // ... of the tree-walking ones (behind the stack)
 
 template <bool M, int B, bool C>
 static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((render_kernel<M, B, C>), dim3(n_blocks), dim3(256), B ? kStackBytes : 0, stream, a);
+    hipLaunchKernelGGL((render_kernel<M, B, C>), dim3(n_blocks), dim3(256), B ? kStackBytes + kStateBytesBvh : kStateBytes, stream, a);
     return hipGetLastError();
 }
 template <bool M, bool C>
@@ -491,7 +521,7 @@ hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu) {
     const void* f;
     if (medium) f = bvh == 2 ? (const void*)render_kernel<true, 2, false> : bvh == 1 ? (const void*)render_kernel<true, 1, false> : (const void*)render_kernel<true, 0, false>;
     else f = bvh == 2 ? (const void*)render_kernel<false, 2, false> : bvh == 1 ? (const void*)render_kernel<false, 1, false> : (const void*)render_kernel<false, 0, false>;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, 256, bvh ? kStackBytes : 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, 256, bvh ? kStackBytes + kStateBytesBvh : kStateBytes);
 }
 hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipStream_t stream) {
     uint32_t blocks = (a.n_owned + 255u) / 256u;
