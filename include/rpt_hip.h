@@ -157,8 +157,10 @@ int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* g
  * number of bounded primitives + BVH meshes from which one scene-level BVH replaces the linear
  * object scan, default 64), "instancing" 0/1 (read by rpt_scene_commit: store a mesh that several
  * shapes share once and instance it, default 1), "room_shell" 0/1 (read by rpt_scene_commit: answer the
- * rectangles that are the faces of one axis-aligned box with a single slab test, default 1); returns
- * RPT_ERR_INVALID for unknown names. */
+ * rectangles that are the faces of one axis-aligned box with a single slab test, default 1),
+ * "photon_block_lists" 0/1 (camera pass of the beam x point kind: collect the photon spheres of each 8x8
+ * pixel block once per work batch, default 1; 0 walks the tree per sample), "photon_skip" (diagnostic bit
+ * mask that switches parts of the photon camera pass off); returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 
 /* ---- Buffer on the device (src/buffer.rs:5-97): the samples of each pixel are kept as running

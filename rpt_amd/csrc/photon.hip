@@ -1430,7 +1430,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         return hipGetLastError();
     };
     int bpc = int(std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / std::max<size_t>(lds, 1))));
-    if (pm->kind == RPT_PHOTON_POINT_BEAM && medium && pm->vol.n) {
+    if (pm->kind == RPT_PHOTON_POINT_BEAM && medium && pm->vol.n && rpti::option_photon_block_lists()) {
         const size_t words = size_t(rpti::scene_dev(s).n_cus) * size_t(bpc) * 4u * kCandCap;
         if (words > pm->cand_words) {
             (void)hipFree(pm->d_cand);

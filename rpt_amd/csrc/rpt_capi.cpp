@@ -52,8 +52,10 @@ static int64_t g_opt_blocks_per_cu = 0;  // 0 = occupancy query
 static int64_t g_opt_timing = 0;
 static int64_t g_opt_room_shell = 1;  // fold rectangles that are the faces of one box into a single slab test
 static int64_t g_opt_photon_skip = 0;
+static int64_t g_opt_photon_block_lists = 1;
 namespace rpti {
 int64_t option_photon_skip() { return g_opt_photon_skip; }
+int64_t option_photon_block_lists() { return g_opt_photon_block_lists; }
 }
 static int64_t g_opt_instancing = 1;     // meshes shared by several shapes are stored once and instanced
 static int64_t g_opt_scene_bvh_min = 64;  // bounded primitives + BVH meshes from which the scene-level BVH is built
@@ -473,6 +475,7 @@ int rpt_set_option(const char* name, int64_t value) {
     else if (s == "timing") g_opt_timing = value;
     else if (s == "room_shell") g_opt_room_shell = value;
     else if (s == "photon_skip") g_opt_photon_skip = value;
+    else if (s == "photon_block_lists") g_opt_photon_block_lists = value;
     else if (s == "instancing") g_opt_instancing = value;
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); g_opt_scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option " + s);

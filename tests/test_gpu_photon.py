@@ -189,3 +189,26 @@ def test_sharded_shooting_gathers_to_the_single_gpu_map_bit_for_bit(kind):
     assert np.array_equal(r.photon_sample_array(2), img_ref)
     with pytest.raises(RptError):
         r.photon_shoot(n, kind, 3, 3)
+
+
+@pytest.mark.parametrize("w,h,spp", [(64, 64, 20), (50, 37, 5), (8, 8, 33)])
+def test_block_candidate_lists_equal_the_per_sample_walk(w, h, spp):
+    """Beam x point camera pass: the per-block candidate lists (one tree walk per 8x8 pixel block and work
+    batch) against the walk per sample, on sizes with clipped blocks and sample counts that do not divide
+    into whole work items.  Same photons tested and accepted => equal up to the fp32 order of the sums."""
+    import rpt_amd
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    n = 30000
+    r = Renderer(scene, cam).width(w).height(h).watts(14.65 * n).seed(5).gather_size(20).gather_size_volume(3)
+    r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    imgs = []
+    try:
+        for on in (1, 0):
+            rpt_amd.set_option("photon_block_lists", on)
+            r._sample_offset = 0
+            imgs.append(r.photon_sample_array(spp))
+    finally:
+        rpt_amd.set_option("photon_block_lists", 1)
+    assert np.all(np.isfinite(imgs[0])) and imgs[1].mean() > 0
+    assert rel_rms(imgs[0], imgs[1]) < 1e-5
+    assert np.max(np.abs(imgs[0] - imgs[1]) / (np.abs(imgs[1]) + 1e-3 * imgs[1].mean())) < 1e-3
