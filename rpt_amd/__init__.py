@@ -7,6 +7,6 @@ scene definitions (`scenes.py`).
 from .api import *  # noqa: F401,F403
 from .api import __all__ as _api_all
 from . import scenes  # noqa: F401
-from .io import load_obj, load_stl  # noqa: F401
+from .io import load_obj, load_obj_with_mtl, load_stl  # noqa: F401
 
-__all__ = list(_api_all) + ["scenes", "load_obj", "load_stl"]
+__all__ = list(_api_all) + ["scenes", "load_obj", "load_obj_with_mtl", "load_stl"]

@@ -186,6 +186,18 @@ f -4/1 -3/1 -2
     assert subprocess.run([exe, str(bad), "obj"], capture_output=True).returncode == 1
 
 
+def test_load_obj_with_mtl_splits_objects_by_usemtl():
+    import io
+    from rpt_amd import load_obj_with_mtl
+    obj = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nusemtl a\nf 1 2 3\nusemtl a\nf 1 3 4\nusemtl b\nf 1 2 4\n"
+    objs = load_obj_with_mtl(io.StringIO(obj), io.StringIO("# lib\nnewmtl a\nnewmtl b\n"))
+    assert [o.shape.tris.shape[0] for o in objs] == [2, 1]               # a repeated `usemtl a` does not split (io.rs:123)
+    with pytest.raises(NotImplementedError):
+        load_obj_with_mtl(io.StringIO(obj), io.StringIO("newmtl a\nKd 1 0 0\n"))    # the reference panics here
+    with pytest.raises(ValueError):
+        load_obj_with_mtl(io.StringIO(obj), io.StringIO("newmtl a\n"))               # usemtl b not in the library
+
+
 def test_kdtree_group_lowers_to_a_children_array():
     """KdTree<Box<dyn Bounded>> (kdtree.rs:103-146): children keep their own transforms, groups nest,
     planes are rejected (not Bounded), and a transform on the group stays on the group."""
