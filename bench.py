@@ -123,7 +123,13 @@ def main():
     spp = args.spp or cfg["spp"]
     r = Renderer(scene, cam).width(width).height(height).max_bounces(cfg["max_bounces"]).seed(0)
     r.device(local_rank).shard(rank, world)
-    d_out = torch.zeros(width * height * 3, dtype=torch.float64, device="cuda")
+    # N > 1: two frames, so that the sum-reduce of step k (RCCL, its own stream) overlaps the rendering of
+    # step k + 1 -- what an iterative render does with consecutive batches.  Every reduce has completed
+    # before the closing synchronize + barrier of the timed region.
+    frames = [torch.zeros(width * height * 3, dtype=torch.float64, device="cuda") for _ in range(2)]
+    d_out = frames[0]
+    pending = [None, None]
+    step_no = [0]
     stream = torch.cuda.current_stream().cuda_stream
     rpt_amd.set_option("timing", 1)
 
@@ -137,27 +143,41 @@ def main():
 
     def step(record=False):
         r._sample_offset = 0
+        slot = step_no[0] % 2 if dist is not None else 0
+        step_no[0] += 1
+        frame = frames[slot]
+        if pending[slot] is not None:   # the reduce that last used this frame must be done before it is overwritten
+            pending[slot].wait()
+            pending[slot] = None
         if photon:
             if dist is not None:   # shooting sharded by photon index, records all-gathered over RCCL
                 photon_map_build_sharded(r, n_photons, Renderer.PHOTON_POINT_BEAM, rank, world)
             else:
                 r.photon_map_build(n_photons, Renderer.PHOTON_POINT_BEAM)
-            r.photon_sample_device(spp, d_out.data_ptr(), stream)
+            r.photon_sample_device(spp, frame.data_ptr(), stream)
         else:
-            r.sample_device(spp, d_out.data_ptr(), stream)
+            r.sample_device(spp, frame.data_ptr(), stream)
         if dist is not None:
-            dist.reduce(d_out, dst=0, op=dist.ReduceOp.SUM)
+            pending[slot] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
         if record:
             kernel_ms.append(r.timing()[0])   # waits for this step's events only
 
+    def drain():
+        for i in range(2):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
+
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(record=True)
+    drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
