@@ -249,10 +249,17 @@ RPT_DEV void slab2(const float lo[3], const float hi[3], V o, V inv, float& tn, 
     tn = max3(fminf(x1, x2), fminf(y1, y2), fminf(z1, z2));
     tf = min3(fmaxf(x1, x2), fmaxf(y1, y2), fmaxf(z1, z2));
 }
-template <bool COUNT, bool PRIMS>
+// Occluder test of a shadow walk: a hit closer than t_block on anything but the light's twin primitives
+// (hit codes tw_lo..tw_hi) decides the shadow test -- the walk may stop without finding the closest hit.
+struct AnyHit {
+    float t_block;
+    uint32_t tw_lo, tw_hi;
+    RPT_DEV bool blocks(float t, uint32_t code) const { return t < t_block && !(code >= tw_lo && code <= tw_hi); }
+};
+template <bool COUNT, bool PRIMS, bool ANY = false>
 RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tmin, float& tbest, uint32_t& code,
                           uint32_t& inst, uint32_t* stk, uint32_t stride, uint32_t cap, uint32_t& c_nodes,
-                          uint32_t& c_tris);
+                          uint32_t& c_tris, AnyHit any = AnyHit{-kInf, 1u, 0u});
 
 // One primitive of a BVH_PRIMS leaf (per lane: kinds may differ between lanes).  `stk`/`cap`:
 // the part of the lane's stack column above the caller's entries, for the nested walk of an instance.
@@ -300,10 +307,10 @@ RPT_DEV void hit_prim(const SceneView& sc, uint32_t pc, V o, V d, V inv, float t
     if (t >= 0.f && t < tbest) { tbest = t; code = pc; }
 }
 
-template <bool COUNT, bool PRIMS>
+template <bool COUNT, bool PRIMS, bool ANY>
 RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tmin, float& tbest, uint32_t& code,
                           uint32_t& inst, uint32_t* stk, uint32_t stride, uint32_t cap, uint32_t& c_nodes,
-                          uint32_t& c_tris) {
+                          uint32_t& c_tris, AnyHit any) {
     const BvhNode* nodes = sc.nodes;
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
     const uint32_t kDone = 0xFFFFFFFFu;  // a 32-item prim leaf at the last index never occurs
@@ -348,6 +355,7 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
                     if (t >= 0.f) { tbest = t; code = (K_BVHTRI << 28) | (first + i); }
                 }
             }
+            if (ANY && code != CODE_MISS && any.blocks(tbest, code)) sp = 0;  // an occluder is known: nothing left to find
             if (sp) {
                 sp--;
                 cur = stk[sp * stride];
@@ -359,16 +367,17 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
 }
 
 // BVH: 0 = no tree in the scene, 1 = per-mesh trees only, 2 = scene-level tree possible.
-template <int BVH, bool COUNT>
+template <int BVH, bool COUNT, bool ANY = false>
 RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
-                         uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
+                         uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris,
+                         AnyHit any = AnyHit{-kInf, 1u, 0u}) {
     if (BVH == 2 && sc.scene_bvh) {  // wave-uniform: planes (unbounded) are scanned, everything else is in the tree
         for (uint32_t i = 0; i < sc.n_pln; i++) {
             const F4 nv = uload(&sc.pln[i]).nv;
             float t = hit_plane(nv, o, d, tmin);
             if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
         }
-        bvh_traverse<COUNT, true>(sc, sc.top_root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris);
+        bvh_traverse<COUNT, true, ANY>(sc, sc.top_root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
         return;
     }
     for (uint32_t i = 0; i < sc.n_sph; i++) {
@@ -426,7 +435,8 @@ RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest
     if (BVH) {
         for (uint32_t i = 0; i < sc.n_mesh; i++) {
             const MeshRef m = uload(&sc.meshes[i]);
-            bvh_traverse<COUNT, false>(sc, m.root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris);
+            if (ANY && code != CODE_MISS && any.blocks(tbest, code)) break;  // (per lane) already occluded
+            bvh_traverse<COUNT, false, ANY>(sc, m.root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
         }
     }
 }

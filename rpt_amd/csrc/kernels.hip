@@ -282,7 +282,10 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
                     // scene object that IS this light, at the sampled distance (rel. tol 1e-3).
                     float ts = dist * (1.f + 1e-3f);
                     uint32_t cs = CODE_MISS, is = 0;
-                    closest_hit<BVH, COUNT>(sc, x, wi, ray_tmin(x), ts, cs, is, stk, stride, c_nodes, c_btris);
+                    // tree-walking scenes: any hit in front of the light on something other than its twin settles the test
+                    const bool range = L.twin_lo <= L.twin_hi;
+                    closest_hit<BVH, COUNT, BVH != 0>(sc, x, wi, ray_tmin(x), ts, cs, is, stk, stride, c_nodes, c_btris,
+                                                     AnyHit{range ? dist * (1.f - 1e-3f) : -kInf, L.twin_lo, L.twin_hi});
                     if (COUNT) c_rays++;
                     SECT(9);
                     const bool twin = (L.twin_lo <= L.twin_hi) ? (cs >= L.twin_lo && cs <= L.twin_hi)   // wave-uniform choice
