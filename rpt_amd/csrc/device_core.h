@@ -51,10 +51,11 @@ RPT_DEV T uload(const T* p) {
     typedef uint32_t u4v __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) u4v* CP;
     CP q = (CP)(uintptr_t)p;
-    T out;
-    u4v* o = reinterpret_cast<u4v*>(&out);
+    u4v raw[sizeof(T) / 16];
 #pragma unroll
-    for (unsigned i = 0; i < sizeof(T) / 16; i++) o[i] = q[i];
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) raw[i] = q[i];
+    T out;
+    __builtin_memcpy(&out, raw, sizeof(T));  // not a cast: the record's fields are floats, the loads are uint vectors
     return out;
 }
 

@@ -75,6 +75,9 @@ inline D3 normalize(D3 a) {
     return {a.x / l, a.y / l, a.z / l};
 }
 inline D3 d3(const double* p) { return {p[0], p[1], p[2]}; }
+// component by index.  (Not (&v.x)[a]: indexing past the member x is undefined, and clang does drop the
+// y / z iterations of such a loop when it is not unrolled.)
+inline double comp(const D3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
 inline F4 f4(D3 v, double w) { return F4{float(v.x), float(v.y), float(v.z), float(w)}; }
 inline float bits_f(uint32_t u) {
     float f;
@@ -613,7 +616,7 @@ static int detect_rect(const double* t0, const double* t1, const Xf& x, uint32_t
     }
     if (lone < 0) return -1;
     for (int axis = 0; axis < 3; axis++) {
-        auto c = [&](const D3& v, int a) { return (&v.x)[a % 3]; };
+        auto c = [&](const D3& v, int a) { return comp(v, a % 3); };
         double pc = c(q[0], axis);
         if (c(q[1], axis) != pc || c(q[2], axis) != pc || c(q[3], axis) != pc) continue;
         int ua = axis + 1, va = axis + 2;
@@ -723,7 +726,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         PBox b;
         D3 v[3] = {x.point(d3(t)), x.point(d3(t + 3)), x.point(d3(t + 6))};
         for (int a = 0; a < 3; a++) {
-            double c0 = (&v[0].x)[a], c1 = (&v[1].x)[a], c2 = (&v[2].x)[a];
+            double c0 = comp(v[0], a), c1 = comp(v[1], a), c2 = comp(v[2], a);
             double lo = std::min(c0, std::min(c1, c2)), hi = std::max(c0, std::max(c1, c2));
             b.lo[a] = std::nextafter(float(lo), -std::numeric_limits<float>::infinity());
             b.hi[a] = std::nextafter(float(hi), std::numeric_limits<float>::infinity());
@@ -1292,7 +1295,7 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, const rpt_camera* cam, const
     for (int i = 0; i < 3; i++) {
         a.cam.eye[i] = float(cam->eye[i]);
         a.cam.ddir[i] = float(dd * cam->direction[i]);
-        a.cam.right[i] = float((&right.x)[i]);
+        a.cam.right[i] = float(comp(right, i));
         a.cam.up[i] = float(cam->up[i]);
     }
     a.cam.aperture = float(cam->aperture);
@@ -1662,7 +1665,7 @@ int rpt_debug_camera_rays(const rpt_camera* cam, const rpt_render_params* prm, u
     for (int i = 0; i < 3; i++) {
         c.eye[i] = float(cam->eye[i]);
         c.ddir[i] = float(dd * cam->direction[i]);
-        c.right[i] = float((&right.x)[i]);
+        c.right[i] = float(comp(right, i));
         c.up[i] = float(cam->up[i]);
     }
     c.aperture = float(cam->aperture);
