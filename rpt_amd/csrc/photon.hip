@@ -511,6 +511,8 @@ RPT_DEV bool box_outside(const float lo[3], const float hi[3], V o, V nrm) {
 struct Frustum {
     V o0, m, nl, nr, nb, nt;
     float ll, lr, lb, lt;
+    V axis;          // unit direction through the middle of the (u, v) bounds
+    float tan_half;  // tangent of the half angle of the cone around `axis` that contains the whole frustum
 };
 // Bounds `nd` directions per live lane (all from one origin).  false if the lanes do not share an origin or
 // a direction is more than 60 degrees off the first lane's.
@@ -551,13 +553,31 @@ RPT_DEV bool frustum_from_dirs(bool active, V o, const V* dirs, int nd, Frustum&
     // u, v, m are orthonormal: |n| = sqrt(1 + bound^2)
     fr.ll = uni(__builtin_sqrtf(fmaf(umin, umin, 1.f))); fr.lr = uni(__builtin_sqrtf(fmaf(umax, umax, 1.f)));
     fr.lb = uni(__builtin_sqrtf(fmaf(vmin, vmin, 1.f))); fr.lt = uni(__builtin_sqrtf(fmaf(vmax, vmax, 1.f)));
+    // bounding cone: axis through the centre of the bounds; its half angle reaches the farthest corner direction
+    const float uc = 0.5f * (umin + umax), vc = 0.5f * (vmin + vmax);
+    const V ax = normalize(m + uc * u + vc * v);
+    float cmin = 1.f;
+    for (int k = 0; k < 4; k++) {
+        const V cd = normalize(m + ((k & 1) ? umax : umin) * u + ((k & 2) ? vmax : vmin) * v);
+        cmin = fminf(cmin, dot(cd, ax));
+    }
+    fr.axis = uni3(ax);
+    fr.tan_half = uni(__builtin_sqrtf(fmaxf(1.f - cmin * cmin, 0.f)) * rcp(fmaxf(cmin, 1e-6f)) * 1.0001f + 1e-7f);
     return true;
 }
 RPT_DEV bool sphere_outside(const Frustum& fr, const F4& pos_r) {
     const V c = xyz(pos_r) - fr.o0;
     const float r = pos_r.w;
-    return dot(fr.m, c) < -r || dot(fr.nl, c) < -r * fr.ll || dot(fr.nr, c) < -r * fr.lr || dot(fr.nb, c) < -r * fr.lb ||
-           dot(fr.nt, c) < -r * fr.lt;
+    if (dot(fr.m, c) < -r || dot(fr.nl, c) < -r * fr.ll || dot(fr.nr, c) < -r * fr.lr || dot(fr.nb, c) < -r * fr.lb ||
+        dot(fr.nt, c) < -r * fr.lt)
+        return true;
+    // the four planes leave a square cross-section; a narrow frustum (one pixel) is far better bounded by its cone:
+    // outside if the centre is farther from the axis than the cone's radius at that depth plus r / cos(half angle)
+    const float z = dot(c, fr.axis);
+    if (z <= 0.f) return false;
+    const float d2 = fmaxf(dot(c, c) - z * z, 0.f);
+    const float reach = fmaf(fr.tan_half, z, r * __builtin_sqrtf(fmaf(fr.tan_half, fr.tan_half, 1.f)));
+    return d2 > reach * reach;
 }
 // Walk of the photon tree against a frustum: each lane culls a DIFFERENT pending node's two child boxes (64
 // nodes per instruction stream), survivors are pushed with a ballot prefix onto the wave-private LDS stack.
@@ -708,121 +728,86 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     const float sigma_t = sc.sigma_a + sc.sigma_s;
     const V mcol0 = mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);  // medium.color(dummy_pos = 0)
 
-    V acc = mk(0, 0, 0);
-    uint32_t slab_idx = 0, s = 0, s_end = 0, pix = 0;
-    float xn = 0.f, yn = 0.f;
-    bool alive = true, have_item = false;
-    bool drained = false;  // wave-uniform: the global queue is exhausted
-    uint32_t pool_next = 0, pool_end = 0;
-    uint32_t pool_chunk = 0, pool_x0 = 0, pool_y0 = 0;  // wave-uniform: the batch's chunk and 8x8 block origin
     uint32_t c0 = 0, c1 = 0;
     float prev_r2 = 0.f;  // squared radius of this lane's previous surface gather
     unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
-    // Beam x point estimate with a pinhole camera: the lanes of a wave work through one 8x8 pixel block of
-    // one chunk in lockstep, and all samples of a pixel stay inside its footprint.  The photon spheres that
-    // reach into the block's frustum are therefore found ONCE per work batch (one tree walk) and kept in a
-    // per-wave list in global memory; every sample then only stages and tests those candidates.
+    // Work decomposition of the camera pass: a wave takes one 8x8 pixel block and one chunk of up to 64 samples
+    // at a time and walks through the block's pixels; in each trip its 64 LANES ARE THE SAMPLES OF ONE PIXEL.
+    // The rays of a trip then differ only by their sub-pixel jitter, so the packet frustum of the beam query is
+    // one pixel wide (459 photons accepted of ~480 tested per ray, instead of 1359 tested with one pixel per
+    // lane), the k-nearest walks of the lanes follow the same path through the tree, and pixel, NDC
+    // coordinates and camera basis are wave-uniform.  The 64 sample values of a pixel are summed across the
+    // wave in a fixed butterfly order and stored as that (pixel, chunk)'s partial sum.
+    //
+    // Beam x point estimate with a pinhole camera: the photon spheres that reach into the BLOCK's frustum are
+    // found once per work item (one tree walk) and kept in a per-wave list in global memory; each pixel trip
+    // re-culls that list against its own frustum while staging.
     uint32_t* const cand = q.cand_cap ? q.cand + size_t(blockIdx.x * 4u + wave_) * q.cand_cap : nullptr;
     const bool cand_mode = MEDIUM && q.kind == RPT_PHOTON_POINT_BEAM && q.cand_cap != 0u && a.cam.aperture <= 0.f && !(q.skip & 1u);
     uint32_t cand_n = 0;       // wave-uniform
-    bool cand_valid = false;   // wave-uniform: the list describes the block every live lane is working on
-    bool cand_fresh = false;   // wave-uniform: a full batch was just handed out, build its list
+    bool cand_valid = false;   // wave-uniform: the list describes the block this wave is working on
+    const uint32_t n_blocks64 = a.n_owned >> 6;  // 8x8 blocks owned by this rank
+    uint32_t pi = 64u, blk = 0, chunk = 0, x0 = 0, y0 = 0, n_s = 0;  // wave-uniform: pixel cursor within the block, item
+    const V cam_right = mk(a.cam.right[0], a.cam.right[1], a.cam.right[2]), cam_up = mk(a.cam.up[0], a.cam.up[1], a.cam.up[2]);
     for (;;) {
-        bool want = alive && s >= s_end;
-        if (__any(want)) {
+        if (pi == 64u) {  // next work item (wave-uniform)
+            unsigned long long got = ~0ull;
+            if (lane_ == 0) got = atomicAdd(a.queue, 1ull);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(got));
+            const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(got >> 32));
+            if (hi != 0 || lo >= a.n_items) break;
+            chunk = lo / n_blocks64;
+            blk = lo - chunk * n_blocks64;
+            const uint32_t tile = a.tiles[blk >> 4], sb = blk & 15u;
+            const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+            x0 = __builtin_amdgcn_readfirstlane(tx * 32u + (sb & 3u) * 8u);
+            y0 = __builtin_amdgcn_readfirstlane(ty * 32u + (sb >> 2) * 8u);
+            n_s = min(64u, a.iterations - chunk * 64u);
+            pi = 0u;
             cand_valid = false;
-            cand_fresh = false;
-            if (want && have_item) {
-                reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(acc.x, acc.y, acc.z, 0.f);
-                have_item = false;
-            }
-            for (;;) {
-                const uint64_t m = __ballot(want);
-                if (m == 0) break;
-                if (pool_next == pool_end) {
-                    // once this wave has seen the queue run dry it never touches the counter again: at the end
-                    // of a launch every lane of every wave retires through here, and 4096 waves x 64 atomics on
-                    // one address (~88 dequeues/us) used to cost ~1 ms per launch
-                    unsigned long long base = ~0ull;
-                    if (!drained && (threadIdx.x & 63u) == 0) base = atomicAdd(a.queue, 64ull);
-                    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(base));
-                    const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(base >> 32));
-                    if (hi != 0 || lo >= a.n_items) {
-                        drained = true;
-                        if (want) alive = false;
-                        break;
-                    }
-                    pool_next = lo;
-                    pool_end = min(lo + 64u, a.n_items);
-                    // one batch = one 8x8 pixel block of one chunk: decoded once, wave-uniformly (see kernels.hip)
-                    pool_chunk = lo / a.n_owned;
-                    const uint32_t p0 = lo - pool_chunk * a.n_owned;
-                    const uint32_t tile = a.tiles[p0 >> 10], sb = (p0 & 1023u) >> 6;
-                    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-                    pool_x0 = __builtin_amdgcn_readfirstlane(tx * 32u + (sb & 3u) * 8u);
-                    pool_y0 = __builtin_amdgcn_readfirstlane(ty * 32u + (sb >> 2) * 8u);
-                    pool_chunk = __builtin_amdgcn_readfirstlane(pool_chunk);
-                }
-                const uint32_t take = min(uint32_t(__popcll(m)), pool_end - pool_next);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-                const uint32_t item = pool_next + rank;
-                const bool got = want && rank < take;
-                // all 64 lanes take one whole, unclipped batch: they will sample the same 8x8 block in lockstep
-                cand_fresh = cand_mode && m == ~0ull && take == 64u && pool_x0 + 8u <= a.width && pool_y0 + 8u <= a.height;
-                pool_next += take;
-                if (got) {
-                    const uint32_t chunk = pool_chunk, l = item & 63u;
-                    const uint32_t x = pool_x0 + (l & 7u), y = pool_y0 + (l >> 3);
-                    if (x < a.width && y < a.height) {
-                        want = false;
-                        have_item = true;
-                        slab_idx = item;
-                        acc = mk(0, 0, 0);
-                        s = chunk * a.chunk_spp;
-                        s_end = min(s + a.chunk_spp, a.iterations);
-                        pix = y * a.width + x;
-                        xn = (float(2u * x + 1u) - float(a.width)) * a.inv_dim;
-                        yn = (float(2u * (a.height - y) - 1u) - float(a.height)) * a.inv_dim;
-                    }
+            if (cand_mode) {
+                // the four corner directions of the block (footprints included): every sample ray lies between them
+                const float e = a.inv_dim * 1.0001f;
+                const float xl = (float(2u * x0 + 1u) - float(a.width)) * a.inv_dim - e;
+                const float xh = (float(2u * (x0 + 7u) + 1u) - float(a.width)) * a.inv_dim + e;
+                const float yh = (float(2u * (a.height - y0) - 1u) - float(a.height)) * a.inv_dim + e;
+                const float yl = (float(2u * (a.height - (y0 + 7u)) - 1u) - float(a.height)) * a.inv_dim - e;
+                const V eye = mk(a.cam.eye[0], a.cam.eye[1], a.cam.eye[2]);
+                const V dd = mk(a.cam.ddir[0], a.cam.ddir[1], a.cam.ddir[2]);
+                const V corners[4] = {dd + xl * cam_right + yl * cam_up, dd + xh * cam_right + yl * cam_up,
+                                      dd + xl * cam_right + yh * cam_up, dd + xh * cam_right + yh * cam_up};
+                Frustum fr;
+                if (frustum_from_dirs(true, eye, corners, 4, fr)) {
+                    uint32_t n_list = 0;  // wave-uniform
+                    frustum_walk<true>(q.v_nodes, q.v_ph, q.n_v, fr, wstack, q.overflow, [&](bool leaf, uint32_t idx, const PhotonRec&) {
+                        const uint64_t lm = __ballot(leaf);
+                        if (leaf) {
+                            const uint32_t slot = n_list + __builtin_amdgcn_mbcnt_hi(uint32_t(lm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(lm), 0u));
+                            if (slot < q.cand_cap) cand[slot] = idx;
+                        }
+                        n_list += uint32_t(__popcll(lm));
+                    });
+                    cand_n = n_list;
+                    cand_valid = n_list <= q.cand_cap;  // an overfull list is dropped: those pixels walk the tree
                 }
             }
         }
-        if (!__any(alive)) break;
-        if (cand_mode && cand_fresh) {  // wave-uniform
-            cand_fresh = false;
-            // corner directions of this lane's pixel footprint (jitter is within +-inv_dim of the centre)
-            const V right = mk(a.cam.right[0], a.cam.right[1], a.cam.right[2]), up = mk(a.cam.up[0], a.cam.up[1], a.cam.up[2]);
-            const V eye = mk(a.cam.eye[0], a.cam.eye[1], a.cam.eye[2]);
-            const V centre = mk(a.cam.ddir[0], a.cam.ddir[1], a.cam.ddir[2]) + xn * right + yn * up;
-            const float e = a.inv_dim * 1.0001f;
-            const V corners[4] = {centre + (-e) * right + (-e) * up, centre + e * right + (-e) * up,
-                                  centre + (-e) * right + e * up, centre + e * right + e * up};
-            Frustum fr;
-            if (frustum_from_dirs(true, eye, corners, 4, fr)) {
-                uint32_t n_list = 0;  // wave-uniform
-                frustum_walk<true>(q.v_nodes, q.v_ph, q.n_v, fr, wstack, q.overflow, [&](bool leaf, uint32_t idx, const PhotonRec&) {
-                    const uint64_t lm = __ballot(leaf);
-                    if (leaf) {
-                        const uint32_t slot = n_list + __builtin_amdgcn_mbcnt_hi(uint32_t(lm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(lm), 0u));
-                        if (slot < q.cand_cap) cand[slot] = idx;
-                    }
-                    n_list += uint32_t(__popcll(lm));
-                });
-                cand_n = n_list;
-                cand_valid = n_list <= q.cand_cap;  // an overfull list is dropped: those samples walk the tree
-            }
-        }
-
-        // ---- one camera sample per live lane (dead lanes idle but stay in the wave-level votes)
-        const bool active = alive;
+        // ---- one pixel of the block per trip; lane = sample
+        const uint32_t px = x0 + (pi & 7u), py = y0 + (pi >> 3);
+        const uint32_t slab_idx = chunk * a.n_owned + blk * 64u + pi;
+        pi++;
+        if (px >= a.width || py >= a.height) continue;  // slots of clipped tiles lie outside the image (wave-uniform)
+        const uint32_t pix = py * a.width + px;
+        const float xn = (float(2u * px + 1u) - float(a.width)) * a.inv_dim;           // src/renderer.rs:174-176
+        const float yn = (float(2u * (a.height - py) - 1u) - float(a.height)) * a.inv_dim;
+        const bool active = lane_ < n_s;
         V ro = mk(0, 0, 0), rd = mk(0, 0, 1), wo = mk(0, 0, -1);
         float tmin = 0.f, t = kInf;
         uint32_t code = CODE_MISS, inst = 0;
         Rng rng;
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
         if (active) {
-            rng.seed(a.seed_mixed, pix, a.sample_offset + s);
-            s++;
+            rng.seed(a.seed_mixed, pix, a.sample_offset + chunk * 64u + lane_);
             c_samp++;
             float dx = rng.range(-a.inv_dim, a.inv_dim), dy = rng.range(-a.inv_dim, a.inv_dim);
             cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
@@ -952,6 +937,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 // this sample's own (tighter) frustum re-culls the block's candidates while they are staged
                 Frustum fs;
                 const bool have_fs = frustum_from_dirs(active, ro, &rd, 1, fs);
+                const V eye0 = mk(a.cam.eye[0], a.cam.eye[1], a.cam.eye[2]);  // pinhole: every ray starts here
+                const float far2 = wave_max(active ? t2 : 0.f);               // farthest hit of the pixel's samples (inf on a miss)
                 for (uint32_t base = 0; base < cand_n; base += 64u) {  // wave-uniform loop
                     const bool mine = base + lane_ < cand_n;
                     PhotonRec staged{};
@@ -959,7 +946,9 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     if (mine) {
                         const PhotonRec raw = q.v_ph[cand[base + lane_]];
                         take = !have_fs || !sphere_outside(fs, raw.pos_r);
-                        if (take) staged = prep_packet(raw, ro);
+                        const V cc = xyz(raw.pos_r) - eye0;
+                        take = take && dot(cc, cc) <= far2;  // the per-ray test rejects centres beyond the ray's hit
+                        if (take) staged = prep_packet(raw, eye0);  // (a staging lane need not hold a live sample: not its own ro)
                     }
                     stage_and_test(take, staged, stage, active, visit_packet);
                 }
@@ -969,12 +958,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             }
             color = vc * mcol0;
         }
-        if (!active) continue;
-        if (!hit && !MEDIUM) {
-            acc = acc + env_color(sc, rd);  // src/photon.rs:597
-            continue;
-        }
-        if (surface_on && !(q.skip & 2u)) {  // surface estimate, src/photon.rs:327-375
+        if (active && !hit && !MEDIUM) color = env_color(sc, rd);  // src/photon.rs:597
+        if (active && surface_on && !(q.skip & 2u)) {  // surface estimate, src/photon.rs:327-375
             V n;
             uint32_t obj;
             finalize_hit(sc, ro, rd, tmin, t, code, inst, n, obj);
@@ -1022,7 +1007,14 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             else if (MEDIUM) sc_col = __expf(-sigma_t * t) * sc_col;                  // :610-611
             color = color + sc_col;
         }
-        acc = acc + color;
+        // the pixel's partial sum over this chunk: its samples are summed in a fixed butterfly order (inactive lanes add 0)
+        V sum = active ? color : mk(0, 0, 0);
+        for (int off = 32; off; off >>= 1) {
+            sum.x += __shfl_xor(sum.x, off);
+            sum.y += __shfl_xor(sum.y, off);
+            sum.z += __shfl_xor(sum.z, off);
+        }
+        if (lane_ == 0) reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(sum.x, sum.y, sum.z, 0.f);
     }
     if (a.counters) {  // diagnostic: [0] camera samples, [5] photon spheres visited, [6] photon spheres accepted
         atomicAdd(&a.counters[0], c_samp);
@@ -1402,9 +1394,13 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         return rpti::fail(RPT_ERR_UNSUPPORTED, "gather sizes > 56 do not fit the LDS gather list");
     const uint64_t gather_lds = pm->kind == RPT_PHOTON_MAP ? std::max(gather_size, gather_size_volume) : gather_size;
     QueryArgs q{};
-    // work items of up to 16 samples: the per-block candidate list of the beam query is built once per item
-    int rc = rpti::prepare_render(s, cam, prm, num_samples, seed, sample_offset, q.r, 16);
+    int rc = rpti::prepare_render(s, cam, prm, num_samples, seed, sample_offset, q.r, 32);
     if (rc) return rc;
+    // Work items of the camera pass are wave-level: (8x8 pixel block, chunk of up to 64 samples).  The slab
+    // prepare_render sized for its (smaller) chunks is large enough: [n_chunks][n_owned] with fewer chunks.
+    q.r.chunk_spp = 64u;
+    q.r.n_chunks = (num_samples + 63u) / 64u;
+    q.r.n_items = (q.r.n_owned / 64u) * q.r.n_chunks;
     q.s_nodes = pm->surf.nodes; q.s_ph = pm->surf.sorted; q.n_s = pm->surf.n;
     q.v_nodes = pm->vol.nodes; q.v_ph = pm->vol.sorted; q.n_v = pm->vol.n;
     q.kind = uint32_t(pm->kind);
@@ -1442,7 +1438,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         q.cand = pm->d_cand;
         q.cand_cap = kCandCap;
     }
-    rc = rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch);
+    rc = rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch, false, true);
     if (rc == RPT_OK && sync_counters) {
         uint32_t ov = 0;
         RPTI_HIP_TRY(hipMemcpyAsync(&ov, pm->d_overflow, 4, hipMemcpyDeviceToHost, st));

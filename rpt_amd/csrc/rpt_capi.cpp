@@ -1355,13 +1355,13 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, const rpt_camera* cam, const
 
 extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st,
                          int blocks_per_cu, const std::function<hipError_t(const RenderArgs&, int, hipStream_t)>& launch,
-                         bool indexed_start) {
+                         bool indexed_start, bool wave_items) {
     HIP_TRY(hipMemsetAsync(a.queue, 0, 8, st));
     if (a.counters) HIP_TRY(hipMemsetAsync(a.counters, 0, 512, st));
     uint32_t shard_count = prm->shard_count == 0 ? 1 : prm->shard_count;
     if (shard_count > 1) HIP_TRY(hipMemsetAsync(d_out, 0, size_t(prm->width) * prm->height * 24, st));
     if (a.n_items) {
-        uint64_t want = (uint64_t(a.n_items) + 255) / 256;
+        uint64_t want = wave_items ? (uint64_t(a.n_items) + 3) / 4 : (uint64_t(a.n_items) + 255) / 256;
         int n_blocks = int(std::min<uint64_t>(uint64_t(s->n_cus) * std::max(blocks_per_cu, 1), want));
         s->last_blocks = n_blocks;
         // indexed_start: every wave of the grid takes the batch with its own index first (render_kernel's work
