@@ -142,7 +142,8 @@ int rpt_scene_stats(rpt_scene*, uint64_t out[16]);
  * [0] camera samples, [1] closest-hit queries (rays), [2] path vertices, [3] kernel loop trips
  * (wave-iterations summed over waves), [4] primitive tests, [5] BVH nodes visited,
  * [6] BVH triangle tests.  Filled only when the library is built with RPT_COUNTERS or
- * rpt_set_option("counters", 1) was called before the render; otherwise zeros. */
+ * rpt_set_option("counters", 1) was called before the render; otherwise zeros (also for a scene with a
+ * group as a Light::Object: that kernel flavour has no counters build). */
 int rpt_get_counters(rpt_scene*, uint64_t out[8]);
 /* Diagnostic (counters on): for section k of the megakernel's loop body (kernels.hip, SECT(k)),
  * out[2k] = wave-level executions and out[2k+1] = lanes active in them during the last path-traced

@@ -624,14 +624,37 @@ RPT_DEV V bsdf(const Mat& m, V n, V wo, V wi) {
 // (src/kdtree.rs:141-146 + src/shape/mesh.rs:85-99, sphere.rs:53-65, cube.rs:76-89,
 //  Transformed::sample src/shape.rs:140-151).
 // Shape::sample of the light's shape: point v, normal n, pdf p (per world area).
-RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng& rng, V& v, V& n, float& p) {
+// The transform of the sampled leaf.  A plain Light::Object is wave-uniform: the whole record sits in SGPRs.
+// A leaf picked out of a group differs per lane: its rows are loaded where they are used, so that the 48
+// floats never live in VGPRs at once.
+template <bool UNIFORM> struct LightXfRows;
+template <> struct LightXfRows<true> {
+    LightXf x;
+    RPT_DEV explicit LightXfRows(const LightXf* p) : x(uload(p)) {}
+    RPT_DEV F4 fwd(int r) const { return x.fwd[r]; }
+    RPT_DEV F4 inv(int r) const { return x.inv[r]; }
+    RPT_DEV F4 nrm(int r) const { return x.nrm[r]; }
+    RPT_DEV F4 lin(int r) const { return x.lin[r]; }
+};
+template <> struct LightXfRows<false> {
+    const LightXf* p;
+    RPT_DEV explicit LightXfRows(const LightXf* q) : p(q) {}
+    RPT_DEV F4 fwd(int r) const { return p->fwd[r]; }
+    RPT_DEV F4 inv(int r) const { return p->inv[r]; }
+    RPT_DEV F4 nrm(int r) const { return p->nrm[r]; }
+    RPT_DEV F4 lin(int r) const { return p->lin[r]; }
+};
+// One leaf shape of a Light::Object (Sphere/Cube/Mesh::sample under Transformed::sample, src/shape.rs:140-151).
+template <bool UNIFORM>
+RPT_DEV void sample_light_leaf(const SceneView& sc, uint32_t shape, uint32_t first, uint32_t count, const LightXf* xp,
+                               V pos, Rng& rng, V& v, V& n, float& p) {
     V vl, nl;
-    const LightXf x = uload(&sc.lxf[L.xf]);  // wave-uniform (the light record is): scalar loads, scalar `xf`
-    const bool xf = x.nrm[1].w != 0.f;
-    const bool mesh = L.shape == LS_MESH;
+    const LightXfRows<UNIFORM> x(xp);
+    const bool xf = x.nrm(1).w != 0.f;
+    const bool mesh = shape == LS_MESH;
     if (mesh) {
-        uint32_t idx = rng.index(L.count);
-        const LightTri tr = sc.ltris[L.first + idx];
+        uint32_t idx = rng.index(count);
+        const LightTri tr = sc.ltris[first + idx];
         float u = rng.uniform(), vv = rng.uniform();
         while (u + vv > 1.f) {
             u = rng.uniform();
@@ -640,9 +663,9 @@ RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng&
         float w = 1.f - u - vv;
         vl = u * xyz(tr.v1) + vv * xyz(tr.v2) + w * xyz(tr.v3);  // already world space
         nl = normalize(u * xyz(tr.n1) + vv * xyz(tr.n2) + w * xyz(tr.n3));
-        p = tr.v1.w * rcp(float(L.count));
-    } else if (L.shape == LS_SPHERE) {
-        V tl = xf ? mk(dot3w(x.inv[0], pos), dot3w(x.inv[1], pos), dot3w(x.inv[2], pos)) : pos;
+        p = tr.v1.w * rcp(float(count));
+    } else if (shape == LS_SPHERE) {
+        V tl = xf ? mk(dot3w(x.inv(0), pos), dot3w(x.inv(1), pos), dot3w(x.inv(2), pos)) : pos;
         float dx, dy;
         rng.unit_disc(dx, dy);
         float z = __builtin_sqrtf(fmaxf(1.f - dx * dx - dy * dy, 0.f));
@@ -667,22 +690,42 @@ RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng&
         p = 1.f / 6.f;
     }
     if (xf) {
-        n = normalize(mk(dot3(x.nrm[0], nl), dot3(x.nrm[1], nl), dot3(x.nrm[2], nl)));
-        V ln = mk(dot3(x.lin[0], nl), dot3(x.lin[1], nl), dot3(x.lin[2], nl));
+        n = normalize(mk(dot3(x.nrm(0), nl), dot3(x.nrm(1), nl), dot3(x.nrm(2), nl)));
+        V ln = mk(dot3(x.lin(0), nl), dot3(x.lin(1), nl), dot3(x.lin(2), nl));
         float height = dot(ln, n);
-        float base = x.nrm[0].w * rcp(height);
-        v = mesh ? vl : mk(dot3w(x.fwd[0], vl), dot3w(x.fwd[1], vl), dot3w(x.fwd[2], vl));
+        float base = x.nrm(0).w * rcp(height);
+        v = mesh ? vl : mk(dot3w(x.fwd(0), vl), dot3w(x.fwd(1), vl), dot3w(x.fwd(2), vl));
         p = p * rcp(base);
     } else {
         v = vl;
         n = nl;
     }
 }
+// Shape::sample of a Light::Object.  A KdTree group (src/kdtree.rs:141-146) samples a uniformly chosen child and
+// divides its pdf by the child count, nested groups repeat that: every lane descends to its own leaf.
+template <bool GROUPS>
+RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng& rng, V& v, V& n, float& p) {
+    if (!GROUPS || L.shape != LS_GROUP) {  // wave-uniform
+        sample_light_leaf<true>(sc, L.shape, L.first, L.count, &sc.lxf[L.xf], pos, rng, v, n, p);
+        return;
+    }
+    uint32_t shape = LS_GROUP, first = L.first, count = L.count, xfi = 0;
+    float pick = 1.f;
+    while (shape == LS_GROUP) {
+        const uint32_t idx = rng.index(count);
+        pick *= rcp(float(count));
+        const LightPart part = sc.lparts[first + idx];
+        shape = part.shape; first = part.first; count = part.count; xfi = part.xf;
+    }
+    sample_light_leaf<false>(sc, shape, first, count, &sc.lxf[xfi], pos, rng, v, n, p);
+    p *= pick;
+}
+template <bool GROUPS>
 RPT_DEV void illuminate_object(const SceneView& sc, const Light& L, V pos, Rng& rng, V& intensity, V& wi,
                                float& dist) {
     V v, n;
     float p;
-    sample_light_shape(sc, L, pos, rng, v, n, p);
+    sample_light_shape<GROUPS>(sc, L, pos, rng, v, n, p);
     V disp = v - pos;
     float len2 = dot(disp, disp);
     float ilen = rsq(len2);

@@ -100,17 +100,26 @@ struct alignas(16) Material {
 };
 // Light record (scene.lights order is preserved: it fixes the RNG draw order).
 enum : uint32_t { L_POINT = 0, L_AMBIENT = 1, L_DIRECTIONAL = 2, L_OBJECT = 3 };
-enum : uint32_t { LS_SPHERE = 0, LS_CUBE = 1, LS_MESH = 3 };
+enum : uint32_t { LS_SPHERE = 0, LS_CUBE = 1, LS_GROUP = 2, LS_MESH = 3 };
 struct alignas(16) Light {
     uint32_t kind;        // L_*
     uint32_t shape;       // LS_* for L_OBJECT
     int32_t twin_object;  // scene object identical to this light's object, or -1 (never visible)
-    uint32_t first;       // LS_MESH: first LightTri
-    uint32_t count;       // LS_MESH: triangle count
+    uint32_t first;       // LS_MESH: first LightTri;  LS_GROUP: first child LightPart
+    uint32_t count;       // LS_MESH: triangle count;  LS_GROUP: number of children
     uint32_t xf;          // index into lxf (every object light has one)
     uint32_t twin_lo, twin_hi;  // hit codes of the twin object's primitives when they form one range (lo <= hi)
     F4 color;             // Ambient: colour;  Object: material.color() * material.emittance()
     F4 albedo;            // Object: material.color() (photon power, src/photon.rs:757)
+};
+// A Light::Object whose shape is a KdTree<Box<dyn Bounded>>: sampling picks a child uniformly (then a
+// child of that child, ...: src/kdtree.rs:141-146), so the hierarchy is kept as parts.  A part is a group
+// (first/count index `lparts`) or a leaf shape with the transform composed down from the root.
+struct alignas(16) LightPart {
+    uint32_t shape;  // LS_*
+    uint32_t first;  // LS_GROUP: first child part;  LS_MESH: first LightTri
+    uint32_t count;  // LS_GROUP: children;          LS_MESH: triangles
+    uint32_t xf;     // leaf: index into lxf
 };
 // Light-mesh triangle: world-space vertices, LOCAL vertex normals and 1/(local area): the
 // pdf / normal mapping of Transformed::sample (src/shape.rs:140-151) is applied per sample.
@@ -153,7 +162,7 @@ struct SceneView {
     const InstRec* inst;   uint32_t n_inst;
     const Material* mats;  uint32_t n_obj;   // one material record per scene object
     const Light* lights;   uint32_t n_lights;
-    const LightTri* ltris; const LightXf* lxf;
+    const LightTri* ltris; const LightXf* lxf; const LightPart* lparts; uint32_t n_lparts;  // n_lparts != 0: some Light::Object is a group
     // medium (media[0]); has_medium = 0: surface-only branch
     uint32_t has_medium, medium_kind;
     float sigma_a, sigma_s;

@@ -74,7 +74,9 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
             }                                                                                    \
         }                                                                                        \
     } while (0)
-template <bool MEDIUM, int BVH, bool COUNT>
+// GROUPS: some Light::Object is a KdTree group (per-lane leaf sampler).  A separate instantiation: the extra
+// sampler copy costs the plain kernels 6 % through register allocation alone, and a call costs 6x.
+template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false>
 __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
     extern __shared__ uint32_t dyn_lds[];
     const SceneView& sc = a.sc;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
                 V I, wi;
                 float dist;
                 SECT(7);
-                illuminate_object(sc, L, x, rng, I, wi, dist);
+                illuminate_object<GROUPS>(sc, L, x, rng, I, wi, dist);
                 if (L.twin_object >= 0) {
                     SECT(8);
                     // Reference: contributes iff the closest hit along wi lies at dist_to_light
@@ -504,7 +506,10 @@ static constexpr size_t kStateBytesBvh = 5u * 256u * sizeof(uint32_t);   // ... 
 
 template <bool M, int B, bool C>
 static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t stream) {
-    hipLaunchKernelGGL((render_kernel<M, B, C>), dim3(n_blocks), dim3(256), B ? kStackBytes + kStateBytesBvh : kStateBytes, stream, a);
+    const size_t lds = B ? kStackBytes + kStateBytesBvh : kStateBytes;
+    // group lights have no counters build: the section counters stay zero for such scenes
+    if (a.sc.n_lparts) hipLaunchKernelGGL((render_kernel<M, B, false, true>), dim3(n_blocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((render_kernel<M, B, C>), dim3(n_blocks), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 template <bool M, bool C>

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
         const bool beams = a.kind == RPT_PHOTON_BEAM_BEAM;
         V ro, n0;
         float p0;
-        sample_light_shape(sc, L, mk(0.f, 0.f, 0.f), rng, ro, n0, p0);  // :733-734 (target is a dummy)
+        sample_light_shape<true>(sc, L, mk(0.f, 0.f, 0.f), rng, ro, n0, p0);  // :733-734 (target is a dummy)
         float u1 = rng.uniform(), u2 = rng.uniform();
         float ct = 1.f - u2;                                           // theta = acos(1 - u), :738
         float st = __builtin_sqrtf(fmaxf(1.f - ct * ct, 0.f));

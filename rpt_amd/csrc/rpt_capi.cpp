@@ -544,8 +544,6 @@ int rpt_scene_add_light_object(rpt_scene* s, const rpt_shape_desc* d, const rpt_
     if (!copy_shape(s, seen, d, l.obj.shape, why) || !check_material(m, why)) return fail(RPT_ERR_INVALID, why);
     if (d->kind == RPT_SHAPE_PLANE)
         return fail(RPT_ERR_INVALID, "a plane cannot be a Light::Object (Plane::sample is unimplemented in rpt)");
-    if (d->kind == RPT_SHAPE_GROUP)
-        return fail(RPT_ERR_UNSUPPORTED, "a KdTree group as a Light::Object is not supported on the device");
     l.obj.mat = *m;
     s->lights.push_back(std::move(l));
     return RPT_OK;
@@ -706,6 +704,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     std::vector<Light> lights;
     std::vector<LightTri> ltris;
     std::vector<LightXf> lxf;
+    std::vector<LightPart> lparts;
 
     // World-space boxes of the bounded primitives, for the scene-level BVH.
     struct PBox { float lo[3], hi[3]; };
@@ -937,41 +936,64 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                          float(has ? o.mat.albedo[2] * e : 0.0), 0.f};
             L.albedo = F4{float(has ? o.mat.albedo[0] : 0.0), float(has ? o.mat.albedo[1] : 0.0),
                           float(has ? o.mat.albedo[2] : 0.0), 0.f};
+            // leaf shape -> LightXf (+ triangles); group -> parts tree (children contiguous, nested groups appended)
+            std::function<LightPart(const HShape&, const Xf&)> light_part = [&](const HShape& shp, const Xf& x) -> LightPart {
+                LightPart part{};
+                if (shp.d.kind == RPT_SHAPE_GROUP) {
+                    part.shape = LS_GROUP;
+                    part.first = uint32_t(lparts.size());
+                    part.count = uint32_t(shp.children.size());
+                    lparts.resize(lparts.size() + shp.children.size());
+                    for (size_t c = 0; c < shp.children.size(); c++) {
+                        Xf cx;
+                        compose_xf(x, shp.children[c].d, cx);
+                        const LightPart child = light_part(shp.children[c], cx);  // may grow lparts: index, not reference
+                        lparts[part.first + c] = child;
+                    }
+                    return part;
+                }
+                LightXf gx;
+                for (int r = 0; r < 3; r++) {
+                    gx.fwd[r] = F4{float(x.M[r][0]), float(x.M[r][1]), float(x.M[r][2]), float(x.M[r][3])};
+                    gx.inv[r] = F4{float(x.Minv[r][0]), float(x.Minv[r][1]), float(x.Minv[r][2]), float(x.Minv[r][3])};
+                    gx.nrm[r] = F4{float(x.N[r][0]), float(x.N[r][1]), float(x.N[r][2]), 0.f};
+                    gx.lin[r] = F4{float(x.L[r][0]), float(x.L[r][1]), float(x.L[r][2]), 0.f};
+                }
+                gx.nrm[0].w = float(x.det);
+                gx.nrm[1].w = x.has ? 1.f : 0.f;
+                part.xf = uint32_t(lxf.size());
+                lxf.push_back(gx);
+                if (shp.d.kind == RPT_SHAPE_MESH) {
+                    part.shape = LS_MESH;
+                    part.first = uint32_t(ltris.size());
+                    const uint64_t nt = shp.T().size() / 18;
+                    part.count = uint32_t(nt);
+                    for (uint64_t i = 0; i < nt; i++) {
+                        const double* t = &shp.T()[i * 18];
+                        D3 a = d3(t), b = d3(t + 3), c = d3(t + 6);
+                        D3 cr = cross(b - a, c - a);
+                        double area = 0.5 * std::sqrt(dot(cr, cr));  // local-space area (src/shape/mesh.rs:93)
+                        LightTri lt;
+                        lt.v1 = f4(x.point(a), 1.0 / area);
+                        lt.v2 = f4(x.point(b), 0);
+                        lt.v3 = f4(x.point(c), 0);
+                        lt.n1 = f4(d3(t + 9), 0);   // local normals; Transformed::sample maps them per sample
+                        lt.n2 = f4(d3(t + 12), 0);
+                        lt.n3 = f4(d3(t + 15), 0);
+                        ltris.push_back(lt);
+                    }
+                } else {
+                    part.shape = shp.d.kind == RPT_SHAPE_SPHERE ? LS_SPHERE : LS_CUBE;
+                }
+                return part;
+            };
             Xf x;
             make_xf(o.shape.d, x);
-            LightXf gx;
-            for (int r = 0; r < 3; r++) {
-                gx.fwd[r] = F4{float(x.M[r][0]), float(x.M[r][1]), float(x.M[r][2]), float(x.M[r][3])};
-                gx.inv[r] = F4{float(x.Minv[r][0]), float(x.Minv[r][1]), float(x.Minv[r][2]), float(x.Minv[r][3])};
-                gx.nrm[r] = F4{float(x.N[r][0]), float(x.N[r][1]), float(x.N[r][2]), 0.f};
-                gx.lin[r] = F4{float(x.L[r][0]), float(x.L[r][1]), float(x.L[r][2]), 0.f};
-            }
-            gx.nrm[0].w = float(x.det);
-            gx.nrm[1].w = x.has ? 1.f : 0.f;
-            L.xf = uint32_t(lxf.size());
-            lxf.push_back(gx);
-            if (o.shape.d.kind == RPT_SHAPE_MESH) {
-                L.shape = LS_MESH;
-                L.first = uint32_t(ltris.size());
-                uint64_t nt = o.shape.T().size() / 18;
-                L.count = uint32_t(nt);
-                for (uint64_t i = 0; i < nt; i++) {
-                    const double* t = &o.shape.T()[i * 18];
-                    D3 a = d3(t), b = d3(t + 3), c = d3(t + 6);
-                    D3 cr = cross(b - a, c - a);
-                    double area = 0.5 * std::sqrt(dot(cr, cr));  // local-space area (src/shape/mesh.rs:93)
-                    LightTri lt;
-                    lt.v1 = f4(x.point(a), 1.0 / area);
-                    lt.v2 = f4(x.point(b), 0);
-                    lt.v3 = f4(x.point(c), 0);
-                    lt.n1 = f4(d3(t + 9), 0);   // local normals; Transformed::sample maps them per sample
-                    lt.n2 = f4(d3(t + 12), 0);
-                    lt.n3 = f4(d3(t + 15), 0);
-                    ltris.push_back(lt);
-                }
-            } else {
-                L.shape = o.shape.d.kind == RPT_SHAPE_SPHERE ? LS_SPHERE : LS_CUBE;
-            }
+            const LightPart root = light_part(o.shape, x);
+            L.shape = root.shape;
+            L.first = root.first;
+            L.count = root.count;
+            L.xf = root.xf;
         }
         lights.push_back(L);
     }
@@ -1170,6 +1192,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     size_t o_lights = reserve(lights.size() * sizeof(Light));
     size_t o_ltris = reserve(ltris.size() * sizeof(LightTri));
     size_t o_lxf = reserve(lxf.size() * sizeof(LightXf));
+    size_t o_lparts = reserve(lparts.size() * sizeof(LightPart));
     size_t o_hdri = reserve(s->hdri.size() * sizeof(float));
     std::vector<char> host(off, 0);
     auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
@@ -1189,6 +1212,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     put(o_lights, lights.data(), lights.size() * sizeof(Light));
     put(o_ltris, ltris.data(), ltris.size() * sizeof(LightTri));
     put(o_lxf, lxf.data(), lxf.size() * sizeof(LightXf));
+    put(o_lparts, lparts.data(), lparts.size() * sizeof(LightPart));
     put(o_hdri, s->hdri.data(), s->hdri.size() * sizeof(float));
     HIP_TRY(hipMalloc(&s->arena, off));
     HIP_TRY(hipMemcpy(s->arena, host.data(), off, hipMemcpyHostToDevice));
@@ -1210,6 +1234,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     v.mats = (const Material*)(base + o_mats);  v.n_obj = uint32_t(mats.size());
     v.lights = (const Light*)(base + o_lights); v.n_lights = uint32_t(lights.size());
     v.ltris = (const LightTri*)(base + o_ltris); v.lxf = (const LightXf*)(base + o_lxf);
+    v.lparts = (const LightPart*)(base + o_lparts); v.n_lparts = uint32_t(lparts.size());
     v.has_medium = s->media.empty() ? 0u : 1u;
     v.medium_kind = 0;
     v.sigma_a = v.sigma_s = 0.f;

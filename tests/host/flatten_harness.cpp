@@ -98,6 +98,9 @@ int main() {
         kids.push_back(kdtree(inner).translate({0, 0, 2}));
         add(s, kdtree(kids).rotate_y(0.2));
         add(s, plane({0, 0, 1}, -6.0));
+        // the nested group once more as a Light::Object: parts tree, a transform and triangles per leaf
+        std::vector<Shape> lamp = {sphere().translate({0, 3, 0}), shared.translate({1, 3, 0}), kdtree(inner).scale({2, 2, 2})};
+        add(s, kdtree(lamp).rotate_x(0.3), true);
         report("groups", s);
         rpt_scene_destroy(s);
     }
