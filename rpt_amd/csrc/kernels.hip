@@ -232,7 +232,10 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
         }
         const V wo = -normalize(rd);
         const float tmin = ray_tmin(ro);
-        float t = kInf;
+        // A hit beyond the sampled medium distance cannot change the event (dmed < t, or a miss with dmed < 400,
+        // is a medium event either way, src/renderer.rs:197-243): the search interval ends there, which culls
+        // most of a tree walk in fog.  The margin keeps the `dmed < t` comparison below the one that decides.
+        float t = (MEDIUM && dmed < 400.f) ? dmed * (1.f + 1e-6f) : kInf;
         uint32_t code = CODE_MISS, inst = 0;
         closest_hit<BVH, COUNT>(sc, ro, rd, tmin, t, code, inst, stk, stride, c_nodes, c_btris);
         if (COUNT) c_rays++;
