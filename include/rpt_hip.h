@@ -161,7 +161,10 @@ int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* g
  * rectangles that are the faces of one axis-aligned box with a single slab test, default 1),
  * "photon_block_lists" 0/1 (camera pass of the beam x point kind: collect the photon spheres of each 8x8
  * pixel block once per work batch, default 1; 0 walks the tree per sample), "photon_skip" (diagnostic bit
- * mask that switches parts of the photon camera pass off); returns RPT_ERR_INVALID for unknown names. */
+ * mask that switches parts of the photon camera pass off), "defer_lanes" / "defer_stop" (scenes whose meshes
+ * have their own trees: a wave starts its parked tree walks when this many lanes wait, default 32, and leaves
+ * them when fewer than this many are still walking, default 16; the image does not depend on either);
+ * returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 
 /* ---- Buffer on the device (src/buffer.rs:5-97): the samples of each pixel are kept as running

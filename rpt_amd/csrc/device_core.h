@@ -367,20 +367,8 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
     }
 }
 
-// BVH: 0 = no tree in the scene, 1 = per-mesh trees only, 2 = scene-level tree possible.
-template <int BVH, bool COUNT, bool ANY = false>
-RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
-                         uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris,
-                         AnyHit any = AnyHit{-kInf, 1u, 0u}) {
-    if (BVH == 2 && sc.scene_bvh) {  // wave-uniform: planes (unbounded) are scanned, everything else is in the tree
-        for (uint32_t i = 0; i < sc.n_pln; i++) {
-            const F4 nv = uload(&sc.pln[i]).nv;
-            float t = hit_plane(nv, o, d, tmin);
-            if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
-        }
-        bvh_traverse<COUNT, true, ANY>(sc, sc.top_root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
-        return;
-    }
+// The linear scan over the wave-uniform primitive records (everything that is not in a tree).
+RPT_DEV void scan_prims(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code) {
     for (uint32_t i = 0; i < sc.n_sph; i++) {
         const XfScan x = uload(&sc.sph[i]);
         V ol, dl;
@@ -433,13 +421,113 @@ RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest
         float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
         if (t >= 0.f) { tbest = t; code = (K_TRI << 28) | i; }
     }
-    if (BVH) {
-        for (uint32_t i = 0; i < sc.n_mesh; i++) {
-            const MeshRef m = uload(&sc.meshes[i]);
-            if (ANY && code != CODE_MISS && any.blocks(tbest, code)) break;  // (per lane) already occluded
-            bvh_traverse<COUNT, false, ANY>(sc, m.root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
+}
+// Would a walk of the per-mesh trees visit anything?  The two child boxes of every mesh root against the
+// interval the scan left (scalar loads: the roots are wave-uniform).
+RPT_DEV bool mesh_roots_hit(const SceneView& sc, V o, V d, float tmin, float tbest) {
+    const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
+    bool need = false;
+    for (uint32_t i = 0; i < sc.n_mesh; i++) {
+        const MeshRef m = uload(&sc.meshes[i]);
+        const BvhNode nd = uload(&sc.nodes[m.root]);
+        float n0, f0, n1, f1;
+        slab2(nd.lo0, nd.hi0, o, inv, n0, f0);
+        slab2(nd.lo1, nd.hi1, o, inv, n1, f1);
+        need = need || fmaxf(n0, tmin) <= fminf(f0, tbest) || fmaxf(n1, tmin) <= fminf(f1, tbest);
+    }
+    return need;
+}
+template <bool COUNT, bool ANY>
+RPT_DEV void walk_meshes(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
+                         uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris, AnyHit any) {
+    for (uint32_t i = 0; i < sc.n_mesh; i++) {
+        const MeshRef m = uload(&sc.meshes[i]);
+        if (ANY && code != CODE_MISS && any.blocks(tbest, code)) break;  // (per lane) already occluded
+        bvh_traverse<COUNT, false, ANY>(sc, m.root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
+    }
+}
+// The same walk as a resumable one (deferred walks of the render kernel): the lane's position -- current entry,
+// stack height, mesh -- lives in `w` and its stack column in LDS, and the wave leaves the loop as soon as fewer
+// than `min_active` lanes are still walking; the stragglers continue with the next batch of parked walks instead
+// of holding 60 idle lanes.  w.cur == kWalkDone: nothing left to do.
+static const uint32_t kWalkDone = 0xFFFFFFFFu;  // has the leaf bit set; a 32-item prim leaf at the last index never occurs
+struct WalkState {
+    uint32_t cur, sp, mesh;
+};
+RPT_DEV WalkState walk_begin(const SceneView& sc) { return WalkState{uload(&sc.meshes[0]).root, 0u, 0u}; }
+template <bool COUNT>
+RPT_DEV void walk_meshes_resumable(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t* stk,
+                                   uint32_t stride, WalkState& w, uint32_t min_active, AnyHit any, uint32_t& c_nodes,
+                                   uint32_t& c_tris) {
+    const BvhNode* nodes = sc.nodes;
+    const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
+    const uint32_t cap = 32u;
+    uint32_t cur = w.cur, sp = w.sp, mesh = w.mesh;
+    while (uint32_t(__popcll(__ballot(cur != kWalkDone))) >= min_active) {
+        while (!(cur & BVH_LEAF)) {  // kWalkDone has the leaf bit set, so finished lanes fall through
+            const BvhNode nd = nodes[cur];
+            if (COUNT) c_nodes++;
+            float n0, f0, n1, f1;
+            slab2(nd.lo0, nd.hi0, o, inv, n0, f0);
+            slab2(nd.lo1, nd.hi1, o, inv, n1, f1);
+            const bool h0 = fmaxf(n0, tmin) <= fminf(f0, tbest);
+            const bool h1 = fmaxf(n1, tmin) <= fminf(f1, tbest);
+            if (h0 && h1) {
+                const bool first0 = n0 <= n1;
+                if (sp < cap) { stk[sp * stride] = first0 ? nd.e1 : nd.e0; sp++; }
+                cur = first0 ? nd.e0 : nd.e1;
+            } else if (h0 || h1) {
+                cur = h0 ? nd.e0 : nd.e1;
+            } else if (sp) {
+                sp--;
+                cur = stk[sp * stride];
+            } else {
+                cur = kWalkDone;
+            }
+        }
+        if (cur != kWalkDone) {
+            const uint32_t first = cur & BVH_INDEX_MASK;
+            const uint32_t count = ((cur >> 26) & 31u) + 1u;
+            for (uint32_t i = 0; i < count; i++) {
+                const TriScan tr = sc.btri[first + i];
+                if (COUNT) c_tris++;
+                float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
+                if (t >= 0.f) { tbest = t; code = (K_BVHTRI << 28) | (first + i); }
+            }
+            if (code != CODE_MISS && any.blocks(tbest, code)) { sp = 0; mesh = sc.n_mesh; }  // an occluder is known
+            if (sp) {
+                sp--;
+                cur = stk[sp * stride];
+            } else {
+                cur = kWalkDone;
+            }
+        }
+        if (cur == kWalkDone && mesh + 1u < sc.n_mesh) {  // the next mesh's tree
+            mesh++;
+            cur = sc.meshes[mesh].root;
         }
     }
+    w.cur = cur;
+    w.sp = sp;
+    w.mesh = mesh;
+}
+
+// BVH: 0 = no tree in the scene, 1 = per-mesh trees only, 2 = scene-level tree possible.
+template <int BVH, bool COUNT, bool ANY = false>
+RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
+                         uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris,
+                         AnyHit any = AnyHit{-kInf, 1u, 0u}) {
+    if (BVH == 2 && sc.scene_bvh) {  // wave-uniform: planes (unbounded) are scanned, everything else is in the tree
+        for (uint32_t i = 0; i < sc.n_pln; i++) {
+            const F4 nv = uload(&sc.pln[i]).nv;
+            float t = hit_plane(nv, o, d, tmin);
+            if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
+        }
+        bvh_traverse<COUNT, true, ANY>(sc, sc.top_root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
+        return;
+    }
+    scan_prims(sc, o, d, tmin, tbest, code);
+    if (BVH) walk_meshes<COUNT, ANY>(sc, o, d, tmin, tbest, code, inst, stk, stride, c_nodes, c_tris, any);
 }
 
 // Normal and object of the winning primitive (per lane).

@@ -25,6 +25,8 @@ struct RenderArgs {
     unsigned long long* queue;  // 64-bit work counter (zeroed before the launch)
     unsigned long long* counters;  // 8 x u64 or nullptr
     uint32_t lds_stack;       // 1: BVH stack in dynamic LDS
+    uint32_t defer_lanes;     // per-mesh-tree kernels: parked tree walks per wave that trigger a walk (1..64)
+    uint32_t defer_stop;      // ... and the number of still-walking lanes below which the wave leaves the walk
 };
 
 struct KernelInfo {

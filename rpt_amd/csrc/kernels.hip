@@ -123,6 +123,20 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
 
     uint32_t c_samples = 0, c_rays = 0, c_vertices = 0, c_trips = 0, c_nodes = 0, c_btris = 0;
 
+    // ---- per-mesh-tree flavour (BVH == 1): deferred walks.  In fog most rays never reach a mesh, a few walk
+    // a hundred nodes, and a wave walks as long as its slowest lane: 43 wave-level node steps per query for 3.4
+    // nodes per ray (8 % of the lanes busy) on C5.  So a query is split: the scan and a test of the mesh roots'
+    // child boxes run at once; a lane that really has to walk parks the query and waits (phase PH_WAIT*) while the
+    // rest of the wave goes on with its paths; when `defer_lanes` lanes wait (or nothing else can run) they walk
+    // together.  Every lane still computes exactly the same sequence: the image is bit-identical.
+    enum : uint32_t { PH_NEW = 0, PH_HAVEP = 1, PH_LIGHT = 2, PH_HAVES = 3, PH_WAITP = 4, PH_WAITS = 5 };
+    uint32_t phase = PH_NEW, q_code = CODE_MISS, q_inst = 0, v_li = 0;
+    float q_t = kInf, v_dmed = kInf, v_dist = 0.f;
+    V v_x = mk(0, 0, 0), v_n = mk(0, 1, 0), v_mcol = mk(0, 0, 0), v_E = mk(0, 0, 0), v_I = mk(0, 0, 0), v_wi = mk(0, 0, 1);
+    Mat v_mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
+    bool v_medium = false;
+    WalkState walk{kWalkDone, 0u, 0u};
+
     for (;;) {
         // ---- work distribution (wave-convergent).  A wave draws batches of 64 items from the global
         // 64-bit counter with ONE atomic per batch and hands them to the lanes that finished their
@@ -220,6 +234,163 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
         }
         if (!__any(alive)) break;
         if (COUNT && (threadIdx.x & 63u) == 0) c_trips++;
+        if constexpr (BVH == 1) {
+            // ---- A: a new path vertex: distance sample, scan, do the trees matter?
+            if (alive && phase == PH_NEW) {
+                if (COUNT) c_vertices++;
+                SECT(2);
+                v_dmed = kInf;
+                if (MEDIUM) {  // Medium::sample_d, src/medium.rs:133-146
+                    float xi = rng.range(0.f, 1.f);
+                    v_dmed = -__logf(xi) * inv_sigma_t;
+                }
+                const float tmin = ray_tmin(ro);
+                q_t = (MEDIUM && v_dmed < 400.f) ? v_dmed * (1.f + 1e-6f) : kInf;  // see the undeferred body below
+                q_code = CODE_MISS;
+                q_inst = 0;
+                scan_prims(sc, ro, rd, tmin, q_t, q_code);
+                if (COUNT) c_rays++;
+                phase = mesh_roots_hit(sc, ro, rd, tmin, q_t) ? PH_WAITP : PH_HAVEP;
+                walk = walk_begin(sc);
+            }
+            // ---- B: the event (src/renderer.rs:197-243, 288-299)
+            if (alive && phase == PH_HAVEP) {
+                SECT(3);
+                const bool hit = q_code != CODE_MISS;
+                v_medium = MEDIUM && (v_dmed < (hit ? q_t : 400.f));
+                if (!v_medium && !hit) {
+                    SECT(4);
+                    acc_add(vmin(fma3(Q, env_color(sc, rd), P), Rc));
+                    need_path = true;
+                    phase = PH_NEW;
+                } else {
+                    if (v_medium) {
+                        SECT(5);
+                        v_x = fma3(v_dmed, rd, ro);
+                        bool hi = sc.medium_kind == 1u && v_x.y > 250.f;
+                        v_mcol = hi ? mk(sc.medium_color_hi[0], sc.medium_color_hi[1], sc.medium_color_hi[2])
+                                    : mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);
+                        v_E = (depth == 0) ? sc.medium_emission * v_mcol : mk(0, 0, 0);
+                    } else {
+                        uint32_t obj;
+                        SECT(6);
+                        finalize_hit(sc, ro, rd, ray_tmin(ro), q_t, q_code, q_inst, v_n, obj);
+                        v_mat = load_mat(sc, obj);
+                        v_x = fma3(q_t, rd, ro);
+                        v_E = (depth == 0) ? mat_emit(v_mat) * mat_color(v_mat) : mk(0, 0, 0);
+                    }
+                    v_li = 0;
+                    phase = PH_LIGHT;
+                }
+            }
+            // ---- L: next-event estimation, one light per iteration; a lane joins at the light it stands at
+            for (uint32_t l = 0; l < sc.n_lights; l++) {
+                const bool pre = alive && phase == PH_LIGHT && v_li == l;
+                if (!__any(pre || (alive && phase == PH_HAVES && v_li == l))) continue;
+                const Light L = uload(&sc.lights[l]);
+                if (pre) {
+                    bool next = true;
+                    if (L.kind == L_AMBIENT) {
+                        v_E = fma3(xyz(L.color), v_medium ? v_mcol : mat_color(v_mat), v_E);
+                    } else if (L.kind == L_OBJECT) {
+                        SECT(7);
+                        illuminate_object<GROUPS>(sc, L, v_x, rng, v_I, v_wi, v_dist);
+                        if (L.twin_object >= 0) {  // the shadow query (see the undeferred body)
+                            SECT(8);
+                            const float tm = ray_tmin(v_x);
+                            q_t = v_dist * (1.f + 1e-3f);
+                            q_code = CODE_MISS;
+                            q_inst = 0;
+                            scan_prims(sc, v_x, v_wi, tm, q_t, q_code);
+                            if (COUNT) c_rays++;
+                            const AnyHit any{L.twin_lo <= L.twin_hi ? v_dist * (1.f - 1e-3f) : -kInf, L.twin_lo, L.twin_hi};
+                            const bool blocked = q_code != CODE_MISS && any.blocks(q_t, q_code);
+                            phase = (!blocked && mesh_roots_hit(sc, v_x, v_wi, tm, q_t)) ? PH_WAITS : PH_HAVES;
+                            walk = walk_begin(sc);
+                            next = false;
+                        }
+                    }
+                    if (next) v_li = l + 1u;
+                }
+                if (alive && phase == PH_HAVES && v_li == l) {
+                    SECT(9);
+                    const bool twin = (L.twin_lo <= L.twin_hi) ? (q_code >= L.twin_lo && q_code <= L.twin_hi)
+                                                               : (q_code != CODE_MISS && code_object(sc, q_code, q_inst) == uint32_t(L.twin_object));
+                    if (q_code != CODE_MISS && q_t >= v_dist * (1.f - 1e-3f) && twin) {
+                        if (v_medium) {
+                            v_E = fma3(albedo_med * sc.medium_phase, v_I * v_mcol, v_E);
+                        } else {
+                            V f = bsdf(v_mat, v_n, -normalize(rd), v_wi);
+                            v_E = fma3(dot(v_wi, v_n), f * v_I, v_E);
+                        }
+                    }
+                    v_li = l + 1u;
+                    phase = PH_LIGHT;
+                }
+            }
+            // ---- C: continue or end the path
+            if (alive && phase == PH_LIGHT && v_li >= sc.n_lights) {
+                bool bounce;
+                V wi = mk(0, 0, 1), k = mk(0, 0, 0);
+                SECT(10);
+                if (v_medium) {  // src/renderer.rs:262-281
+                    SECT(11);
+                    bounce = rng.uniform() < 0.8f;
+                    if (bounce) {
+                        float ax = rng.range(-1.f, 1.f), ay = rng.range(-1.f, 1.f), az = rng.range(-1.f, 1.f);
+                        wi = normalize(mk(ax, ay, az));
+                        k = (albedo_med * 1.25f) * v_mcol;
+                    }
+                } else {
+                    SECT(12);
+                    bounce = MEDIUM ? (rng.uniform() < 0.8f) : (depth < a.max_bounces);
+                    if (bounce) {
+                        float pdf;
+                        SECT(13);
+                        const V wo = -normalize(rd);
+                        bounce = sample_f(v_mat, v_n, wo, rng, wi, pdf);
+                        if (bounce) {
+                            V f = bsdf(v_mat, v_n, wo, wi);
+                            float wgt = fabsf(dot(wi, v_n)) * rcp(MEDIUM ? pdf * 0.8f : pdf);
+                            k = wgt * f;
+                        }
+                    }
+                }
+                SECT(14);
+                P = fma3(Q, v_E, P);
+                if (bounce && !is_zero(k)) {
+                    if (!MEDIUM) Rc = vmin(Rc, fma3(100.f, Q, P));
+                    Q = Q * k;
+                    ro = v_x;
+                    rd = wi;
+                    depth++;
+                } else {
+                    acc_add(vmin(P, Rc));
+                    need_path = true;
+                }
+                phase = PH_NEW;
+            }
+            // ---- the parked walks: start when enough lanes wait, stop when most of them are through
+            const bool waiting = alive && phase >= PH_WAITP;
+            const uint64_t wm = __ballot(waiting);
+            const bool idle = __ballot(alive && !waiting) == 0;  // nothing else this wave could do
+            if (wm != 0 && (uint32_t(__popcll(wm)) >= a.defer_lanes || idle)) {
+                if (waiting) {
+                    SECT(15);
+                    const bool shadow = phase == PH_WAITS;
+                    const V qo = shadow ? v_x : ro, qd = shadow ? v_wi : rd;
+                    AnyHit any{-kInf, 1u, 0u};  // a primary query: nothing blocks
+                    if (shadow) {
+                        const uint32_t lo = sc.lights[v_li].twin_lo, hi = sc.lights[v_li].twin_hi;
+                        any = AnyHit{lo <= hi ? v_dist * (1.f - 1e-3f) : -kInf, lo, hi};
+                    }
+                    walk_meshes_resumable<COUNT>(sc, qo, qd, ray_tmin(qo), q_t, q_code, stk, stride, walk,
+                                                 idle ? 1u : a.defer_stop, any, c_nodes, c_btris);
+                    if (walk.cur == kWalkDone) phase = shadow ? PH_HAVES : PH_HAVEP;
+                }
+            }
+            continue;
+        }
         if (!alive) continue;
 
         // ---- one path vertex (one trace_ray invocation, src/renderer.rs:187-322)

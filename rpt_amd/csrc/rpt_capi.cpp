@@ -58,6 +58,8 @@ int64_t option_photon_skip() { return g_opt_photon_skip; }
 int64_t option_photon_block_lists() { return g_opt_photon_block_lists; }
 }
 static int64_t g_opt_instancing = 1;     // meshes shared by several shapes are stored once and instanced
+static int64_t g_opt_defer_stop = 16;     // still-walking lanes below which a wave leaves the walk (the rest resume later)
+static int64_t g_opt_defer_lanes = 32;    // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
 static int64_t g_opt_scene_bvh_min = 64;  // bounded primitives + BVH meshes from which the scene-level BVH is built
 
 // ---------------------------------------------------------------------------- fp64 helpers
@@ -480,6 +482,8 @@ int rpt_set_option(const char* name, int64_t value) {
     else if (s == "photon_skip") g_opt_photon_skip = value;
     else if (s == "photon_block_lists") g_opt_photon_block_lists = value;
     else if (s == "instancing") g_opt_instancing = value;
+    else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); g_opt_defer_lanes = value; }
+    else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); g_opt_defer_stop = value; }
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); g_opt_scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option " + s);
     return RPT_OK;
@@ -1375,6 +1379,8 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, const rpt_camera* cam, const
     a.queue = s->d_queue;
     a.counters = g_opt_counters ? s->d_counters : nullptr;
     a.lds_stack = s->view.n_nodes ? 1u : 0u;
+    a.defer_lanes = uint32_t(g_opt_defer_lanes);
+    a.defer_stop = uint32_t(std::min(g_opt_defer_stop, g_opt_defer_lanes));
     return RPT_OK;
 }
 

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from rpt_amd import Renderer, scenes
+from rpt_amd import Camera, Material, Object, Renderer, Scene, plane, scenes, vec3
 from rpt_amd import _lib
 from tests.util import random_rays, rel_rms
 
@@ -282,6 +282,48 @@ def test_mesh_in_fog_render_matches_oracle():
     assert np.all(np.isfinite(got)) and exp.mean() > 0
     assert rel_rms(got, exp) < 1e-2
     assert abs(got.mean() - exp.mean()) / exp.mean() < 5e-3
+
+
+@pytest.mark.parametrize("fog", [True, False])
+def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
+    """Per-mesh-tree kernels park the tree walks of a wave and run them together (kernels.hip, PH_WAIT*):
+    when they start ("defer_lanes") and when the wave leaves them ("defer_stop") must not change one bit --
+    every lane computes its own path in its own order -- and the frame matches the oracle.  Two meshes, two
+    object lights with twins (shadow walks with an occluder range), surface and medium events."""
+    import rpt_amd
+    from rpt_amd import Light, Medium, Mesh
+    sc = Scene()
+    sc.add(Object(Mesh(scenes.bumpy_torus(40, 24)).scale(vec3(2, 2, 2)).rotate_x(0.6)).material(Material.specular(vec3(0.8, 0.6, 0.3), 0.2)))
+    sc.add(Object(Mesh(scenes.bumpy_torus(24, 24)).translate(vec3(1.0, 0.8, 0.5))).material(Material.diffuse(vec3(0.3, 0.6, 0.9))))
+    sc.add(Object(plane(vec3(0, 1, 0), -1.0)).material(Material.diffuse(vec3(0.8, 0.8, 0.8))))
+    for pos, col in ((vec3(0.0, 3.0, 0.0), vec3(1, 1, 1)), (vec3(2.5, 1.0, 2.0), vec3(1.0, 0.5, 0.2))):
+        lamp = Mesh(scenes.bumpy_torus(4, 3)).scale(vec3(0.8, 0.8, 0.8)).translate(pos)
+        sc.add(Object(lamp.clone()).material(Material.light(col, 30.0)))
+        sc.add(Light.Object(Object(lamp.clone()).material(Material.light(col, 30.0))))
+    if fog:
+        sc.add(Medium.homogeneous_isotropic(0.02, 0.1))
+    cam = Camera.look_at(vec3(0.0, 1.5, 6.0), vec3(0.0, 0.0, 0.0), vec3(0, 1, 0), 0.8)
+    w, h, spp = 96, 72, 24
+
+    def render(lanes, stop):
+        rpt_amd.set_option("defer_lanes", lanes)
+        rpt_amd.set_option("defer_stop", stop)
+        r = Renderer(sc, cam).width(w).height(h).max_bounces(3).seed(6)
+        img = r.sample_array(spp)
+        st = r.scene_stats()
+        assert st["bvh_nodes"] > 0 and st["scene_bvh"] == 0      # the per-mesh-tree kernel
+        return img
+    try:
+        frames = [render(*v) for v in ((32, 16), (1, 1), (64, 64), (64, 1), (8, 5))]
+    finally:
+        rpt_amd.set_option("defer_lanes", 32)
+        rpt_amd.set_option("defer_stop", 16)
+    for f in frames[1:]:
+        assert np.array_equal(frames[0], f)
+    exp = _oracle(sc).render(cam, w, h, spp, 3, seed=6, robust=1)
+    assert np.all(np.isfinite(frames[0])) and exp.mean() > 0
+    assert rel_rms(frames[0], exp) < 2e-2
+    assert abs(frames[0].mean() - exp.mean()) / exp.mean() < 5e-3
 
 
 def test_cpp_mirror_example_renders_the_same_bytes_as_the_python_mirror():

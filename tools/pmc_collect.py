@@ -11,7 +11,7 @@ tot, launches = defaultdict(float), defaultdict(set)
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
-        if "render_kernel" not in name or re.search(r"render_kernel<\w+, \d, true>", name) or "ELb1EEE" in name:
+        if "render_kernel" not in name or re.search(r"render_kernel<\w+, \d, true[,>]", name) or re.search(r"render_kernelILb[01]ELi\dELb1E", name):
             continue  # the timed launches only (the COUNT = true instantiation is bench.py's untimed counter pass)
         tot[row["Counter_Name"]] += float(row["Counter_Value"])
         launches[row["Counter_Name"]].add(row.get("Dispatch_Id"))

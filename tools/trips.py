@@ -10,17 +10,18 @@ from rpt_amd import Renderer, _lib, scenes  # noqa: E402
 NAMES = ["0 work pull", "1 regenerate camera ray", "2 vertex start (medium d, wo)", "3 after primary scan", "4 miss/env",
          "5 medium event setup", "6 surface finalize + material", "7 light sample", "8 shadow scan start",
          "9 after shadow scan (visibility, NEE shading)", "10 bounce start", "11 medium bounce", "12 surface RR",
-         "13 surface sample_f + bsdf", "14 path update"]
+         "13 surface sample_f + bsdf", "14 path update", "15 parked tree walks (per-mesh-tree kernels)"]
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 scene, cam, cfg = scenes.CONFIGS[name]()
-r = Renderer(scene, cam).width(cfg["width"]).height(cfg["height"]).max_bounces(cfg["max_bounces"]).seed(0)
+r = Renderer(scene, cam).width(min(cfg["width"], 1024)).height(min(cfg["height"], 1024)).max_bounces(cfg["max_bounces"]).seed(0)
 rpt_amd.set_option("counters", 1)
 r.sample_array(spp)
 c = r.counters()
 out = (C.c_uint64 * 56)()
 _lib.check(_lib.load().rpt_debug_section_counters(r.scene._handle, out))
-print(f"{name} {spp} spp: wave trips {c['wave_trips']}, rays/sample {c['rays'] / c['samples']:.3f}")
+print(f"{name} {spp} spp: wave trips {c['wave_trips']}, rays/sample {c['rays'] / c['samples']:.3f}, tree nodes/ray {c['bvh_nodes'] / c['rays']:.2f}, "
+      f"trips per 64 vertices {c['wave_trips'] * 64 / c['vertices']:.2f}")
 for k, nm in enumerate(NAMES):
     w, l = int(out[2 * k]), int(out[2 * k + 1])
     if w:
