@@ -386,7 +386,12 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
                     }
                     walk_meshes_resumable<COUNT>(sc, qo, qd, ray_tmin(qo), q_t, q_code, stk, stride, walk,
                                                  idle ? 1u : a.defer_stop, any, c_nodes, c_btris);
-                    if (walk.cur == kWalkDone) phase = shadow ? PH_HAVES : PH_HAVEP;
+                    if (walk.cur == kWalkDone) {
+                        phase = shadow ? PH_HAVES : PH_HAVEP;
+                        SECT(16);
+                        if ((q_code >> 28) == K_BVHTRI) { SECT(17); }
+                        if (shadow) { SECT(18); }
+                    }
                 }
             }
             continue;

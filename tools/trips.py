@@ -10,7 +10,7 @@ from rpt_amd import Renderer, _lib, scenes  # noqa: E402
 NAMES = ["0 work pull", "1 regenerate camera ray", "2 vertex start (medium d, wo)", "3 after primary scan", "4 miss/env",
          "5 medium event setup", "6 surface finalize + material", "7 light sample", "8 shadow scan start",
          "9 after shadow scan (visibility, NEE shading)", "10 bounce start", "11 medium bounce", "12 surface RR",
-         "13 surface sample_f + bsdf", "14 path update", "15 parked tree walks (per-mesh-tree kernels)"]
+         "13 surface sample_f + bsdf", "14 path update", "15 parked tree walks (per-mesh-tree kernels)", "16 walk finished", "17 ... with a triangle hit", "18 ... shadow query"]
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 scene, cam, cfg = scenes.CONFIGS[name]()
