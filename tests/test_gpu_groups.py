@@ -256,11 +256,13 @@ def test_group_as_object_light_matches_oracle(fog):
     rng = np.random.default_rng(3)
     clutter = [sphere().scale(vec3(0.1, 0.1, 0.1)).translate(np.array([rng.uniform(-3, 3), -0.9, rng.uniform(-3, 3)]))
                for _ in range(80)]
-    for extra in ([], clutter):                      # linear scan, then scene-level BVH
+    torus = [Mesh(scenes.bumpy_torus(12, 8)).scale(vec3(1.5, 1.5, 1.5)).translate(vec3(-2.0, 0.0, 1.0))]
+    for extra in ([], torus, clutter):               # linear scan, per-mesh tree (deferred walks), scene-level BVH
         scene = build(extra)
         r = Renderer(scene, cam).width(w).height(h).max_bounces(3).seed(9)
         got = r.sample_array(spp)
-        assert r.scene_stats()["scene_bvh"] == (1 if extra else 0)
+        st = r.scene_stats()
+        assert st["scene_bvh"] == (1 if extra is clutter else 0) and (st["bvh_nodes"] > 0) == (len(extra) > 0)
         exp = _oracle(scene).render(cam, w, h, spp, 3, seed=9, robust=1)
         assert np.all(np.isfinite(got)) and exp.mean() > 0
         assert rel_rms(got, exp) < 2e-2

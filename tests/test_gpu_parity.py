@@ -326,6 +326,26 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
     assert abs(frames[0].mean() - exp.mean()) / exp.mean() < 5e-3
 
 
+def test_mesh_scene_without_lights_under_an_environment_colour():
+    """Per-mesh-tree kernel with an empty light list (stage L has no iterations): only the environment lights
+    the scene (src/renderer.rs:288), mirror and diffuse bounces up to max_bounces."""
+    from rpt_amd import Environment, Mesh, sphere
+    sc = Scene()
+    sc.add(Object(Mesh(scenes.bumpy_torus(24, 16)).scale(vec3(2, 2, 2)).rotate_x(0.9)).material(Material.diffuse(vec3(0.7, 0.5, 0.3))))
+    sc.add(Object(plane(vec3(0, 1, 0), -1.0)).material(Material.diffuse(vec3(0.8, 0.8, 0.8))))
+    sc.add(Object(sphere().scale(vec3(0.5, 0.5, 0.5)).translate(vec3(1.5, -0.5, 1.0))).material(Material.mirror()))
+    sc.environment = Environment.Color(vec3(0.6, 0.7, 0.9))
+    cam = Camera.look_at(vec3(0.0, 1.5, 6.0), vec3(0.0, 0.0, 0.0), vec3(0, 1, 0), 0.8)
+    w, h, spp = 80, 60, 32
+    r = Renderer(sc, cam).width(w).height(h).max_bounces(3).seed(12)
+    got = r.sample_array(spp)
+    assert r.scene_stats()["bvh_nodes"] > 0 and r.scene_stats()["scene_bvh"] == 0
+    exp = _oracle(sc).render(cam, w, h, spp, 3, seed=12, robust=1)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0.1
+    assert rel_rms(got, exp) < 1e-2
+    assert abs(got.mean() - exp.mean()) / exp.mean() < 3e-3
+
+
 def test_cpp_mirror_example_renders_the_same_bytes_as_the_python_mirror():
     """examples/cornell.cpp (include/rpt.hpp over the C ABI) vs rpt_amd.api on the same scene/seed."""
     import os
