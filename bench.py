@@ -141,7 +141,7 @@ def main():
         r.gather_size(cfg["gather_size"]).gather_size_volume(cfg["gather_size_volume"])
         r.watts(cfg["renderer_watts"] / cfg["photons"] * n_photons)
 
-    def step(record=False):
+    def step():
         r._sample_offset = 0
         slot = step_no[0] % 2 if dist is not None else 0
         step_no[0] += 1
@@ -159,8 +159,6 @@ def main():
             r.sample_device(spp, frame.data_ptr(), stream)
         if dist is not None:
             pending[slot] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
-        if record:
-            kernel_ms.append(r.timing()[0])   # waits for this step's events only
 
     def drain():
         for i in range(2):
@@ -172,21 +170,24 @@ def main():
         step()
     drain()
     torch.cuda.synchronize()
+    if args.warmup:
+        r.timing_mean()   # start the kernel-time measurement at the timed region
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(record=True)
+    for _ in range(args.steps):   # nothing in a step waits for the device: the launches queue up behind each other
+        step()
     drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    grid_blocks = r.timing()[2]
+    kernel_ms.append(r.timing_mean()[0])   # HIP events around every timed launch, on the stream it ran on
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    grid_blocks = r.timing()[2]
 
     if photon:
         if rank == 0:

@@ -153,6 +153,10 @@ int rpt_debug_section_counters(rpt_scene*, uint64_t out[56]);
  * milliseconds of the megakernel and of the resolve kernel on the stream they ran on, and the
  * persistent grid size.  Synchronises on the last recorded event. */
 int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* grid_blocks);
+/* The same over every timed render since the previous call of this function (at most the latest 1024): mean
+ * milliseconds per launch.  Renders do not wait for their events, so a loop of rpt_render_sample_device calls
+ * stays asynchronous and is measured afterwards.  Starts a new measurement. */
+int rpt_get_timing_mean(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* launches);
 /* Runtime options (all optional): "counters" 0/1, "chunk_spp" (samples per work item, 0 = auto),
  * "blocks_per_cu" (persistent grid size), "timing" 0/1, "scene_bvh_min" (read by rpt_scene_commit:
  * number of bounded primitives + BVH meshes from which one scene-level BVH replaces the linear

@@ -772,6 +772,13 @@ class Renderer:
         _lib.check(_lib.load().rpt_get_timing(self.scene._handle, C.byref(a), C.byref(b), C.byref(g)))
         return a.value, b.value, g.value
 
+    def timing_mean(self):
+        """(mean render_ms, mean resolve_ms, launches) over the timed calls since the previous timing_mean();
+        the calls themselves never wait for their events."""
+        a, b, n = C.c_double(), C.c_double(), C.c_int32()
+        _lib.check(_lib.load().rpt_get_timing_mean(self.scene._handle, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     def scene_stats(self):
         """rpt_scene_stats of the committed scene (flattened-layout record counts and bytes)."""
         out = (C.c_uint64 * 16)()

@@ -381,8 +381,11 @@ struct rpt_scene {
     double* d_out = nullptr;
     size_t out_cap = 0;  // bytes
     uint64_t last_counters[64] = {0};  // [0..7] counters, [8..63] diagnostic trip stamps
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // before render, after render, after resolve
-    bool ev_valid = false;
+    // "timing": an event triple (before render, after render, after resolve) per launch, in a ring; nothing waits
+    // for them until rpt_get_timing / rpt_get_timing_mean is called
+    static constexpr size_t kTimedLaunches = 1024;
+    std::vector<hipEvent_t> evs;
+    size_t ev_count = 0;  // timed launches since the last rpt_get_timing_mean
     int last_blocks = 0;
     uint64_t prims_per_ray = 0;
     uint64_t stats[16] = {0};
@@ -501,7 +504,7 @@ void rpt_scene_destroy(rpt_scene* s) {
         (void)hipFree(s->d_queue);
         (void)hipFree(s->d_counters);
         (void)hipFree(s->d_out);
-        for (auto& e : s->ev)
+        for (auto& e : s->evs)
             if (e) (void)hipEventDestroy(e);
         if (s->photon) rpti::photon_release(s->photon);
     }
@@ -1398,17 +1401,23 @@ extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm
         // indexed_start: every wave of the grid takes the batch with its own index first (render_kernel's work
         // pull), so the counter starts behind those batches
         if (indexed_start) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.queue, int(uint32_t(n_blocks) * 4u * 64u), 1, st));
+        hipEvent_t* ev = nullptr;
         if (g_opt_timing) {
-            for (auto& e : s->ev)
-                if (!e) HIP_TRY(hipEventCreate(&e));
-            HIP_TRY(hipEventRecord(s->ev[0], st));
+            const size_t slot = s->ev_count % rpt_scene::kTimedLaunches;
+            while (s->evs.size() < 3 * (slot + 1)) {
+                hipEvent_t e = nullptr;
+                HIP_TRY(hipEventCreate(&e));
+                s->evs.push_back(e);
+            }
+            ev = &s->evs[3 * slot];
+            HIP_TRY(hipEventRecord(ev[0], st));
         }
         HIP_TRY(launch(a, n_blocks, st));
-        if (g_opt_timing) HIP_TRY(hipEventRecord(s->ev[1], st));
+        if (ev) HIP_TRY(hipEventRecord(ev[1], st));
         HIP_TRY(launch_resolve(a, std::pow(2.0, prm->exposure_value), d_out, st));
-        if (g_opt_timing) {
-            HIP_TRY(hipEventRecord(s->ev[2], st));
-            s->ev_valid = true;
+        if (ev) {
+            HIP_TRY(hipEventRecord(ev[2], st));
+            s->ev_count++;
         }
     }
     return RPT_OK;
@@ -1581,14 +1590,36 @@ int rpt_render_into_buffer(rpt_scene* s, const rpt_camera* cam, const rpt_render
 
 int rpt_get_timing(rpt_scene* s, double* render_ms, double* resolve_ms, int32_t* grid_blocks) {
     if (!s) return fail(RPT_ERR_INVALID, "null scene");
-    if (!s->ev_valid) return fail(RPT_ERR_STATE, "no timed render: rpt_set_option(\"timing\", 1) first");
-    HIP_TRY(hipEventSynchronize(s->ev[2]));
+    if (!s->ev_count) return fail(RPT_ERR_STATE, "no timed render: rpt_set_option(\"timing\", 1) first");
+    const hipEvent_t* ev = &s->evs[3 * ((s->ev_count - 1) % rpt_scene::kTimedLaunches)];
+    HIP_TRY(hipEventSynchronize(ev[2]));
     float a = 0.f, b = 0.f;
-    HIP_TRY(hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, ev[1], ev[2]));
     if (render_ms) *render_ms = a;
     if (resolve_ms) *resolve_ms = b;
     if (grid_blocks) *grid_blocks = s->last_blocks;
+    return RPT_OK;
+}
+
+int rpt_get_timing_mean(rpt_scene* s, double* render_ms, double* resolve_ms, int32_t* launches) {
+    if (!s) return fail(RPT_ERR_INVALID, "null scene");
+    if (!s->ev_count) return fail(RPT_ERR_STATE, "no timed render: rpt_set_option(\"timing\", 1) first");
+    const size_t n = std::min(s->ev_count, rpt_scene::kTimedLaunches);  // the ring keeps the latest launches
+    HIP_TRY(hipEventSynchronize(s->evs[3 * ((s->ev_count - 1) % rpt_scene::kTimedLaunches) + 2]));
+    double a = 0.0, b = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        const hipEvent_t* ev = &s->evs[3 * i];
+        float x = 0.f, y = 0.f;
+        HIP_TRY(hipEventElapsedTime(&x, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&y, ev[1], ev[2]));
+        a += x;
+        b += y;
+    }
+    if (render_ms) *render_ms = a / double(n);
+    if (resolve_ms) *resolve_ms = b / double(n);
+    if (launches) *launches = int32_t(n);
+    s->ev_count = 0;
     return RPT_OK;
 }
 

@@ -90,3 +90,27 @@ def test_photon_beam_walk_without_a_common_ray_origin():
     exp = pm.render(lens, size, size, spp, seed=6)
     assert np.all(np.isfinite(got)) and exp.mean() > 0
     assert rel_rms(got, exp) < 1e-2 and abs(got.mean() - exp.mean()) / exp.mean() < 3e-3
+
+
+def test_timing_events_are_kept_per_launch_and_read_afterwards():
+    """rpt_get_timing / rpt_get_timing_mean: HIP events around every launch on its stream; the renders never
+    wait for them, the mean covers the launches since the previous mean and then starts over."""
+    scene, cam, cfg = scenes.cornell()
+    r = Renderer(scene, cam).width(64).height(64).max_bounces(2).seed(1)
+    with pytest.raises(RptError):
+        r.sample_array(1)
+        r.timing()                                            # timing was off: nothing recorded
+    rpt_amd.set_option("timing", 1)
+    try:
+        for _ in range(3):
+            r.sample_array(4)
+        last = r.timing()
+        mean = r.timing_mean()
+        assert mean[2] == 3 and mean[0] > 0 and mean[1] > 0 and last[0] > 0 and last[2] > 0
+        assert 0.2 * last[0] < mean[0] < 5 * last[0]
+        with pytest.raises(RptError):
+            r.timing_mean()                                   # nothing since the previous mean
+        r.sample_array(4)
+        assert r.timing_mean()[2] == 1
+    finally:
+        rpt_amd.set_option("timing", 0)
