@@ -136,7 +136,9 @@ int rpt_intersect_batch(rpt_scene*, uint64_t n, const float* origins, const floa
 /* Flattened-layout statistics of a committed scene: [0] spheres, [1] general (rotated) cubes,
  * [2] planes, [3] linearly scanned triangles, [4] axis-aligned boxes, [5] axis-aligned
  * rectangles (pairs of wall triangles), [6] BVH triangles, [7] BVH nodes, [8] bytes of scan
- * records every closest-hit query walks, [9] bytes of scene data resident in HBM. */
+ * records every closest-hit query walks, [9] bytes of scene data resident in HBM, [10] 1 if one scene-level
+ * tree replaces the scan, [11] primitives in it, [12] mesh instances, [13] meshes stored once and instanced,
+ * [14] wall rectangles folded into a box shell, [15] levels of the deepest walk (scene tree + mesh tree). */
 int rpt_scene_stats(rpt_scene*, uint64_t out[16]);
 /* Counters of the last rpt_render_sample* call on this scene (device-side, exact):
  * [0] camera samples, [1] closest-hit queries (rays), [2] path vertices, [3] kernel loop trips
@@ -167,7 +169,10 @@ int rpt_get_timing_mean(rpt_scene*, double* render_ms, double* resolve_ms, int32
  * pixel block once per work batch, default 1; 0 walks the tree per sample), "photon_skip" (diagnostic bit
  * mask that switches parts of the photon camera pass off), "defer_lanes" / "defer_stop" (scenes whose meshes
  * have their own trees: a wave starts its parked tree walks when this many lanes wait, default 32, and leaves
- * them when fewer than this many are still walking, default 16; the image does not depend on either);
+ * them when fewer than this many are still walking, default 16; the image does not depend on either),
+ * "bvh_max_depth" (read by rpt_scene_commit: a mesh tree that the SAH builder makes deeper than this is rebuilt
+ * with object-median splits, default 20 -- the traversal stack holds 32 levels for scene tree + mesh tree;
+ * a scene that still does not fit is refused with RPT_ERR_UNSUPPORTED);
  * returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
 

@@ -784,7 +784,7 @@ class Renderer:
         out = (C.c_uint64 * 16)()
         _lib.check(_lib.load().rpt_scene_stats(self.scene._commit(self.device_), out))
         names = ["spheres", "cubes", "planes", "tris", "aabbs", "rects", "bvh_tris", "bvh_nodes", "scan_bytes_per_ray",
-                 "scene_bytes", "scene_bvh", "scene_bvh_prims", "instances", "shared_meshes", "shell_faces"]
+                 "scene_bytes", "scene_bvh", "scene_bvh_prims", "instances", "shared_meshes", "shell_faces", "tree_depth"]
         return dict(zip(names, [int(v) for v in out]))
 
     # ---- photon mapping (src/photon.rs:631-720)

@@ -58,6 +58,7 @@ int64_t option_photon_skip() { return g_opt_photon_skip; }
 int64_t option_photon_block_lists() { return g_opt_photon_block_lists; }
 }
 static int64_t g_opt_instancing = 1;     // meshes shared by several shapes are stored once and instanced
+static int64_t g_opt_bvh_max_depth = 20;  // a mesh tree deeper than this is rebuilt balanced (read by rpt_scene_commit)
 static int64_t g_opt_defer_stop = 16;     // still-walking lanes below which a wave leaves the walk (the rest resume later)
 static int64_t g_opt_defer_lanes = 32;    // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
 static int64_t g_opt_scene_bvh_min = 64;  // bounded primitives + BVH meshes from which the scene-level BVH is built
@@ -239,6 +240,11 @@ struct BvhBuilder {
     static constexpr int kBins = 16, kMaxDepth = 28;
     uint32_t leaf_max = 4;
     const std::vector<uint8_t>* solo = nullptr;  // by BTri::idx: items that must be alone in their leaf
+    // The traversal keeps at most one stack entry per level and the stack has 32 (device_core.h): a tree that
+    // comes out deeper than the caller can afford is rebuilt with `balanced` = object-median splits along the widest
+    // centroid axis, whose depth is ceil(log2(n)) whatever the input looks like.
+    bool balanced = false;
+    int max_depth = 0;
     bool can_leaf(uint32_t first, uint32_t count) const {
         if (!solo || count == 1) return true;
         for (uint32_t i = first; i < first + count; i++)
@@ -265,6 +271,7 @@ struct BvhBuilder {
     void build(uint32_t node, uint32_t first, uint32_t count, int depth) {
         float lo[3], hi[3], clo[3], chi[3];
         bounds(first, count, lo, hi, clo, chi);
+        max_depth = std::max(max_depth, depth);
         TmpNode& n = nodes[node];
         for (int a = 0; a < 3; a++) {  // conservative padding for the fp32 slab test
             float pad = 1e-6f * std::max(std::fabs(lo[a]), std::fabs(hi[a])) + 1e-30f;
@@ -279,7 +286,7 @@ struct BvhBuilder {
         if (leaf_ok && (count <= leaf_max || (depth >= kMaxDepth && count <= 32))) return make_leaf();
         int best_axis = -1, best_bin = -1;
         float best_cost = std::numeric_limits<float>::infinity();
-        for (int a = 0; a < 3; a++) {
+        for (int a = 0; a < 3 && !balanced; a++) {
             float ext = chi[a] - clo[a];
             if (!(ext > 0.f)) continue;
             uint32_t cnt[kBins] = {0};
@@ -324,7 +331,14 @@ struct BvhBuilder {
             }
         }
         uint32_t mid;
-        if (best_axis < 0 || depth >= kMaxDepth) {
+        if (balanced) {
+            int axis = 0;
+            for (int a = 1; a < 3; a++)
+                if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
+            mid = first + count / 2;
+            std::nth_element(t.begin() + first, t.begin() + mid, t.begin() + first + count,
+                             [axis](const BTri& p, const BTri& q) { return p.c[axis] < q.c[axis]; });
+        } else if (best_axis < 0 || depth >= kMaxDepth) {
             if (count <= 16 && leaf_ok) return make_leaf();
             mid = first + count / 2;  // all centroids coincide (or depth cap): split by index
         } else {
@@ -486,6 +500,7 @@ int rpt_set_option(const char* name, int64_t value) {
     else if (s == "photon_block_lists") g_opt_photon_block_lists = value;
     else if (s == "instancing") g_opt_instancing = value;
     else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); g_opt_defer_lanes = value; }
+    else if (s == "bvh_max_depth") { if (value < 1 || value > 31) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..31"); g_opt_bvh_max_depth = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); g_opt_defer_stop = value; }
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); g_opt_scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option " + s);
@@ -743,6 +758,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     std::vector<PBox> box_inst;
     std::unordered_map<const std::vector<double>*, uint32_t> mesh_uses;
     std::unordered_map<const std::vector<double>*, std::pair<MeshRef, PBox>> shared;
+    int mesh_depth = 0, top_depth = 0;  // deepest mesh tree / the scene-level tree: their sum must fit the walk's stack
     // Triangles of one mesh under `x` (identity for a shared mesh) + its two-box tree, appended to btri / nodes.
     auto add_bvh_mesh = [&](const std::vector<double>& mt, const Xf& x, uint32_t obj, PBox& box) {
         const uint64_t nt = mt.size() / 18;
@@ -770,8 +786,20 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         std::vector<TmpNode> tmp;
         tmp.reserve(nt);
         tmp.push_back(TmpNode{});
-        BvhBuilder b{bt, tmp};
-        b.build(0, 0, uint32_t(nt), 0);
+        int depth = 0;
+        {
+            BvhBuilder b{bt, tmp};
+            b.build(0, 0, uint32_t(nt), 0);
+            depth = b.max_depth;
+        }
+        if (depth > g_opt_bvh_max_depth) {  // a chain-like SAH tree: the walk's stack could not hold it
+            tmp.assign(1, TmpNode{});
+            BvhBuilder b{bt, tmp};
+            b.balanced = true;
+            b.build(0, 0, uint32_t(nt), 0);
+            depth = b.max_depth;
+        }
+        mesh_depth = std::max(mesh_depth, depth);
         // convert to two-box nodes: inner tmp node k -> wide node remap[k]
         std::vector<uint32_t> remap(tmp.size(), 0);
         uint32_t n_inner = 0;
@@ -1151,11 +1179,19 @@ int rpt_scene_commit(rpt_scene* s, int device) {
             scene_bvh = true;
             std::vector<TmpNode> tmp;
             tmp.reserve(2 * items.size());
-            tmp.push_back(TmpNode{});
-            BvhBuilder b{items, tmp};
-            b.leaf_max = 2;
-            b.solo = &solo;
-            b.build(0, 0, uint32_t(items.size()), 0);
+            // a mesh tree hangs below a leaf of this one (spliced in, or walked as an instance on the same stack)
+            for (int attempt = 0; attempt < 2; attempt++) {
+                tmp.assign(1, TmpNode{});
+                BvhBuilder b{items, tmp};
+                b.leaf_max = 2;
+                b.solo = &solo;
+                b.balanced = attempt == 1;
+                b.build(0, 0, uint32_t(items.size()), 0);
+                top_depth = b.max_depth + 1;
+                if (top_depth + mesh_depth <= 31) break;
+            }
+            if (top_depth + mesh_depth > 31)
+                return fail(RPT_ERR_UNSUPPORTED, "scene tree + mesh tree are deeper than the traversal stack (32 levels)");
             std::vector<uint32_t> remap(tmp.size(), 0);
             uint32_t n_inner = 0;
             for (size_t k = 0; k < tmp.size(); k++)
@@ -1282,6 +1318,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     s->stats[10] = scene_bvh ? 1 : 0;
     s->stats[11] = pleaf.size();
     s->stats[14] = has_shell ? shell_sh.size() : 0;
+    s->stats[15] = uint64_t(top_depth + mesh_depth);
     s->stats[12] = insts.size();
     s->stats[13] = shared.size();
 

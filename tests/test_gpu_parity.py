@@ -326,6 +326,35 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
     assert abs(frames[0].mean() - exp.mean()) / exp.mean() < 5e-3
 
 
+def test_too_deep_mesh_tree_is_rebuilt_balanced_with_the_same_hits():
+    """The walk's stack holds 32 levels: a mesh tree the SAH builder makes deeper than "bvh_max_depth" is rebuilt
+    with object-median splits (rpt_capi.cpp BvhBuilder::balanced).  Forced here on an ordinary mesh: shallower tree,
+    identical closest hits (same triangles, same fp32 tests: bit-equal t and object, normals too except on a shared edge)."""
+    import rpt_amd
+    from rpt_amd import Mesh
+    tris = scenes.bumpy_torus(64, 48)
+
+    def build():
+        sc = Scene()
+        sc.add(Object(Mesh(tris).scale(vec3(2, 2, 2)).rotate_x(0.4)).material(Material.diffuse(vec3(1, 1, 1))))
+        sc.add(Object(plane(vec3(0, 1, 0), -1.5)).material(Material.diffuse(vec3(1, 1, 1))))
+        return Renderer(sc, Camera())
+    o, d = random_rays(np.random.default_rng(3), 50000, np.zeros(3), 3.0)
+    sah = build()
+    t0, obj0, n0 = sah.get_closest_hit(o, d)
+    rpt_amd.set_option("bvh_max_depth", 5)
+    try:
+        bal = build()
+        t1, obj1, n1 = bal.get_closest_hit(o, d)
+    finally:
+        rpt_amd.set_option("bvh_max_depth", 20)
+    d_sah, d_bal = sah.scene_stats()["tree_depth"], bal.scene_stats()["tree_depth"]
+    assert 5 < d_bal < d_sah <= 20 and d_bal == 11              # 6144 triangles: ceil(log2(6144 / 4)) = 11 levels
+    assert (obj0 == 0).mean() > 0.05
+    assert np.array_equal(obj0, obj1) and np.array_equal(t0, t1)
+    assert (np.abs(n0 - n1).max(axis=1) > 0).sum() <= 3       # an edge shared by two triangles: either may win the tie
+
+
 def test_mesh_scene_without_lights_under_an_environment_colour():
     """Per-mesh-tree kernel with an empty light list (stage L has no iterations): only the environment lights
     the scene (src/renderer.rs:288), mirror and diffuse bounces up to max_bounces."""
