@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--photons", type=int, default=0, help="C4 only: photons shot per step (default: the config's 1,000,000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
+                    help="HIP streams the consecutive steps alternate between (2: the start of a step overlaps the tail of the previous one)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl) even with one rank, to rehearse the N > 1 code path")
     args = ap.parse_args()
@@ -123,10 +125,13 @@ def main():
     spp = args.spp or cfg["spp"]
     r = Renderer(scene, cam).width(width).height(height).max_bounces(cfg["max_bounces"]).seed(0)
     r.device(local_rank).shard(rank, world)
-    # N > 1: two frames, so that the sum-reduce of step k (RCCL, its own stream) overlaps the rendering of
-    # step k + 1 -- what an iterative render does with consecutive batches.  Every reduce has completed
-    # before the closing synchronize + barrier of the timed region.
+    # Two frames on two HIP streams, used alternately -- what an iterative render does with consecutive batches:
+    # the first blocks of step k + 1 take over the CUs that the last paths of step k no longer fill (the library
+    # keeps a slab + work counter per stream), and for N > 1 the sum-reduce of step k (RCCL, its own stream)
+    # overlaps the rendering of step k + 1.  Everything has completed before the closing synchronize + barrier of
+    # the timed region.
     frames = [torch.zeros(width * height * 3, dtype=torch.float64, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
     d_out = frames[0]
     pending = [None, None]
     step_no = [0]
@@ -143,22 +148,25 @@ def main():
 
     def step():
         r._sample_offset = 0
-        slot = step_no[0] % 2 if dist is not None else 0
+        slot = step_no[0] % 2 if (args.streams == 2 and not photon) else 0   # the photon map is built on the null stream
         step_no[0] += 1
         frame = frames[slot]
-        if pending[slot] is not None:   # the reduce that last used this frame must be done before it is overwritten
-            pending[slot].wait()
-            pending[slot] = None
-        if photon:
-            if dist is not None:   # shooting sharded by photon index, records all-gathered over RCCL
-                photon_map_build_sharded(r, n_photons, Renderer.PHOTON_POINT_BEAM, rank, world)
+        on = torch.cuda.default_stream() if (photon or args.streams == 1) else streams[slot]
+        with torch.cuda.stream(on):
+            st = on.cuda_stream
+            if pending[slot] is not None:   # the reduce that last used this frame must be done before it is overwritten
+                pending[slot].wait()
+                pending[slot] = None
+            if photon:
+                if dist is not None:   # shooting sharded by photon index, records all-gathered over RCCL
+                    photon_map_build_sharded(r, n_photons, Renderer.PHOTON_POINT_BEAM, rank, world)
+                else:
+                    r.photon_map_build(n_photons, Renderer.PHOTON_POINT_BEAM)
+                r.photon_sample_device(spp, frame.data_ptr(), st)
             else:
-                r.photon_map_build(n_photons, Renderer.PHOTON_POINT_BEAM)
-            r.photon_sample_device(spp, frame.data_ptr(), stream)
-        else:
-            r.sample_device(spp, frame.data_ptr(), stream)
-        if dist is not None:
-            pending[slot] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+                r.sample_device(spp, frame.data_ptr(), st)
+            if dist is not None:
+                pending[slot] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
 
     def drain():
         for i in range(2):

@@ -124,7 +124,10 @@ int rpt_scene_commit(rpt_scene*, int device);
 int rpt_render_sample(rpt_scene*, const rpt_camera*, const rpt_render_params*, uint32_t iterations,
                       uint64_t seed, uint32_t sample_offset, double* out_rgb);
 /* Same, asynchronous: d_out_rgb is a DEVICE pointer (width*height*3 doubles) on the scene's
- * device and hip_stream a hipStream_t (NULL = default stream).  Nothing is copied to the host. */
+ * device and hip_stream a hipStream_t (NULL = default stream).  Nothing is copied to the host.  Calls on one
+ * stream run in order; calls that alternate between two streams overlap (the scene keeps the per-launch scratch
+ * twice), which hides the tail of each launch behind the start of the next; a third stream waits for the scratch
+ * it takes over.  Calls on the same scene must still come from one host thread at a time. */
 int rpt_render_sample_device(rpt_scene*, const rpt_camera*, const rpt_render_params*, uint32_t iterations,
                              uint64_t seed, uint32_t sample_offset, void* d_out_rgb, void* hip_stream);
 

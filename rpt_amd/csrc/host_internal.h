@@ -20,9 +20,10 @@ struct SceneDev {
 SceneDev scene_dev(rpt_scene* s);
 void*& photon_slot(rpt_scene* s);  // owned by photon.hip (PhotonMapDev*), released through photon_release
 void photon_release(void* p);      // defined in photon.hip
-// Fills camera, tiles, slab, queue, chunking exactly as for the path tracer.
+// Fills camera, tiles, slab, queue, chunking exactly as for the path tracer; `st` is the stream the launch will run
+// on (it selects the launch set: slab + work counter).
 // min_chunk: lower bound of the automatic samples-per-work-item choice (an explicit "chunk_spp" option wins).
-int prepare_render(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations, uint64_t seed,
+int prepare_render(rpt_scene* s, hipStream_t st, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations, uint64_t seed,
                    uint32_t sample_offset, rptg::RenderArgs& a, uint32_t min_chunk = 0);
 // Zeroes the queue / sharded frame, calls `launch(args, n_blocks, stream)` with a persistent grid of
 // blocks_per_cu blocks per CU, then resolves the slab into d_out.

@@ -1394,7 +1394,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         return rpti::fail(RPT_ERR_UNSUPPORTED, "gather sizes > 56 do not fit the LDS gather list");
     const uint64_t gather_lds = pm->kind == RPT_PHOTON_MAP ? std::max(gather_size, gather_size_volume) : gather_size;
     QueryArgs q{};
-    int rc = rpti::prepare_render(s, cam, prm, num_samples, seed, sample_offset, q.r, 32);
+    int rc = rpti::prepare_render(s, st, cam, prm, num_samples, seed, sample_offset, q.r, 32);
     if (rc) return rc;
     // Work items of the camera pass are wave-level: (8x8 pixel block, chunk of up to 64 samples).  The slab
     // prepare_render sized for its (smaller) chunks is large enough: [n_chunks][n_owned] with fewer chunks.

@@ -26,6 +26,8 @@ hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t n, hipStream_t) {
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

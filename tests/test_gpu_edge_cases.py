@@ -114,3 +114,28 @@ def test_timing_events_are_kept_per_launch_and_read_afterwards():
         assert r.timing_mean()[2] == 1
     finally:
         rpt_amd.set_option("timing", 0)
+
+
+def test_launches_on_two_streams_overlap_without_sharing_their_slab():
+    """The library keeps a slab + work counter per stream (rpt_capi.cpp LaunchSet): frames launched alternately on
+    two streams, nothing waiting in between, are each bit-identical to the frame of a lone launch -- also for
+    different sample offsets and sizes in flight at the same time, and on a third stream that has to wait."""
+    import torch
+    scene, cam, cfg = scenes.lampshade()
+    w, h, spp = 96, 64, 12
+    r = Renderer(scene, cam).width(w).height(h).max_bounces(10).seed(4)
+
+    def lone(offset):
+        r._sample_offset = offset
+        return r.sample_array(spp).copy()
+    expect = [lone(0), lone(spp), lone(2 * spp)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    frames = [torch.zeros(w * h * 3, dtype=torch.float64, device="cuda") for _ in range(6)]
+    for i, f in enumerate(frames):                             # 6 launches queued back to back: streams 0 1 2 0 1 2
+        st = streams[i % 3]
+        r._sample_offset = (i % 3) * spp
+        with torch.cuda.stream(st):
+            r.sample_device(spp, f.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    for i, f in enumerate(frames):
+        assert np.array_equal(f.cpu().numpy().reshape(-1, 3), expect[i % 3])
