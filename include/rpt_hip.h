@@ -127,7 +127,8 @@ int rpt_render_sample(rpt_scene*, const rpt_camera*, const rpt_render_params*, u
  * device and hip_stream a hipStream_t (NULL = default stream).  Nothing is copied to the host.  Calls on one
  * stream run in order; calls that alternate between two streams overlap (the scene keeps the per-launch scratch
  * twice), which hides the tail of each launch behind the start of the next; a third stream waits for the scratch
- * it takes over.  Calls on the same scene must still come from one host thread at a time. */
+ * it takes over (photon-mapped renders of one scene never overlap: their photon scratch exists once).  Calls on
+ * the same scene must still come from one host thread at a time. */
 int rpt_render_sample_device(rpt_scene*, const rpt_camera*, const rpt_render_params*, uint32_t iterations,
                              uint64_t seed, uint32_t sample_offset, void* d_out_rgb, void* hip_stream);
 

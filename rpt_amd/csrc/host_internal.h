@@ -30,6 +30,7 @@ int prepare_render(rpt_scene* s, hipStream_t st, const rpt_camera* cam, const rp
 int run_persistent(rpt_scene* s, const rpt_render_params* prm, const rptg::RenderArgs& a, double* d_out, hipStream_t st,
                    int blocks_per_cu, const std::function<hipError_t(const rptg::RenderArgs&, int, hipStream_t)>& launch,
                    bool indexed_start = false, bool wave_items = false);  // wave_items: n_items counts one item per wave, not per lane
+int serialize_with_other_streams(rpt_scene* s, hipStream_t st);  // for launches with per-scene scratch outside the launch set
 int fetch_counters(rpt_scene* s, const rptg::RenderArgs& a);  // after the stream has been synchronised
 double* scratch_out(rpt_scene* s, size_t bytes);  // cached device frame for the host-buffer entry points
 int64_t option_photon_skip();  // rpt_set_option("photon_skip"): diagnostic bit mask for the camera pass

@@ -1396,6 +1396,8 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     QueryArgs q{};
     int rc = rpti::prepare_render(s, st, cam, prm, num_samples, seed, sample_offset, q.r, 32);
     if (rc) return rc;
+    rc = rpti::serialize_with_other_streams(s, st);  // candidate lists and the overflow flag exist once per scene
+    if (rc) return rc;
     // Work items of the camera pass are wave-level: (8x8 pixel block, chunk of up to 64 samples).  The slab
     // prepare_render sized for its (smaller) chunks is large enough: [n_chunks][n_owned] with fewer chunks.
     q.r.chunk_spp = 64u;

@@ -1450,6 +1450,14 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     return RPT_OK;
 }
 
+// A launch that uses per-scene scratch beyond its launch set (the photon camera pass: candidate lists, overflow
+// flag) must not overlap a launch on another stream: wait for whatever the other stream still has in flight.
+extern "C++" int rpti::serialize_with_other_streams(rpt_scene* s, hipStream_t st) {
+    for (auto& ls : s->sets)
+        if (ls.used && ls.stream != st) HIP_TRY(hipStreamWaitEvent(st, ls.done, 0));
+    return RPT_OK;
+}
+
 extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st,
                          int blocks_per_cu, const std::function<hipError_t(const RenderArgs&, int, hipStream_t)>& launch,
                          bool indexed_start, bool wave_items) {
