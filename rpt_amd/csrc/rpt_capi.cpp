@@ -58,6 +58,7 @@ int64_t option_photon_skip() { return g_opt_photon_skip; }
 int64_t option_photon_block_lists() { return g_opt_photon_block_lists; }
 }
 static int64_t g_opt_instancing = 1;     // meshes shared by several shapes are stored once and instanced
+static int64_t g_opt_bvh_leaf_max = 4;    // triangles per leaf of a mesh tree (read by rpt_scene_commit)
 static int64_t g_opt_bvh_max_depth = 20;  // a mesh tree deeper than this is rebuilt balanced (read by rpt_scene_commit)
 static int64_t g_opt_defer_stop = 16;     // still-walking lanes below which a wave leaves the walk (the rest resume later)
 static int64_t g_opt_defer_lanes = 32;    // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
@@ -512,6 +513,7 @@ int rpt_set_option(const char* name, int64_t value) {
     else if (s == "photon_block_lists") g_opt_photon_block_lists = value;
     else if (s == "instancing") g_opt_instancing = value;
     else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); g_opt_defer_lanes = value; }
+    else if (s == "bvh_leaf_max") { if (value < 1 || value > 16) return fail(RPT_ERR_INVALID, "bvh_leaf_max must be 1..16"); g_opt_bvh_leaf_max = value; }
     else if (s == "bvh_max_depth") { if (value < 1 || value > 31) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..31"); g_opt_bvh_max_depth = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); g_opt_defer_stop = value; }
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); g_opt_scene_bvh_min = value; }
@@ -805,12 +807,14 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         int depth = 0;
         {
             BvhBuilder b{bt, tmp};
+            b.leaf_max = uint32_t(g_opt_bvh_leaf_max);
             b.build(0, 0, uint32_t(nt), 0);
             depth = b.max_depth;
         }
         if (depth > g_opt_bvh_max_depth) {  // a chain-like SAH tree: the walk's stack could not hold it
             tmp.assign(1, TmpNode{});
             BvhBuilder b{bt, tmp};
+            b.leaf_max = uint32_t(g_opt_bvh_leaf_max);
             b.balanced = true;
             b.build(0, 0, uint32_t(nt), 0);
             depth = b.max_depth;
