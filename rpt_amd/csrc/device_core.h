@@ -488,8 +488,10 @@ RPT_DEV void walk_meshes_resumable(const SceneView& sc, V o, V d, float tmin, fl
         if (cur != kWalkDone) {
             const uint32_t first = cur & BVH_INDEX_MASK;
             const uint32_t count = ((cur >> 26) & 31u) + 1u;
-            for (uint32_t i = 0; i < count; i++) {
-                const TriScan tr = sc.btri[first + i];
+            TriScan nxt = sc.btri[first];
+            for (uint32_t i = 0; i < count; i++) {  // the next triangle is in flight while this one is tested
+                const TriScan tr = nxt;
+                if (i + 1u < count) nxt = sc.btri[first + i + 1u];
                 if (COUNT) c_tris++;
                 float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
                 if (t >= 0.f) { tbest = t; code = (K_BVHTRI << 28) | (first + i); }
