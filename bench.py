@@ -1,18 +1,33 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C4|C5]
 
 One "step" = one pass of the hot path over the whole workload: Renderer::sample of the
 lampshade scene in fog (BASELINE config C3, examples/volumetric_pathtrace_lampshade.rs) at
 1024x1024 pixels x 256 paths per pixel, scene resident in HBM before the timed region.  With
-N > 1 (launched by torch.distributed.run, one rank per GPU) the 32x32 pixel tiles are sharded
-over the ranks and the frame is assembled on rank 0 with one RCCL sum-reduce per step; the
-total work is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+N > 1 the 32x32 pixel tiles are sharded over one rank per GPU and the frame is assembled on rank 0
+with one RCCL sum-reduce per step; the total work is fixed, so scaling is "strong".  `python bench.py
+--gpus N` starts its N ranks itself (fresh children through torch.distributed.run, before this process
+has touched a GPU); under torch.distributed.run it is one of the ranks.  Rank 0 prints ONE JSON line.
+
+Figures in the line:
+  value                 camera samples per second, whole job, frame resident in HBM at the end of a step
+  value_host_resident   the same with the frame on the host of rank 0 (SURVEY.md 8d's wall definition)
+  roofline              bound "hbm": measured HBM bytes of the dominant kernel / its duration against 8 TB/s.
+                        The path is NOT HBM-bound (frac ~ 0.02); what binds it is fp32 VALU issue:
+  valu_frac             algorithmic fp32 flops (SURVEY.md 8d's per-primitive counts on the reference's
+                        structure x exact device counters) / kernel time / 157.3 TFLOP/s
+  valu_issue_frac       wave-level VALU instructions issued / (SIMDs x clk/2 x kernel time), from the PMC profile
+  active_lanes          mean fraction of the 64 lanes that are enabled in an issued VALU instruction (PMC), and
+  path_lanes            fraction of lanes holding a live path vertex per loop trip (device counters of this run)
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,6 +36,49 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+N_SIMD = 1024              # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues every 2 clocks per SIMD
+
+SCENE_FILES = {"C2": "examples/cornell.rs", "C3": "examples/volumetric_pathtrace_lampshade.rs",
+               "C4": "examples/volumetric_beamphoton_lampshade.rs", "C5": "examples/dragon.rs layout, procedural 100,352-triangle mesh"}
+WORKLOAD_NAMES = {"C2": "C2 cornell box path trace", "C3": "C3 lampshade-in-fog path trace",
+                  "C4": "C4 lampshade beam x point photon map", "C5": "C5 100k-triangle mesh in fog path trace"}
+
+
+def usable_cpus():
+    """CPUs this process may actually run on: the affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as fresh child processes (this
+    process has not initialised a GPU -- torch is not even imported yet -- and never will), relay their output and
+    exit with their status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def algorithmic_work(stats, n_objects, counters, samples):
@@ -42,49 +100,116 @@ def algorithmic_work(stats, n_objects, counters, samples):
     return total_bytes / samples, total_flops / samples, rays / samples
 
 
-def hbm_traffic_from_profile(workload, width, height, spp, world):
-    """HBM bytes per render_kernel launch from the committed rocprofv3 PMC passes
-    (profiles/r01/final_c3_pmc_render_kernel.json: FETCH_SIZE and WRITE_SIZE in KB, collected in
-    separate --pmc runs; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM).  Only valid for the
-    configuration that was profiled (C3 at full size on one GPU); null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01", "final_c3_pmc_render_kernel.json")
-    if (workload, width, height, spp, world) != ("C3", 1024, 1024, 256, 1) or not os.path.exists(path):
-        return None
-    pmc = json.load(open(path))
-    if "FETCH_SIZE" not in pmc or "WRITE_SIZE" not in pmc:
-        return None
-    return int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
+def pmc_profile(workload, width, height, spp, world, photons=0):
+    """The committed rocprofv3 PMC summary of the dominant kernel for exactly this configuration
+    (profiles/rNN/pmc_<workload>.json, written by tools/pmc_passes.sh + tools/pmc_collect.py: separate --pmc passes,
+    per-launch sums), newest round first; (None, None) when this configuration was never profiled."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{workload}.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        cfg = pmc.get("_config", {})
+        if (cfg.get("width"), cfg.get("height"), cfg.get("spp"), cfg.get("n_gpus", 1)) != (width, height, spp, world):
+            continue
+        if photons and cfg.get("photons") != photons:
+            continue
+        return pmc, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def roofline_block(kernel, k_ms, k_ms_source, grid_blocks, pmc, pmc_path, compulsory_bytes, model_bytes, extra=None):
+    """The bench contract's roofline object for the dominant kernel, HBM view: achieved = HBM bytes per launch /
+    launch duration.  Bytes are the measured ones (2 x FETCH_SIZE + WRITE_SIZE of the PMC profile of this very
+    configuration, MI355X_MICROARCH.md section HBM) when such a profile is committed, else the bytes the kernel
+    moves by design (partial-sum slab written + read back, frame written).  `compulsory_bytes` is what the
+    algorithm has to move (the fp32 RGB frame): traffic / compulsory is the waste factor."""
+    traffic, source = None, None
+    if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)   # rocprofv3 reports KB
+        source = f"{pmc_path}: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this configuration (not this run)"
+    used = traffic if traffic is not None else model_bytes
+    ach = used / (k_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+           "traffic": traffic, "traffic_source": source or "no PMC profile of this configuration: `achieved` uses bytes_by_design",
+           "bytes_by_design": int(model_bytes), "compulsory_bytes": int(compulsory_bytes),
+           "kernel": kernel, "kernel_ms": round(k_ms, 3), "kernel_ms_source": k_ms_source, "grid_blocks": grid_blocks,
+           "note": "not HBM-bound: scene records are wave-uniform scalar-cache reads; the binding resource is fp32 VALU "
+                   "issue -- see the top-level valu_frac / valu_issue_frac / active_lanes"}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def issue_view(pmc, k_ms):
+    """(valu_issue_frac, active_lanes, s_waitcnt share) from the PMC summary: VALU instructions issued against the
+    chip's issue slots over the profiled launch (its own GRBM_GUI_ACTIVE cycles give the clock), enabled lanes
+    per issued VALU instruction, share of wave cycles spent waiting in s_waitcnt."""
+    if not pmc or "SQ_INSTS_VALU" not in pmc or "GRBM_GUI_ACTIVE" not in pmc:
+        return None, None, None
+    slots = N_SIMD * pmc["GRBM_GUI_ACTIVE"] / 2.0
+    issue = pmc["SQ_INSTS_VALU"] / slots
+    lanes = None
+    if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_ACTIVE_INST_VALU"):
+        lanes = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+    wait = pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"] if pmc.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in pmc else None
+    rnd = lambda v: None if v is None else round(v, 4)
+    return rnd(issue), rnd(lanes), rnd(wait)
 
 
 def cpu_baseline(scene, cam, cfg, width, height, target_seconds=15.0):
     """The fp64 oracle (C++ restatement of rpt's CPU algorithm, literal reference semantics,
-    one task per image row like the rayon loop) on all host cores, on a bounded sample."""
+    one task per image row like the rayon loop) on the host CPUs this process may use, on a bounded sample."""
     from oracle.pyoracle import OracleScene
     osc = OracleScene(scene)
-    cores = os.cpu_count() or 1
+    threads = usable_cpus()
     t0 = time.perf_counter()
-    osc.render(cam, width, height, 1, cfg["max_bounces"], seed=0, threads=cores)
+    osc.render(cam, width, height, 1, cfg["max_bounces"], seed=0, threads=threads)
     t1 = time.perf_counter() - t0
     spp = int(max(1, min(32, target_seconds / max(t1, 1e-3))))
     t0 = time.perf_counter()
-    osc.render(cam, width, height, spp, cfg["max_bounces"], seed=0, threads=cores)
+    osc.render(cam, width, height, spp, cfg["max_bounces"], seed=0, threads=threads)
     dt = time.perf_counter() - t0
     return {
         "value": round(width * height * spp / dt / 1e6, 4),
         "unit": "Msamples/s",
-        "cores": cores,
+        "cores": threads,
         "kind": "port",
         "sample": f"{width}x{height}x{spp}spp of the same scene (fp64 C++ restatement of rpt's CPU algorithm, "
-                  f"{dt:.1f} s, {cores} threads)",
+                  f"{dt:.1f} s, {threads} threads = usable CPUs of {os.cpu_count()} logical)",
     }
 
 
-def main():
+def cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, watts, npix=4096):
+    """C4 on the CPU: the oracle shoots the same number of photons and builds the map once (the whole of
+    photon.rs:656-704), then runs the camera pass on a random pixel subset at 1 sample per pixel; the camera time
+    is scaled to the full frame and sample count (cost is linear in both)."""
+    import numpy as np
+    from oracle.pyoracle import OracleScene
+    threads = usable_cpus()
+    t0 = time.perf_counter()
+    pm = OracleScene(scene).photon_map(n_photons, 1, watts, cfg["gather_size"], cfg["gather_size_volume"], seed=0, robust=0)
+    t_map = time.perf_counter() - t0
+    pix = np.sort(np.random.default_rng(0).choice(width * height, size=min(npix, width * height), replace=False)).astype(np.uint32)
+    t0 = time.perf_counter()
+    pm.render(cam, width, height, 1, seed=0, pixels=pix, threads=threads)
+    t_cam = (time.perf_counter() - t0) * (width * height / len(pix)) * spp
+    return {
+        "value": round(width * height * spp / (t_map + t_cam) / 1e6, 4),
+        "unit": "Msamples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{n_photons} photons shot + map built ({t_map:.1f} s) + camera pass on {len(pix)} random pixels x 1 spp scaled to "
+                  f"{width}x{height}x{spp} ({t_cam:.0f} s extrapolated); fp64 C++ restatement of src/photon.rs, {threads} threads",
+    }
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--workload", default="C3", choices=sorted(SCENE_FILES))
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -95,17 +220,22 @@ def main():
                          "previous one; 0 = 1 stream on one GPU, where the per-launch kernel time is the figure of merit, 2 on several)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl) even with one rank, to rehearse the N > 1 code path")
-    args = ap.parse_args()
+    ap.add_argument("--dryrun-cpu", action="store_true",
+                    help="no GPU: rehearse launch, rendezvous (gloo), frame reduce and the JSON line with an all-zero frame")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become the launcher.  Nothing below this line runs in this process.
+        sys.exit(spawn_ranks(args.gpus, argv))
 
     import torch  # before the HIP library: one shared HIP runtime (rpt_amd/_lib.py)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -113,7 +243,15 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dryrun_cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()   # n_gpus in the line = the ranks the communicator actually formed
+    if args.dryrun_cpu:
+        return dryrun_cpu(args, dist, rank, world)
+    torch.cuda.set_device(local_rank)
 
     import numpy as np
     import rpt_amd
@@ -141,9 +279,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     rpt_amd.set_option("timing", 1)
 
-    kernel_ms = []
-
     photon = "photons" in cfg   # C4: Renderer::photon_render = shoot + build the map + camera pass, every step
+    n_photons = 0
     if photon:
         n_photons = args.photons or cfg["photons"]
         r.gather_size(cfg["gather_size"]).gather_size_volume(cfg["gather_size_volume"])
@@ -195,26 +332,83 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     grid_blocks = r.timing()[2]
-    kernel_ms.append(r.timing_mean()[0])   # HIP events around every timed launch, on the stream it ran on
+    k_ms = r.timing_mean()[0]   # HIP events around every timed launch of the dominant kernel, on the stream it ran on
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the same steps with the frame delivered to the host of rank 0 ("kernel launch -> framebuffer
+    # resident on host"): one pinned 24 B/pixel fp64 copy per step behind the render (and the reduce)
+    host_elapsed = None
+    if not photon or dist is None:
+        host_frame = torch.empty(width * height * 3, dtype=torch.float64, pin_memory=True) if rank == 0 else None
+        n_host = max(1, min(args.steps, 5))
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_host):
+            step()
+            drain()
+            if rank == 0:
+                slot = (step_no[0] - 1) % 2 if (args.streams == 2 and not photon) else 0
+                on = torch.cuda.default_stream() if (photon or args.streams == 1) else streams[slot]
+                with torch.cuda.stream(on):
+                    host_frame.copy_(frames[slot], non_blocking=True)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        host_elapsed = (time.perf_counter() - t0) / n_host
+        r.timing_mean()
+
+    samples_per_step = width * height * spp
+    ms_per_step = elapsed / args.steps * 1e3
+    value = samples_per_step * args.steps / elapsed / 1e6
+    local_samples = samples_per_step / world          # tiles are sharded evenly over ranks
+    n_owned_px = width * height / world
+    overlapped = args.streams == 2 and not photon
+    k_src = "HIP events around each launch"
+    if overlapped:
+        # two launches are in flight: the events of one span its wait for the CUs the other still holds, so the
+        # per-launch figure is the step time (an upper bound of the kernel's own time; the resolve is inside it)
+        k_ms, k_src = ms_per_step, "step time (launches overlap on two streams)"
+    pmc, pmc_path = pmc_profile(args.workload, width, height, spp, world, n_photons)
+    issue, lanes, wait = issue_view(pmc, k_ms)
+    compulsory = n_owned_px * 12.0   # fp32 RGB per owned pixel, written once
+    out = {
+        "metric": "Msamples/sec",
+        "value": round(value, 3),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "wall_clock_s": round(ms_per_step / 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+    }
+    if host_elapsed is not None:
+        out["value_host_resident"] = round(samples_per_step / host_elapsed / 1e6, 3)
+        out["ms_per_step_host_resident"] = round(host_elapsed * 1e3, 3)
+
     if photon:
+        # slab: one float4 per (pixel, 64-sample chunk) written by the camera pass and read by the resolve; frame: 24 B/pixel
+        n_chunks = (spp + 63) // 64
+        model = n_owned_px * (32.0 * n_chunks + 24.0)
+        out["config"] = {"workload": f"{WORKLOAD_NAMES['C4']} {width}x{height}x{spp}spp, {n_photons} photons shot + map build + "
+                                     f"camera pass per step", "scene": SCENE_FILES["C4"], "parallelism": f"tile-shard x{world}",
+                         "streams": args.streams, "camera_pass_kernel_ms": round(k_ms, 3)}
+        out["roofline"] = roofline_block("rptg::photon_query_kernel", k_ms, k_src, grid_blocks, pmc, pmc_path, compulsory, model)
+        out.update({"valu_frac": None, "valu_issue_frac": issue, "active_lanes": lanes, "s_waitcnt_share": wait,
+                    "pmc_source": pmc_path})
         if rank == 0:
-            samples_per_step = width * height * spp
-            ms_per_step = elapsed / args.steps * 1e3
-            print(json.dumps({
-                "metric": "Msamples/sec", "value": round(samples_per_step * args.steps / elapsed / 1e6, 3),
-                "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"C4 lampshade beam x point photon map {width}x{height}x{spp}spp, "
-                                       f"{n_photons} photons shot + map build + camera pass per step",
-                           "scene": "examples/volumetric_beamphoton_lampshade.rs", "parallelism": f"tile-shard x{world}", "streams": args.streams,
-                           "camera_pass_kernel_ms": round(float(np.mean(kernel_ms)), 3)},
-                "roofline": None}), flush=True)
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, r.watts_)
+                out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -231,64 +425,62 @@ def main():
     rpt_amd.set_option("counters", 0)
 
     if rank == 0:
-        samples_per_step = width * height * spp
-        ms_per_step = elapsed / args.steps * 1e3
-        value = samples_per_step * args.steps / elapsed / 1e6
         stats = r.scene_stats()
         bytes_ps, flops_ps, rays_ps = algorithmic_work(stats, len(scene.objects), cnt, max(cnt["samples"], 1))
-        k_ms = float(np.mean(kernel_ms))
-        overlapped = args.streams == 2
-        if overlapped:
-            # two launches are in flight: the events of one span its wait for the CUs the other still holds, so the
-            # per-launch figure is the step time (an upper bound of the kernel's own time; the resolve is inside it)
-            k_ms = ms_per_step
-        local_samples = samples_per_step / world          # tiles are sharded evenly over ranks
-        ach_gbs = bytes_ps * local_samples / (k_ms * 1e-3) / 1e9
         ach_tflops = flops_ps * local_samples / (k_ms * 1e-3) / 1e12
-        out = {
-            "metric": "Msamples/sec",
-            "value": round(value, 3),
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3),
-            "wall_clock_s": round(ms_per_step / 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload} lampshade-in-fog path trace {width}x{height}x{spp}spp"
-                       if args.workload == "C3" else f"{args.workload} {width}x{height}x{spp}spp",
-                       "scene": "examples/volumetric_pathtrace_lampshade.rs" if args.workload == "C3" else args.workload,
-                       "parallelism": f"tile-shard x{world}", "streams": args.streams, "rays_per_sample": round(rays_ps, 3),
-                       "Mrays_per_s": round(value * rays_ps, 1)},
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(ach_gbs, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(ach_gbs / HBM_PEAK_GBS, 4),
-                "traffic": hbm_traffic_from_profile(args.workload, width, height, spp, world),
-                "kernel": "rptg::render_kernel",
-                "kernel_ms": round(k_ms, 3),
-                "kernel_ms_source": "step time (launches overlap on two streams)" if overlapped else "HIP events around each launch",
-                "grid_blocks": grid_blocks,
-                "algorithmic_bytes_per_sample": round(bytes_ps, 1),
-                "note": "scene records are wave-uniform and served from the scalar cache, not HBM: the binding "
-                        "resource is fp32 VALU issue, see `valu` and DESIGN.md section 5",
-                "valu": {"achieved": round(ach_tflops, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach_tflops / FP32_PEAK_TFLOPS, 4),
-                         "algorithmic_flops_per_sample": round(flops_ps, 1)},
-            },
-        }
+        chunk_spp, n_chunks = r.chunking(spp)
+        model = n_owned_px * (32.0 * n_chunks + 24.0)   # slab written + read, fp64 frame written
+        out["config"] = {"workload": f"{WORKLOAD_NAMES[args.workload]} {width}x{height}x{spp}spp", "scene": SCENE_FILES[args.workload],
+                         "parallelism": f"tile-shard x{world}", "streams": args.streams, "rays_per_sample": round(rays_ps, 3),
+                         "Mrays_per_s": round(value * rays_ps, 1), "chunk_spp": chunk_spp}
+        out["roofline"] = roofline_block("rptg::render_kernel", k_ms, k_src, grid_blocks, pmc, pmc_path, compulsory, model,
+                                         {"algorithmic_scene_bytes_per_sample": round(bytes_ps, 1)})
+        out.update({"valu_frac": round(ach_tflops / FP32_PEAK_TFLOPS, 4), "valu_tflops": round(ach_tflops, 3),
+                    "valu_peak_tflops": FP32_PEAK_TFLOPS, "algorithmic_flops_per_sample": round(flops_ps, 1),
+                    "valu_issue_frac": issue, "active_lanes": lanes, "s_waitcnt_share": wait, "pmc_source": pmc_path,
+                    "path_lanes": round(cnt["vertices"] / max(1, 64 * cnt["wave_trips"]), 4)})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cam, cfg, width, height)
             out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
+        dist.destroy_process_group()
+
+
+def dryrun_cpu(args, dist, rank, world):
+    """--dryrun-cpu: everything around the device work -- argument handling, rank launch, rendezvous, tile sharding,
+    the per-step frame reduce to rank 0, max-over-ranks timing, the JSON line -- on the CPU with gloo.  Each rank
+    writes 1.0 into the pixels of the tiles it owns; the reduced frame must be all ones."""
+    import numpy as np
+    import torch
+    from rpt_amd.api import shard_pixels
+    width, height = args.width or 256, args.height or 192
+    frame = torch.zeros(height * width, 3, dtype=torch.float64)
+    frame[torch.from_numpy(shard_pixels(width, height, rank, world).astype(np.int64))] = 1.0
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = frame.clone()
+        if dist is not None:
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ok = bool(np.all(out.numpy() == 1.0))
+        print(json.dumps({"metric": "Msamples/sec", "value": 0.0, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "dryrun": True, "frame_assembled": ok,
+                          "config": {"workload": f"dry run {width}x{height}: tile shards reduced to rank 0, no device work",
+                                     "parallelism": f"tile-shard x{world}"}}), flush=True)
+    if dist is not None:
         dist.destroy_process_group()
 
 

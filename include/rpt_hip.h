@@ -163,6 +163,10 @@ int rpt_get_timing(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* g
  * milliseconds per launch.  Renders do not wait for their events, so a loop of rpt_render_sample_device calls
  * stays asynchronous and is measured afterwards.  Starts a new measurement. */
 int rpt_get_timing_mean(rpt_scene*, double* render_ms, double* resolve_ms, int32_t* launches);
+/* The work decomposition rpt_render_sample* will use for `iterations` samples per pixel (pure host function of
+ * `iterations` and the "chunk_spp" option): samples per work item and work items (= partial-sum slab entries of
+ * 16 bytes) per pixel. */
+int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_chunks);
 /* Runtime options (all optional): "counters" 0/1, "chunk_spp" (samples per work item, 0 = auto),
  * "blocks_per_cu" (persistent grid size), "timing" 0/1, "scene_bvh_min" (read by rpt_scene_commit:
  * number of bounded primitives + BVH meshes from which one scene-level BVH replaces the linear

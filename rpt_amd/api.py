@@ -779,6 +779,13 @@ class Renderer:
         _lib.check(_lib.load().rpt_get_timing_mean(self.scene._handle, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
 
+    @staticmethod
+    def chunking(iterations):
+        """(samples per work item, work items per pixel) of a sample(iterations) call (rpt_render_chunking)."""
+        c, n = C.c_uint32(), C.c_uint32()
+        _lib.check(_lib.load().rpt_render_chunking(int(iterations), C.byref(c), C.byref(n)))
+        return int(c.value), int(n.value)
+
     def scene_stats(self):
         """rpt_scene_stats of the committed scene (flattened-layout record counts and bytes)."""
         out = (C.c_uint64 * 16)()

@@ -23,8 +23,11 @@ void photon_release(void* p);      // defined in photon.hip
 // Fills camera, tiles, slab, queue, chunking exactly as for the path tracer; `st` is the stream the launch will run
 // on (it selects the launch set: slab + work counter).
 // min_chunk: lower bound of the automatic samples-per-work-item choice (an explicit "chunk_spp" option wins).
+// fixed_chunk != 0: the caller's kernel has its own work decomposition with exactly that many samples per chunk
+// (the photon camera pass: 64); option and automatic rule are ignored, so the slab [n_chunks][n_owned] this
+// function sizes is the one that kernel and resolve_kernel index.
 int prepare_render(rpt_scene* s, hipStream_t st, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations, uint64_t seed,
-                   uint32_t sample_offset, rptg::RenderArgs& a, uint32_t min_chunk = 0);
+                   uint32_t sample_offset, rptg::RenderArgs& a, uint32_t min_chunk = 0, uint32_t fixed_chunk = 0);
 // Zeroes the queue / sharded frame, calls `launch(args, n_blocks, stream)` with a persistent grid of
 // blocks_per_cu blocks per CU, then resolves the slab into d_out.
 int run_persistent(rpt_scene* s, const rpt_render_params* prm, const rptg::RenderArgs& a, double* d_out, hipStream_t st,

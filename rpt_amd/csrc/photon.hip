@@ -417,6 +417,7 @@ struct QueryArgs {
     uint32_t skip;           // diagnostic (rpt_set_option "photon_skip"): 1 = no volume estimate, 2 = no surface estimate
     uint32_t* cand;          // [waves of the grid][cand_cap] candidate photons of each wave's current pixel block
     uint32_t cand_cap;       // 0: no candidate lists (every sample walks the tree)
+    uint32_t* gather;        // GG kernels (gather size > kGatherLds): [waves of the grid][2][K][64] gather lists in global memory
 };
 
 // Batched wave-cooperative walk (used when the rays of a wave do not form a packet).  Walking one
@@ -429,6 +430,11 @@ struct QueryArgs {
 // wave-private LDS stack of kBeamCap entries; near the cap the walk degrades to depth-first (batch
 // of 1), whose extra footprint is bounded by the tree depth.  *overflow is set if even that fails.
 static constexpr uint32_t kBeamCap = 1024;
+// Largest k-nearest gather whose per-lane (distance, index) lists fit the wave's LDS region (4 waves x [2][K][64]
+// dwords in 160 KB next to the 32 KB traversal stack); larger gathers (examples/lighthouse.rs and
+// volumetric_photonphoton_lampshade.rs use gather_size 100) keep the same lists in global memory (GG kernels).
+static constexpr uint32_t kGatherLds = 56;
+static constexpr uint32_t kGatherMax = 1024;
 static constexpr uint32_t kCandCap = 4096;  // candidate photons one wave keeps per 8x8 pixel block (global memory)
 template <class G, class F>
 RPT_DEV void beam_walk_batch(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
@@ -709,7 +715,7 @@ RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint
 
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
-template <bool MEDIUM, bool BVH>
+template <bool MEDIUM, bool BVH, bool GG = false>
 __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q) {
     extern __shared__ uint32_t dyn_lds[];
     const RenderArgs& a = q.r;
@@ -721,8 +727,10 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     // the beam walk's pending-entry stack + staging slots.
     const uint32_t lane_ = threadIdx.x & 63u, wave_ = threadIdx.x >> 6;
     uint32_t* region = dyn_lds + (BVH ? 32u * 256u : 0u) + wave_ * q.region_dwords;
-    float* gd = reinterpret_cast<float*>(region) + lane_;
-    uint32_t* gi = region + K * 64u + lane_;
+    // GG: the lists of a gather larger than kGatherLds live in a per-wave global-memory region, same [k][lane] layout
+    uint32_t* const lists = GG ? q.gather + size_t(blockIdx.x * 4u + wave_) * (size_t(K) * 128u) : region;
+    float* gd = reinterpret_cast<float*>(lists) + lane_;
+    uint32_t* gi = lists + K * 64u + lane_;
     uint32_t* wstack = region;
     F4* stage = reinterpret_cast<F4*>(region + kBeamCap);
     const float sigma_t = sc.sigma_a + sc.sigma_s;
@@ -1047,6 +1055,8 @@ struct PhotonMapDev {
     uint32_t* d_overflow = nullptr;
     uint32_t* d_cand = nullptr;  // per-wave candidate lists of the camera pass
     size_t cand_words = 0;
+    uint32_t* d_gather = nullptr;  // per-wave k-nearest lists of gathers too large for LDS
+    size_t gather_words = 0;
     void release_raw() {
         (void)hipFree(raw_s); (void)hipFree(raw_v);
         raw_s = raw_v = nullptr;
@@ -1058,10 +1068,12 @@ struct PhotonMapDev {
         (void)hipFree(vol.nodes); (void)hipFree(vol.sorted);
         (void)hipFree(d_overflow);
         (void)hipFree(d_cand);
+        (void)hipFree(d_gather);
         release_raw();
         d_overflow = nullptr;
         d_cand = nullptr;
-        cand_words = 0;
+        d_gather = nullptr;
+        cand_words = gather_words = 0;
         surf = DevLbvh{};
         vol = DevLbvh{};
         built = false;
@@ -1390,18 +1402,17 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
                               double* d_out, hipStream_t st, bool sync_counters) {
     auto* pm = s ? static_cast<PhotonMapDev*>(rpti::photon_slot(s)) : nullptr;
     if (!pm || !pm->built) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
-    if (std::max(gather_size, gather_size_volume) > 56)
-        return rpti::fail(RPT_ERR_UNSUPPORTED, "gather sizes > 56 do not fit the LDS gather list");
-    const uint64_t gather_lds = pm->kind == RPT_PHOTON_MAP ? std::max(gather_size, gather_size_volume) : gather_size;
+    const uint64_t gather_max = pm->kind == RPT_PHOTON_MAP ? std::max(gather_size, gather_size_volume) : gather_size;
+    if (gather_max > kGatherMax) return rpti::fail(RPT_ERR_UNSUPPORTED, "gather sizes above 1024 are not supported");
+    const bool gg = gather_max > kGatherLds;  // lists in global memory
+    const uint64_t gather_lds = gg ? 0 : gather_max;
     QueryArgs q{};
-    int rc = rpti::prepare_render(s, st, cam, prm, num_samples, seed, sample_offset, q.r, 32);
+    // Work items of the camera pass are wave-level: (8x8 pixel block, chunk of up to 64 samples); the chunking is
+    // fixed here (whatever the "chunk_spp" option says) and prepare_render sizes the slab [n_chunks][n_owned] for it.
+    int rc = rpti::prepare_render(s, st, cam, prm, num_samples, seed, sample_offset, q.r, 0, 64);
     if (rc) return rc;
     rc = rpti::serialize_with_other_streams(s, st);  // candidate lists and the overflow flag exist once per scene
     if (rc) return rc;
-    // Work items of the camera pass are wave-level: (8x8 pixel block, chunk of up to 64 samples).  The slab
-    // prepare_render sized for its (smaller) chunks is large enough: [n_chunks][n_owned] with fewer chunks.
-    q.r.chunk_spp = 64u;
-    q.r.n_chunks = (num_samples + 63u) / 64u;
     q.r.n_items = (q.r.n_owned / 64u) * q.r.n_chunks;
     q.s_nodes = pm->surf.nodes; q.s_ph = pm->surf.sorted; q.n_s = pm->surf.n;
     q.v_nodes = pm->vol.nodes; q.v_ph = pm->vol.sorted; q.n_v = pm->vol.n;
@@ -1418,16 +1429,36 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     auto launch = [&](const RenderArgs& ra, int nb, hipStream_t stream) -> hipError_t {
         QueryArgs qq = q;
         qq.r = ra;
-        if (medium) {
-            if (bvh) hipLaunchKernelGGL((photon_query_kernel<true, true>), dim3(nb), dim3(256), lds, stream, qq);
-            else hipLaunchKernelGGL((photon_query_kernel<true, false>), dim3(nb), dim3(256), lds, stream, qq);
+        const dim3 g(nb), b(256);
+        if (gg) {
+            if (medium) {
+                if (bvh) hipLaunchKernelGGL((photon_query_kernel<true, true, true>), g, b, lds, stream, qq);
+                else hipLaunchKernelGGL((photon_query_kernel<true, false, true>), g, b, lds, stream, qq);
+            } else {
+                if (bvh) hipLaunchKernelGGL((photon_query_kernel<false, true, true>), g, b, lds, stream, qq);
+                else hipLaunchKernelGGL((photon_query_kernel<false, false, true>), g, b, lds, stream, qq);
+            }
+        } else if (medium) {
+            if (bvh) hipLaunchKernelGGL((photon_query_kernel<true, true>), g, b, lds, stream, qq);
+            else hipLaunchKernelGGL((photon_query_kernel<true, false>), g, b, lds, stream, qq);
         } else {
-            if (bvh) hipLaunchKernelGGL((photon_query_kernel<false, true>), dim3(nb), dim3(256), lds, stream, qq);
-            else hipLaunchKernelGGL((photon_query_kernel<false, false>), dim3(nb), dim3(256), lds, stream, qq);
+            if (bvh) hipLaunchKernelGGL((photon_query_kernel<false, true>), g, b, lds, stream, qq);
+            else hipLaunchKernelGGL((photon_query_kernel<false, false>), g, b, lds, stream, qq);
         }
         return hipGetLastError();
     };
     int bpc = int(std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / std::max<size_t>(lds, 1))));
+    if (gg) {  // one [2][K][64]-dword region per wave of the largest grid run_persistent may launch
+        const size_t words = size_t(rpti::scene_dev(s).n_cus) * size_t(bpc) * 4u * size_t(gather_max) * 128u;
+        if (words > pm->gather_words) {
+            (void)hipFree(pm->d_gather);
+            pm->d_gather = nullptr;
+            pm->gather_words = 0;
+            RPTI_HIP_TRY(hipMalloc((void**)&pm->d_gather, words * 4u));
+            pm->gather_words = words;
+        }
+        q.gather = pm->d_gather;
+    }
     if (pm->kind == RPT_PHOTON_POINT_BEAM && medium && pm->vol.n && rpti::option_photon_block_lists()) {
         const size_t words = size_t(rpti::scene_dev(s).n_cus) * size_t(bpc) * 4u * kCandCap;
         if (words > pm->cand_words) {

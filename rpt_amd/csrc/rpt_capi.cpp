@@ -1370,8 +1370,25 @@ extern "C" int64_t rpt_shard_tiles(uint32_t width, uint32_t height, uint32_t sha
     return n;
 }
 
+// Samples per work item.  Small items keep the persistent grid's tail short when a GPU owns only 1/8 of the
+// tiles; the value depends on `iterations` alone so that the fp32 partial sums, and hence the image bits, do not
+// change with the shard count.  At most 64 chunks per pixel.
+static uint32_t chunk_rule(uint32_t iterations, uint32_t min_chunk, uint32_t fixed_chunk) {
+    if (fixed_chunk) return fixed_chunk;
+    const int64_t chunk = g_opt_chunk_spp > 0 ? g_opt_chunk_spp
+                                              : std::min<int64_t>(32, std::max<int64_t>(std::max<int64_t>(2, min_chunk), (int64_t(iterations) + 63) / 64));
+    return uint32_t(std::min<int64_t>(chunk, iterations));
+}
+int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_chunks) {
+    if (iterations == 0) return fail(RPT_ERR_INVALID, "empty render");
+    const uint32_t c = chunk_rule(iterations, 0, 0);
+    if (chunk_spp) *chunk_spp = c;
+    if (n_chunks) *n_chunks = (iterations + c - 1) / c;
+    return RPT_OK;
+}
+
 extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
-                         uint64_t seed, uint32_t sample_offset, RenderArgs& a, uint32_t min_chunk) {
+                         uint64_t seed, uint32_t sample_offset, RenderArgs& a, uint32_t min_chunk, uint32_t fixed_chunk) {
     if (!s || !cam || !prm) return fail(RPT_ERR_INVALID, "null argument");
     if (!s->committed) return fail(RPT_ERR_STATE, "rpt_scene_commit must be called before rendering");
     if (prm->width == 0 || prm->height == 0 || iterations == 0) return fail(RPT_ERR_INVALID, "empty render");
@@ -1399,12 +1416,7 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     a.max_bounces = prm->max_bounces;
     a.iterations = iterations;
     a.sample_offset = sample_offset;
-    // Samples per work item.  Small items keep the persistent grid's tail short when a GPU owns only
-    // 1/8 of the tiles; the value depends on `iterations` alone so that the fp32 partial sums, and
-    // hence the image bits, do not change with the shard count.  At most 64 chunks per pixel.
-    int64_t chunk = g_opt_chunk_spp > 0 ? g_opt_chunk_spp
-                                        : std::min<int64_t>(32, std::max<int64_t>(std::max<int64_t>(2, min_chunk), (int64_t(iterations) + 63) / 64));
-    a.chunk_spp = uint32_t(std::min<int64_t>(chunk, iterations));
+    a.chunk_spp = chunk_rule(iterations, min_chunk, fixed_chunk);
     a.n_chunks = (iterations + a.chunk_spp - 1) / a.chunk_spp;
     a.seed_mixed = seed_mix(seed);
 

@@ -19,22 +19,28 @@ from rpt_amd import scenes  # noqa: E402
 from tests.util import random_rays  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = {  # name -> (scene factory, ray sphere centre, radius, tile size, spp)
+CASES = {  # name -> (scene factory, ray sphere centre, radius, tile size, spp[, number of rays (default 256)])
     "C1": (scenes.spheres, (0.5, 0.0, 1.0), 12.0, 32, 16),
     "C1lit": (scenes.spheres_lit, (0.5, 0.0, 1.0), 12.0, 32, 16),
     "C2": (scenes.cornell, (278.0, 274.0, 280.0), 700.0, 32, 16),
     "C3": (scenes.lampshade, (278.0, 274.0, 280.0), 700.0, 32, 16),
     "C5small": (lambda: scenes.mesh_in_fog(nu=32, nv=32), (0.0, 0.0, 0.0), 4.0, 32, 16),
+    # config C5 at the size bench.py --workload C5 walks: 224 x 224 x 2 = 100,352 triangles (the reference's kd-tree in
+    # the oracle, the two-box BVH on the device); more rays than the small cases because only ~14 % of them reach the mesh
+    "C5": (scenes.mesh_in_fog, (0.0, 0.0, 0.0), 4.0, 64, 16, 4096),
     "fractal": (scenes.fractal_spheres, (0.0, 0.0, 0.0), 4.0, 32, 16),
 }
 
 
 def main():
-    for name, (make, centre, radius, size, spp) in CASES.items():
+    only = sys.argv[1:]
+    for name, (make, centre, radius, size, spp, *rest) in CASES.items():
+        if only and name not in only:
+            continue
         scene, cam, cfg = make()
         o = OracleScene(scene)
         rng = np.random.default_rng(2024)
-        ro, rd = random_rays(rng, 256, np.array(centre), radius)
+        ro, rd = random_rays(rng, rest[0] if rest else 256, np.array(centre), radius)
         ro, rd = ro.astype(np.float32), rd.astype(np.float32)   # what the device is given
         t, obj, nrm = o.intersect(ro, rd, robust=1)
         bounces = max(cfg["max_bounces"], 2) if name == "fractal" else cfg["max_bounces"]

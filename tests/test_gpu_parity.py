@@ -284,6 +284,34 @@ def test_mesh_in_fog_render_matches_oracle():
     assert abs(got.mean() - exp.mean()) / exp.mean() < 5e-3
 
 
+def test_c5_at_its_configured_mesh_size_matches_oracle():
+    """Config C5 as bench.py --workload C5 renders it: scenes.mesh_in_fog() at its default 224 x 224 x 2 = 100,352
+    triangles (examples/dragon.rs:32-73 layout).  The device walks its two-box BVH with deferred, resumable walks; the
+    oracle walks the reference's kd-tree (src/kdtree.rs:154-226) recursively.  (a) closest hits on 40 k rays,
+    (b) a 64x64x16 render of the full mesh in fog at the same seed.  tests/golden/C5.npz freezes the same two things."""
+    scene, cam, cfg = scenes.mesh_in_fog()
+    r = Renderer(scene, cam)
+    st = r.scene_stats()
+    assert st["bvh_tris"] == 100352 and st["scene_bvh"] == 0 and st["tree_depth"] <= 20
+    o, d = random_rays(np.random.default_rng(3), 40000, np.zeros(3), 4.0)
+    t, obj, nrm = r.get_closest_hit(o, d)
+    orc = _oracle(scene)
+    te, obje, nrme = orc.intersect(o.astype(np.float32), d.astype(np.float32), robust=1)
+    same = obj == obje
+    assert same.mean() > 0.999 and (obje == 0).sum() > 5000
+    hit = same & (obje >= 0)
+    rel = np.abs(t[hit] - te[hit]) / te[hit]
+    assert np.quantile(rel, 0.999) < 2e-4                    # silhouette edges may pick the neighbouring triangle
+    close = hit & (np.abs(t - te) <= 2e-4 * te)
+    assert np.quantile(np.abs(nrm[close] - nrme[close]).max(axis=1), 0.999) < 5e-3
+    size, spp = 64, 16
+    got = r.width(size).height(size).max_bounces(cfg["max_bounces"]).seed(8).sample_array(spp)
+    exp = orc.render(cam, size, size, spp, cfg["max_bounces"], seed=8, robust=1)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert rel_rms(got, exp) < 1e-2
+    assert abs(got.mean() - exp.mean()) / exp.mean() < 5e-3
+
+
 @pytest.mark.parametrize("fog", [True, False])
 def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
     """Per-mesh-tree kernels park the tree walks of a wave and run them together (kernels.hip, PH_WAIT*):
@@ -407,12 +435,18 @@ def test_cpp_mirror_example_renders_the_same_bytes_as_the_python_mirror():
 
 
 # ------------------------------------------------------------------ BASELINE.json full sizes
-@pytest.mark.parametrize("name,npix,tol_robust,tol_literal", [("C2", 4096, 2e-3, 2e-2), ("C3", 2048, 2e-3, 3e-2)])
-def test_full_size_configs_match_oracle_on_a_pixel_subset(name, npix, tol_robust, tol_literal):
-    """The full BASELINE configuration (C2 512x512x64, C3 1024x1024x256) on the GPU; the fp64
-    oracle renders the same seed on a random pixel subset (it is ~1000x slower).  Both epsilon
-    policies of the oracle are reported: `robust` is what the fp32 path implements, `literal`
-    is the reference's 1e-12 policy whose fp64 rounding noise the fp32 path cannot reproduce."""
+# (config, pixels in the subset, rel-RMS bound vs the robust oracle, vs the literal oracle, bound on the mean bias vs literal)
+# The last column is the known delta to rpt itself: the reference's 1e-12 shadow / t_min
+# epsilons lose energy to fp64 self-hits and false shadow rejections, which the fp32 policy does not reproduce; measured
+# +0.77 % (C2), +0.16 % (C3) in round 1.  The bounds sit just above the measured values so that the gap cannot grow unseen.
+@pytest.mark.parametrize("name,npix,tol_robust,tol_literal,bias_literal", [
+    ("C2", 4096, 2e-3, 2e-2, (6.5e-3, 9.0e-3)), ("C3", 2048, 2e-3, 3e-2, (0.5e-3, 2.5e-3)), ("C5", 1024, 5e-3, 5e-2, (-5e-3, 1.5e-2))])
+def test_full_size_configs_match_oracle_on_a_pixel_subset(name, npix, tol_robust, tol_literal, bias_literal):
+    """The full BASELINE configuration (C2 512x512x64, C3 1024x1024x256, C5 2048x2048x1024 over the 100,352-triangle
+    mesh) on the GPU; the fp64 oracle renders the same seed on a random pixel subset (it is ~1000x slower).  Both
+    epsilon policies of the oracle are reported: `robust` is what the fp32 path implements, `literal` is the
+    reference's 1e-12 policy whose fp64 rounding noise the fp32 path cannot reproduce; the mean bias against
+    `literal` is asserted to stay inside the recorded interval."""
     import json
     import os
     scene, cam, cfg = scenes.CONFIGS[name]()
@@ -424,16 +458,20 @@ def test_full_size_configs_match_oracle_on_a_pixel_subset(name, npix, tol_robust
     rob = orc.render(cam, w, h, spp, mb, seed=11, robust=1, pixels=pix)[pix]
     lit = orc.render(cam, w, h, spp, mb, seed=11, robust=0, pixels=pix)[pix]
     e_rob, e_lit, e_orc = rel_rms(got[pix], rob), rel_rms(got[pix], lit), rel_rms(rob, lit)
+    bias_rob = (got[pix].mean() - rob.mean()) / rob.mean()
+    bias_lit = (got[pix].mean() - lit.mean()) / lit.mean()
     out = {"config": name, "size": [w, h, spp], "pixels": int(npix), "rel_rms_vs_robust_oracle": e_rob,
            "rel_rms_vs_literal_oracle": e_lit, "rel_rms_oracle_robust_vs_literal": e_orc,
-           "mean_gpu": float(got[pix].mean()), "mean_robust": float(rob.mean()), "mean_literal": float(lit.mean())}
+           "mean_gpu": float(got[pix].mean()), "mean_robust": float(rob.mean()), "mean_literal": float(lit.mean()),
+           "mean_bias_vs_robust": float(bias_rob), "mean_bias_vs_literal": float(bias_lit)}
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/parity_full_{name}.json", "w") as f:
         json.dump(out, f, indent=1)
     print(out)
     assert e_rob < tol_robust
     assert e_lit < tol_literal
-    assert abs(got[pix].mean() - rob.mean()) / rob.mean() < 1e-3
+    assert abs(bias_rob) < 1e-3
+    assert bias_literal[0] < bias_lit < bias_literal[1]
 
 
 def test_hdri_environment_matches_oracle():

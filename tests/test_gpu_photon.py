@@ -48,6 +48,53 @@ def test_photon_shooting_and_radii_match_oracle(name):
             assert np.median(rr) < 1e-5 and (rr > 1e-2).mean() < 0.03                    # 10-NN gather radius
 
 
+def test_c4_at_its_configured_one_million_photons():
+    """Config C4 at the photon count examples/volumetric_beamphoton_lampshade.rs:139-164 uses (1 M photons -> ~1.9 M
+    surface + ~2.0 M volume records): the device LBVH (63-bit Morton keys, Karras with index tie-break, multi-photon
+    leaves) and the oracle's restatement of src/photon.rs:204-247 on the same seed.
+    (a) stored-photon counts; (b) a 20 k subset of the oracle's photons is found among the device's; (c) the 10-NN
+    radii of a 10 k subset of the DEVICE's volume photons equal an independent scipy cKDTree query on the downloaded
+    positions (no oracle involved); (d) the camera pass at 1024 x 1024 x 4 spp on a 2,048-pixel subset."""
+    from scipy.spatial import cKDTree
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    n = cfg["photons"]
+    assert n == 1_000_000
+    watts = cfg["renderer_watts"]
+    w = h = 1024
+    r = Renderer(scene, cam).width(w).height(h).watts(watts).gather_size(cfg["gather_size"]) \
+        .gather_size_volume(cfg["gather_size_volume"]).seed(7)
+    st = r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    pm = _oracle(scene).photon_map(n, 1, watts, cfg["gather_size"], cfg["gather_size_volume"], seed=7, robust=1)
+    rng = np.random.default_rng(1)
+    for which in (0, 1):
+        g, e = r.photon_map_download(which), pm.photons(which)
+        assert len(g) == st["surface" if which == 0 else "volume"] and len(e) > 1_800_000
+        assert abs(len(g) - len(e)) < 2e-3 * len(e)         # a few chains flip a decision in fp32
+        tree = cKDTree(g[:, :3].astype(np.float64))
+        sub = e[rng.choice(len(e), size=20000, replace=False)]
+        dist, j = tree.query(sub[:, :3])
+        ok = dist < 1e-4 * (1 + np.abs(sub[:, :3]).max(axis=1))
+        assert ok.mean() > 0.998
+        gp, ep = g[j[ok]], sub[ok]
+        assert np.quantile((np.abs(gp[:, 6:9] - ep[:, 6:9]) / (np.abs(ep[:, 6:9]) + 1e-12)).max(axis=1), 0.999) < 1e-4
+        if which == 1:
+            rr = np.abs(gp[:, 9] - ep[:, 9]) / ep[:, 9]
+            assert np.median(rr) < 1e-5 and (rr > 1e-2).mean() < 0.03
+            # independent of the oracle: the radius is the distance to the 10th nearest volume photon, itself included
+            # (src/photon.rs:214-232, `nearests(p, 10)` on the map that holds p)
+            pick = rng.choice(len(g), size=10000, replace=False)
+            d10 = tree.query(g[pick, :3].astype(np.float64), k=10)[0][:, 9]
+            assert np.max(np.abs(d10 - g[pick, 9]) / d10) < 1e-5
+    pix = np.sort(np.random.default_rng(5).choice(w * h, size=2048, replace=False)).astype(np.uint32)
+    got = r.seed(0).photon_sample_array(4)[pix]
+    r.seed(7)
+    exp = pm.render(cam, w, h, 4, seed=0, pixels=pix)[pix]
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    err, bias = rel_rms(got, exp), abs(got.mean() - exp.mean()) / exp.mean()
+    print({"C4_1M_rel_rms": err, "C4_1M_mean_bias": bias, "surface": st["surface"], "volume": st["volume"]})
+    assert err < 1e-2 and bias < 2e-3
+
+
 def test_photon_map_is_deterministic_and_seeded():
     scene, cam, cfg = scenes.CONFIGS["C4"]()
     r = Renderer(scene, cam).watts(1000.0).seed(3)
@@ -94,6 +141,48 @@ def test_point_point_photon_map_matches_oracle(name, tol):
     assert abs(got.mean() - exp.mean()) / exp.mean() < 5e-3
     d = np.abs(got - exp).sum(axis=1) / (np.abs(exp).sum(axis=1) + 1e-9)
     assert (d > 0.01).mean() < 0.05
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_gather_size_of_the_reference_examples_above_the_lds_limit(kind):
+    """examples/lighthouse.rs and examples/volumetric_photonphoton_lampshade.rs use gather_size 100 with
+    gather_size_volume 30: more (distance, index) pairs per lane than the wave's LDS region holds (56), so the camera
+    pass keeps its k-nearest lists in global memory (photon.hip, GG kernels).  Same estimate, same oracle."""
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    n, size, spp = 20000, 48, 4
+    watts = 14.65 * n
+    r = Renderer(scene, cam).width(size).height(size).watts(watts).gather_size(100).gather_size_volume(30).seed(2)
+    r.photon_map_build(n, kind)
+    got = r.photon_sample_array(spp)
+    pm = _oracle(scene).photon_map(n, kind, watts, 100, 30, seed=2, robust=1)
+    exp = pm.render(cam, size, size, spp, seed=2)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert rel_rms(got, exp) < 2e-2
+    assert abs(got.mean() - exp.mean()) / exp.mean() < 5e-3
+    # and the LDS path gives the same answer as the global-memory path where both apply (k = 56 vs the oracle)
+    r56 = Renderer(scene, cam).width(size).height(size).watts(watts).gather_size(56).gather_size_volume(30).seed(2)
+    r56.photon_map_build(n, kind)
+    exp56 = _oracle(scene).photon_map(n, kind, watts, 56, 30, seed=2, robust=1).render(cam, size, size, spp, seed=2)
+    assert rel_rms(r56.photon_sample_array(spp), exp56) < 2e-2
+
+
+def test_camera_pass_slab_follows_its_own_chunking_whatever_chunk_spp_says():
+    """The photon camera pass works in chunks of 64 samples; the "chunk_spp" option (path tracer) must not size its
+    slab: with chunk_spp = 128 and 130 samples the pass writes three chunks per pixel (the slab held one)."""
+    import rpt_amd
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    n, size, spp = 5000, 64, 130
+    r = Renderer(scene, cam).width(size).height(size).watts(14.65 * n).gather_size(20).gather_size_volume(3).seed(4)
+    r.photon_map_build(n, 1)
+    ref = r.photon_sample_array(spp)
+    rpt_amd.set_option("chunk_spp", 128)
+    try:
+        r2 = Renderer(scene, cam).width(size).height(size).watts(14.65 * n).gather_size(20).gather_size_volume(3).seed(4)
+        r2.photon_map_build(n, 1)
+        got = r2.photon_sample_array(spp)
+    finally:
+        rpt_amd.set_option("chunk_spp", 0)
+    assert np.array_equal(got, ref) and np.all(np.isfinite(got)) and got.mean() > 0
 
 
 def test_beam_beam_photon_map_matches_oracle():

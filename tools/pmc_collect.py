@@ -1,21 +1,50 @@
-"""Sum the counter_collection CSVs of tools/pmc_passes.sh per counter for the render kernel (per launch)."""
+"""Sum the counter_collection CSVs of tools/pmc_passes.sh per counter for the dominant kernel (per launch) and write
+<out>/pmc_<workload>.json -- the file bench.py looks up under profiles/rNN/ for its roofline / issue figures.
+
+    python tools/pmc_collect.py <out_dir> [workload] [--width W --height H --spp S --photons P]
+"""
+import argparse
 import csv
 import glob
 import json
+import os
 import re
 import sys
 from collections import defaultdict
 
-out = sys.argv[1]
-tot, launches = defaultdict(float), defaultdict(set)
-for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("out")
+ap.add_argument("workload", nargs="?", default="C3")
+ap.add_argument("--width", type=int, default=0)
+ap.add_argument("--height", type=int, default=0)
+ap.add_argument("--spp", type=int, default=0)
+ap.add_argument("--photons", type=int, default=0)
+args, _ = ap.parse_known_args()
+
+from rpt_amd import scenes  # noqa: E402  (pure Python: scene constants only)
+cfg = scenes.CONFIGS[args.workload]()[2]
+kernel = "photon_query_kernel" if "photons" in cfg else "render_kernel"
+tot, launches, durations = defaultdict(float), defaultdict(set), []
+for f in glob.glob(args.out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
-        if "render_kernel" not in name or re.search(r"render_kernel<\w+, \d, true[,>]", name) or re.search(r"render_kernelILb[01]ELi\dELb1E", name):
+        if kernel not in name:
+            continue
+        if kernel == "render_kernel" and (re.search(r"render_kernel<\w+, \d, true[,>]", name) or re.search(r"render_kernelILb[01]ELi\dELb1E", name)):
             continue  # the timed launches only (the COUNT = true instantiation is bench.py's untimed counter pass)
         tot[row["Counter_Name"]] += float(row["Counter_Value"])
         launches[row["Counter_Name"]].add(row.get("Dispatch_Id"))
 res = {k: tot[k] / max(1, len(launches[k])) for k in sorted(tot)}
 res["_launches_per_counter"] = {k: len(v) for k, v in launches.items()}
-json.dump(res, open(out + "/pmc_render_kernel.json", "w"), indent=1)
+res["_kernel"] = kernel
+res["_config"] = {"workload": args.workload, "width": args.width or cfg["width"], "height": args.height or cfg["height"],
+                  "spp": args.spp or cfg["spp"], "n_gpus": 1}
+if "photons" in cfg:
+    res["_config"]["photons"] = args.photons or cfg["photons"]
+res["_how"] = ("rocprofv3 --kernel-trace --pmc <group>, one run per counter group (tools/pmc_passes.sh), bench.py --steps 1 --warmup 1; "
+               "values are per-launch means over the timed launches; FETCH_SIZE / WRITE_SIZE in KB")
+path = os.path.join(args.out, f"pmc_{args.workload}.json")
+json.dump(res, open(path, "w"), indent=1)
 print(json.dumps(res, indent=1))
