@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
     // are read once per sample: 4 blocks x (32 + 5) KB still fit the CU's 160 KB.
     constexpr uint32_t kStateBase = BVH ? 32u * 256u : 0u;  // dwords: after the traversal stack
     uint32_t* const ls = dyn_lds + kStateBase + threadIdx.x;  // [slots][256] dwords, one column per lane
-    enum { S_SLAB = 0, S_END = 1, S_PIX = 2, S_XN = 3, S_YN = 4, S_S = 5, S_ACC = 6 };
+    enum { S_SLAB = 0, S_END = 1, S_PIX = 2, S_XN = 3, S_YN = 4, S_S = 5, S_ACC = 6, S_P = 9, S_Q = 12, S_RC = 15, S_MAT = 18, S_N = 24 };
     auto in_lds = [](int k) { return BVH == 0 || k <= S_YN; };
     V acc_r = mk(0, 0, 0);
     uint32_t slab_idx_r = 0, s_r = 0, s_end_r = 0, pix_r = 0;
@@ -112,6 +112,13 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
         stf(S_ACC + 0, acc_r.x, ldf(S_ACC + 0, acc_r.x) + v.x);
         stf(S_ACC + 1, acc_r.y, ldf(S_ACC + 1, acc_r.y) + v.y);
         stf(S_ACC + 2, acc_r.z, ldf(S_ACC + 2, acc_r.z) + v.z);
+    };
+    // The radiance carrier (P, Q, Rc) is read and written once per vertex: in the scan instantiations it lives in LDS
+    // as well, which takes 6 (9 without a medium) long-lived values out of the 96-VGPR budget.
+    auto ldv = [&](int k, V reg) { return BVH == 0 ? mk(__uint_as_float(ls[k * 256]), __uint_as_float(ls[(k + 1) * 256]), __uint_as_float(ls[(k + 2) * 256])) : reg; };
+    auto stv = [&](int k, V& reg, V v) {
+        if (BVH == 0) { ls[k * 256] = __float_as_uint(v.x); ls[(k + 1) * 256] = __float_as_uint(v.y); ls[(k + 2) * 256] = __float_as_uint(v.z); }
+        else reg = v;
     };
     uint32_t depth = 0;
     bool alive = true, have_item = false, need_path = true;
@@ -223,9 +230,15 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
                 float dy = rng.range(-a.inv_dim, a.inv_dim);
                 cast_ray(a.cam, ldf(S_XN, xn_r) + dx, ldf(S_YN, yn_r) + dy, rng, ro, rd);
                 depth = 0;
-                P = mk(0, 0, 0);
-                Q = mk(1, 1, 1);
-                Rc = mk(kInf, kInf, kInf);
+                if constexpr (BVH == 0) {
+                    stv(S_P, P, mk(0, 0, 0));
+                    stv(S_Q, Q, mk(1, 1, 1));
+                    if (!MEDIUM) stv(S_RC, Rc, mk(kInf, kInf, kInf));
+                } else {
+                    P = mk(0, 0, 0);
+                    Q = mk(1, 1, 1);
+                    Rc = mk(kInf, kInf, kInf);
+                }
                 stu(S_S, s_r, s + 1u);
                 item_done = s + 1u >= ldu(S_END, s_end_r);
                 need_path = false;
@@ -422,7 +435,12 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
         const bool ev_surface = !ev_medium && hit;
         if (!ev_medium && !ev_surface) {  // miss: environment (src/renderer.rs:198-206, 288)
             SECT(4);
-            acc_add(vmin(fma3(Q, env_color(sc, rd), P), Rc));
+            if constexpr (BVH == 0) {
+                const V v = fma3(ldv(S_Q, Q), env_color(sc, rd), ldv(S_P, P));
+                acc_add(MEDIUM ? v : vmin(v, ldv(S_RC, Rc)));   // in a medium Rc stays +inf (no firefly clamp, src/renderer.rs:229-232)
+            } else {
+                acc_add(vmin(fma3(Q, env_color(sc, rd), P), Rc));
+            }
             need_path = true;
             continue;
         }
@@ -513,16 +531,32 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
             }
         }
         SECT(14);
-        P = fma3(Q, E, P);
-        if (bounce && !is_zero(k)) {
-            if (!MEDIUM) Rc = vmin(Rc, fma3(100.f, Q, P));  // FIREFLY_CLAMP, src/renderer.rs:311-313
-            Q = Q * k;
-            ro = x;
-            rd = wi;
-            depth++;
+        if constexpr (BVH == 0) {
+            const V q = ldv(S_Q, Q);
+            const V pn = fma3(q, E, ldv(S_P, P));
+            if (bounce && !is_zero(k)) {
+                stv(S_P, P, pn);
+                if (!MEDIUM) stv(S_RC, Rc, vmin(ldv(S_RC, Rc), fma3(100.f, q, pn)));  // FIREFLY_CLAMP, src/renderer.rs:311-313
+                stv(S_Q, Q, q * k);
+                ro = x;
+                rd = wi;
+                depth++;
+            } else {
+                acc_add(MEDIUM ? pn : vmin(pn, ldv(S_RC, Rc)));
+                need_path = true;
+            }
         } else {
-            acc_add(vmin(P, Rc));
-            need_path = true;
+            P = fma3(Q, E, P);
+            if (bounce && !is_zero(k)) {
+                if (!MEDIUM) Rc = vmin(Rc, fma3(100.f, Q, P));  // FIREFLY_CLAMP, src/renderer.rs:311-313
+                Q = Q * k;
+                ro = x;
+                rd = wi;
+                depth++;
+            } else {
+                acc_add(vmin(P, Rc));
+                need_path = true;
+            }
         }
     }
 
@@ -680,7 +714,7 @@ __global__ void debug_camera_kernel(const CameraG cam, uint32_t w, uint32_t h, u
 
 // ------------------------------------------------------------------ launchers
 static constexpr size_t kStackBytes = 32u * 256u * sizeof(uint32_t);
-static constexpr size_t kStateBytes = 9u * 256u * sizeof(uint32_t);      // LDS-resident lane state of the scan instantiations
+static constexpr size_t kStateBytes = 18u * 256u * sizeof(uint32_t);      // LDS-resident lane state of the scan instantiations
 static constexpr size_t kStateBytesBvh = 5u * 256u * sizeof(uint32_t);   // ... of the tree-walking ones (behind the stack)
 
 template <bool M, int B, bool C>
