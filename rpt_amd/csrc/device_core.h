@@ -368,15 +368,23 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
 }
 
 // The linear scan over the wave-uniform primitive records (everything that is not in a tree).
-RPT_DEV void scan_prims(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code) {
+// MASKED: bit i of `mask` (wave-uniform) says whether bounded record i -- numbered in scan order: spheres, cubes,
+// boxes, rectangles, triangles, as in SceneView::pbox -- can be hit at all; planes and the shell are always tested.
+template <bool MASKED = false>
+RPT_DEV void scan_prims(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint64_t mask = ~0ull) {
+    uint32_t bit = 0;  // wave-uniform record number
+    auto on = [&](uint32_t i) { return !MASKED || ((mask >> ((bit + i) & 63u)) & 1ull) != 0ull; };
     for (uint32_t i = 0; i < sc.n_sph; i++) {
+        if (!on(i)) continue;
         const XfScan x = uload(&sc.sph[i]);
         V ol, dl;
         to_local(x, o, d, ol, dl);
         float t = hit_sphere(ol, dl, tmin);
         if (t >= 0.f && t < tbest) { tbest = t; code = (K_SPHERE << 28) | i; }
     }
+    bit += sc.n_sph;
     for (uint32_t i = 0; i < sc.n_cub; i++) {
+        if (!on(i)) continue;
         const XfScan x = uload(&sc.cub[i]);
         V ol, dl;
         to_local(x, o, d, ol, dl);
@@ -384,6 +392,7 @@ RPT_DEV void scan_prims(const SceneView& sc, V o, V d, float tmin, float& tbest,
         float t = hit_cube<false>(ol, dl, tmin, f);
         if (t >= 0.f && t < tbest) { tbest = t; code = (K_CUBE << 28) | i; }
     }
+    bit += sc.n_cub;
     for (uint32_t i = 0; i < sc.n_pln; i++) {
         const F4 nv = uload(&sc.pln[i]).nv;
         float t = hit_plane(nv, o, d, tmin);
@@ -394,33 +403,59 @@ RPT_DEV void scan_prims(const SceneView& sc, V o, V d, float tmin, float& tbest,
         const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
         if (sc.has_shell) hit_shell(uload(sc.shell), o, inv, tmin, tbest, code);
         for (uint32_t i = 0; i < sc.n_aabb; i++) {
+            if (!on(i)) continue;
             const AabbScan b = uload(&sc.aabb[i]);
             uint32_t f;
             float t = hit_aabb<false>(b.lo, b.hi, o, inv, tmin, f);
             if (t >= 0.f && t < tbest) { tbest = t; code = (K_AABB << 28) | i; }
         }
+        bit += sc.n_aabb;
         uint32_t i = 0;
         for (uint32_t e = sc.n_rect_x; i < e; i++) {
+            if (!on(i)) continue;
             const RectScan r = uload(&sc.rect[i]);
             float t = hit_rect(r.a, r.b.x, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, tbest);
             if (t >= 0.f) { tbest = t; code = (K_RECT << 28) | i; }
         }
         for (uint32_t e = sc.n_rect_x + sc.n_rect_y; i < e; i++) {
+            if (!on(i)) continue;
             const RectScan r = uload(&sc.rect[i]);
             float t = hit_rect(r.a, r.b.x, o.y, inv.y, o.z, d.z, o.x, d.x, tmin, tbest);
             if (t >= 0.f) { tbest = t; code = (K_RECT << 28) | i; }
         }
         for (uint32_t e = n_rect; i < e; i++) {
+            if (!on(i)) continue;
             const RectScan r = uload(&sc.rect[i]);
             float t = hit_rect(r.a, r.b.x, o.z, inv.z, o.x, d.x, o.y, d.y, tmin, tbest);
             if (t >= 0.f) { tbest = t; code = (K_RECT << 28) | i; }
         }
+        bit += n_rect;
+    } else {
+        bit += sc.n_aabb + n_rect;
     }
     for (uint32_t i = 0; i < sc.n_tri; i++) {
+        if (!on(i)) continue;
         const TriScan tr = uload(&sc.tri[i]);
         float t = hit_tri(tr.pn, tr.A, tr.B, o, d, tmin, tbest);
         if (t >= 0.f) { tbest = t; code = (K_TRI << 28) | i; }
     }
+}
+// Which scanned records can a query touch that stays inside the ball (c, r) of each live lane?  Wave-uniform mask
+// for scan_prims<true> (the union over the lanes: one lane's ball reaching a box keeps that record for all of them).
+// Scenes with more than 64 bounded scan records do not occur (from 64 on, the scene-level tree takes over).
+RPT_DEV uint64_t scan_mask_for_ball(const SceneView& sc, bool live, V c, float r) {
+    const uint32_t n = sc.n_sph + sc.n_cub + sc.n_aabb + sc.n_rect_x + sc.n_rect_y + sc.n_rect_z + sc.n_tri;
+    if (n > 64u) return ~0ull;
+    const float r2 = r * r;
+    uint64_t mask = 0ull;
+    for (uint32_t i = 0; i < n; i++) {
+        const AabbScan b = uload(&sc.pbox[i]);
+        const float dx = fmaxf(fmaxf(b.lo.x - c.x, c.x - b.hi.x), 0.f);
+        const float dy = fmaxf(fmaxf(b.lo.y - c.y, c.y - b.hi.y), 0.f);
+        const float dz = fmaxf(fmaxf(b.lo.z - c.z, c.z - b.hi.z), 0.f);
+        if (__any(live && fmaf(dx, dx, fmaf(dy, dy, dz * dz)) <= r2)) mask |= 1ull << i;
+    }
+    return mask;
 }
 // Would a walk of the per-mesh trees visit anything?  The two child boxes of every mesh root against the
 // interval the scan left (scalar loads: the roots are wave-uniform).

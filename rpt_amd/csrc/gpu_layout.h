@@ -153,6 +153,10 @@ struct SceneView {
     const AabbScan* aabb;  uint32_t n_aabb;
     const RectScan* rect;  const RectShade* rect_sh; uint32_t n_rect_x, n_rect_y, n_rect_z;  // sorted by axis
     const ShellScan* shell; uint32_t has_shell;  // rectangles folded into the shell follow the scanned ones in rect_sh
+    // World boxes (lo, hi; padded) of the scanned bounded records in scan order -- spheres, cubes, boxes, rectangles,
+    // triangles -- for queries that are known to stay inside a small ball (photon-gather visibility rays): records whose
+    // box misses the ball are skipped (scan_prims<true>).  Planes and the shell have no entry: always tested.
+    const AabbScan* pbox;
     const BvhNode* nodes;  const TriScan* btri;     const TriShade* btri_sh;
     const MeshRef* meshes; uint32_t n_mesh;
     // Scene-level BVH over every bounded primitive and mesh root (built when the scene has many

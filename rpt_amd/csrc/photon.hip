@@ -306,9 +306,11 @@ __global__ void refit_kernel(const PhotonRec* p, int n, const uint32_t* left, co
 // leaf_max > 1 collapses every subtree of at most leaf_max photons into one leaf entry (its photons are a
 // contiguous run of the sorted array): fewer dependent node loads per k-NN query.  The internal nodes
 // below a collapsed entry stay in the array, unreferenced.
+// pad0 / pad1 of a photon-tree node: its parent node (0xFFFFFFFF at the root) and which child of it this node is --
+// what the stackless wave-level search (knn_walk_wave) climbs back on.
 __global__ void pack_kernel(const PhotonRec* p, int n, const uint32_t* left, const uint32_t* right, const float* box,
-                            const uint32_t* range_lo, const uint32_t* range_hi, BvhNode* nodes, int use_radius,
-                            uint32_t leaf_max) {
+                            const uint32_t* range_lo, const uint32_t* range_hi, const uint32_t* parent_int, BvhNode* nodes,
+                            int use_radius, uint32_t leaf_max) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     BvhNode w;
@@ -327,7 +329,9 @@ __global__ void pack_kernel(const PhotonRec* p, int n, const uint32_t* left, con
     for (int k = 0; k < 3; k++) { w.lo0[k] = lo[0][k]; w.hi0[k] = hi[0][k]; w.lo1[k] = lo[1][k]; w.hi1[k] = hi[1][k]; }
     w.e0 = ch[0];
     w.e1 = ch[1];
-    w.pad0 = w.pad1 = 0;
+    const uint32_t par = parent_int[i];
+    w.pad0 = par;
+    w.pad1 = (par != 0xFFFFFFFFu && left[par] != uint32_t(i)) ? 1u : 0u;
     nodes[i] = w;
 }
 
@@ -373,6 +377,50 @@ RPT_DEV void knn_walk(const BvhNode* nodes, const PhotonRec* p, uint32_t n, V q,
         }
         if (sp == 0) break;
         cur = stack[--sp];
+    }
+}
+// The same search for the live lanes of a wave TOGETHER: one traversal whose control flow is wave-uniform -- a
+// child is opened when ANY lane's bound reaches its box -- with the node in scalar registers (one s_load instead of
+// 64 per-lane loads) and only the distance tests and the visit per lane.  In lock-step SIMD execution the per-lane
+// walks already cost the union of their node visits; what this removes is the 64-entry per-lane stack in scratch
+// memory (a dependent memory round trip per pop) and the exec-mask bookkeeping of a divergent loop.  It needs no
+// stack at all: a node knows its parent (pad0) and which child of it it is (pad1), and the order in which a node's
+// children are opened is a function of the node and the query points alone (the child nearer to most lanes first),
+// so a node re-read on the way up knows which child it has just finished.  Every lane is offered a superset of the
+// photons its own walk would visit, in another order: the K nearest are the same set.  Meant for queries that lie
+// close together (the samples of one pixel); every lane that is live at the call stays live throughout.
+template <class F>
+RPT_DEV void knn_walk_wave(const BvhNode* nodes, const PhotonRec* p, uint32_t n, V q, float& bound, F&& visit) {
+    if (n == 0) return;
+    auto leaf = [&](uint32_t e) {
+        const uint32_t first = e & PH_LEAF_INDEX, count = ((e >> 26) & 31u) + 1u;
+        for (uint32_t k = 0; k < count; k++) {
+            const F4 pr = uload(reinterpret_cast<const F4*>(p + first + k));   // pos_r is the record's first 16 bytes
+            V d = xyz(pr) - q;
+            bound = visit(first + k, dot(d, d));
+        }
+    };
+    if (n == 1u) { leaf(BVH_LEAF); return; }
+    const uint32_t live = uint32_t(__popcll(__ballot(true)));
+    uint32_t cur = 0u, from = 2u;   // wave-uniform: node, and where it was entered from (2: its parent, 0 / 1: back from that child)
+    for (;;) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        const BvhNode nd = uload(nodes + cur);
+        const float d0 = box_dist2(nd.lo0, nd.hi0, q), d1 = box_dist2(nd.lo1, nd.hi1, q);
+        const uint32_t c_first = (2u * uint32_t(__popcll(__ballot(d0 <= d1))) >= live) ? 0u : 1u;
+        uint32_t next = from == 2u ? c_first : (from == c_first ? 1u - c_first : 2u);   // 2: nothing left here
+        bool descend = false;
+        while (next != 2u) {
+            const bool hit = __ballot((next == 0u ? d0 : d1) <= bound) != 0ull;   // (the bounds have shrunk since the node was entered)
+            const uint32_t e = next == 0u ? nd.e0 : nd.e1;
+            if (hit && !(e & BVH_LEAF)) { cur = e; from = 2u; descend = true; break; }
+            if (hit) leaf(e);
+            next = next == c_first ? 1u - c_first : 2u;
+        }
+        if (descend) continue;
+        if (nd.pad0 == 0xFFFFFFFFu) break;
+        from = nd.pad1;
+        cur = nd.pad0;
     }
 }
 // radius = distance to the k-th (k = 10, self included) nearest photon: src/photon.rs:214-232
@@ -681,13 +729,19 @@ RPT_DEV bool beam_walk_packet(const BvhNode* nodes, const PhotonRec* photons, ui
 }
 // `guess`: squared radius the search starts with instead of +inf.  If fewer than K photons lie inside it
 // the caller repeats the search unbounded, so the result is always the exact K nearest.
+// WAVE: the live lanes search together (knn_walk_wave); every live lane of the wave must make the call.
+template <bool WAVE = false>
 RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, V x, uint32_t K, float* gd,
                             uint32_t* gi, float& max_d2, float guess = kInf) {
     uint32_t found = 0;
     float bound = guess, worst = 0.f;
     uint32_t worst_slot = 0;
     if (K > 0) {
-        knn_walk(nodes, photons, n, x, bound, [&](uint32_t idx, float d2) {
+        auto walk = [&](auto&& visit) {
+            if (WAVE) knn_walk_wave(nodes, photons, n, x, bound, visit);
+            else knn_walk(nodes, photons, n, x, bound, visit);
+        };
+        walk([&](uint32_t idx, float d2) {
             if (found < K) {
                 if (d2 > guess) return guess;
                 gd[found * 64u] = d2;
@@ -715,7 +769,10 @@ RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint
 
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
-template <bool MEDIUM, bool BVH, bool GG = false>
+// KIND: the PhotonRenderKind of the map (RPT_PHOTON_*).  One instantiation per kind: the three estimators share the
+// camera ray and the surface gather, but each drags its own register and scratch needs along (the point x point
+// volume gather keeps a 64-entry per-lane stack), which a run-time switch makes every kind pay.
+template <bool MEDIUM, bool BVH, bool GG, int KIND>
 __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q) {
     extern __shared__ uint32_t dyn_lds[];
     const RenderArgs& a = q.r;
@@ -751,7 +808,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     // found once per work item (one tree walk) and kept in a per-wave list in global memory; each pixel trip
     // re-culls that list against its own frustum while staging.
     uint32_t* const cand = q.cand_cap ? q.cand + size_t(blockIdx.x * 4u + wave_) * q.cand_cap : nullptr;
-    const bool cand_mode = MEDIUM && q.kind == RPT_PHOTON_POINT_BEAM && q.cand_cap != 0u && a.cam.aperture <= 0.f && !(q.skip & 1u);
+    const bool cand_mode = MEDIUM && KIND == RPT_PHOTON_POINT_BEAM && q.cand_cap != 0u && a.cam.aperture <= 0.f && !(q.skip & 1u);
     uint32_t cand_n = 0;       // wave-uniform
     bool cand_valid = false;   // wave-uniform: the list describes the block this wave is working on
     const uint32_t n_blocks64 = a.n_owned >> 6;  // 8x8 blocks owned by this rank
@@ -827,7 +884,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         V color = mk(0, 0, 0);
         bool surface_on = hit;
         float surface_scale = 1.f;
-        if (MEDIUM && q.kind == RPT_PHOTON_MAP) {  // point x point volume estimate, src/photon.rs:384-438
+        if (MEDIUM && KIND == RPT_PHOTON_MAP) {  // point x point volume estimate, src/photon.rs:384-438
             if (active) {
                 const float xi = rng.range(0.f, 1.f);               // Medium::sample_d
                 const float dd = -__logf(xi) / sigma_t;
@@ -937,7 +994,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     vc = fma3(w, xyz(ph.pow), vc);
                 }
             };
-            if (q.kind == RPT_PHOTON_BEAM_BEAM) {
+            if (KIND == RPT_PHOTON_BEAM_BEAM) {
                 if (!beam_walk_packet<false>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow,
                                              [](const PhotonRec& ph, const V&) { return ph; }, visit_beam))
                     beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_none, visit_beam);
@@ -978,10 +1035,19 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             float max_d2;
             const uint32_t want_k = min(q.gather_size, q.n_s);
             uint32_t found = 0;
-            if (prev_r2 > 0.f) found = gather_knn(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2, 2.f * prev_r2);
-            if (found < want_k || !(prev_r2 > 0.f)) found = gather_knn(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2);
+            // (the samples of a pixel hit within a footprint of each other: they search the tree together)
+            if (prev_r2 > 0.f) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2, 2.f * prev_r2);
+            if (found < want_k || !(prev_r2 > 0.f)) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2);
             prev_r2 = max_d2;
             V sc_col = mat_emit(mat) * mat_color(mat);
+            // Visibility of the gathered photons (src/photon.rs:357-361: "something lies between the photon and the
+            // query point").  Only a hit closer than the query point can block, and every point of the segment
+            // photon -> x lies within the gather radius of x: scanned records whose box misses that ball (of any
+            // sample of this pixel: the mask is wave-uniform) cannot decide any of the `found` tests and are skipped.
+            // The closest hit below |disp| (1 - 1e-3) is the closest hit of the unbounded query whenever that one
+            // would block, so the decisions are the same as with the full scan.
+            uint64_t vis_mask = ~0ull;
+            if (!BVH) vis_mask = scan_mask_for_ball(sc, true, x, __builtin_sqrtf(max_d2) * (1.f + 1e-4f) + 1e-6f);
             for (uint32_t k = 0; k < found; k++) {
                 const PhotonRec ph = q.s_ph[gi[k * 64u]];
                 V disp = x - xyz(ph.pos_r);
@@ -990,13 +1056,14 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 V pd = ilen * disp;
                 V po = xyz(ph.pos_r);
                 float len = len2 * ilen;
-                float ts = kInf;
+                float ts = BVH ? kInf : len * (1.f - 1e-3f);
                 uint32_t cs = CODE_MISS, is = 0;
-                if (!(q.skip & 8u))  // diagnostic: 8 = no visibility scans
-                    closest_hit<(BVH ? 2 : 0), false>(sc, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
-                // :357-361 "something lies between the photon and the query point".  A hit inside the
-                // query point's own tangent plane is the grazing ray meeting its own surface: fp64 rejects
-                // it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
+                if (!(q.skip & 8u)) {  // diagnostic: 8 = no visibility scans
+                    if (BVH) closest_hit<2, false>(sc, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
+                    else scan_prims<true>(sc, po, pd, ray_tmin_p(po), ts, cs, vis_mask);
+                }
+                // A hit inside the query point's own tangent plane is the grazing ray meeting its own surface: fp64
+                // rejects it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
                 V hp = fma3(ts, pd, po) - x;
                 bool own_plane = fabsf(dot(hp, n)) <= 1e-4f * len;
                 bool blocked = cs != CODE_MISS && !own_plane && ts < len * (1.f - 1e-3f);
@@ -1011,7 +1078,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 }
             }
             sc_col = (kInvPi * rcp(max_d2)) * sc_col;
-            if (MEDIUM && q.kind == RPT_PHOTON_MAP) sc_col = surface_scale * sc_col;  // :433-435
+            if (MEDIUM && KIND == RPT_PHOTON_MAP) sc_col = surface_scale * sc_col;  // :433-435
             else if (MEDIUM) sc_col = __expf(-sigma_t * t) * sc_col;                  // :610-611
             color = color + sc_col;
         }
@@ -1138,7 +1205,7 @@ int build_lbvh(PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t s
         RPTI_HIP_TRY(hipMemsetAsync(flags, 0, size_t(n) * 4, st));
         hipLaunchKernelGGL(refit_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, par_i, par_l, flags, box, first_mode);
         // point trees are walked by the k-NN search only (radii, gathers): collapsed leaves
-        hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, rlo, rhi, out.nodes,
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, rlo, rhi, par_i, out.nodes,
                            first_mode, first_mode == 0 ? kKnnLeaf : 1u);
     }
     if (with_radius) {
@@ -1149,7 +1216,7 @@ int build_lbvh(PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t s
         if (n >= 2) {
             RPTI_HIP_TRY(hipMemsetAsync(flags, 0, size_t(n) * 4, st));
             hipLaunchKernelGGL(refit_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, par_i, par_l, flags, box, 1);
-            hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, rlo, rhi, out.nodes, 1,
+            hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), left, right, box, rlo, rhi, par_i, out.nodes, 1,
                                1u);  // sphere tree for the beam walkers: one photon per leaf
         }
     }
@@ -1180,6 +1247,27 @@ void rpti::photon_release(void* p) {
     if (m) {
         m->release();
         delete m;
+    }
+}
+
+template <bool M, bool B, bool G>
+static void launch_query_k(const QueryArgs& q, int kind, int nb, size_t lds, hipStream_t st) {
+    const dim3 g(nb), b(256);
+    if (kind == RPT_PHOTON_MAP) hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_MAP>), g, b, lds, st, q);
+    else if (kind == RPT_PHOTON_BEAM_BEAM) hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_BEAM_BEAM>), g, b, lds, st, q);
+    else hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_POINT_BEAM>), g, b, lds, st, q);
+}
+static void launch_query(const QueryArgs& q, bool medium, bool bvh, bool gg, int kind, int nb, size_t lds, hipStream_t st) {
+    const int sel = (medium ? 4 : 0) | (bvh ? 2 : 0) | (gg ? 1 : 0);
+    switch (sel) {
+        case 0: launch_query_k<false, false, false>(q, kind, nb, lds, st); break;
+        case 1: launch_query_k<false, false, true>(q, kind, nb, lds, st); break;
+        case 2: launch_query_k<false, true, false>(q, kind, nb, lds, st); break;
+        case 3: launch_query_k<false, true, true>(q, kind, nb, lds, st); break;
+        case 4: launch_query_k<true, false, false>(q, kind, nb, lds, st); break;
+        case 5: launch_query_k<true, false, true>(q, kind, nb, lds, st); break;
+        case 6: launch_query_k<true, true, false>(q, kind, nb, lds, st); break;
+        default: launch_query_k<true, true, true>(q, kind, nb, lds, st); break;
     }
 }
 
@@ -1429,22 +1517,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     auto launch = [&](const RenderArgs& ra, int nb, hipStream_t stream) -> hipError_t {
         QueryArgs qq = q;
         qq.r = ra;
-        const dim3 g(nb), b(256);
-        if (gg) {
-            if (medium) {
-                if (bvh) hipLaunchKernelGGL((photon_query_kernel<true, true, true>), g, b, lds, stream, qq);
-                else hipLaunchKernelGGL((photon_query_kernel<true, false, true>), g, b, lds, stream, qq);
-            } else {
-                if (bvh) hipLaunchKernelGGL((photon_query_kernel<false, true, true>), g, b, lds, stream, qq);
-                else hipLaunchKernelGGL((photon_query_kernel<false, false, true>), g, b, lds, stream, qq);
-            }
-        } else if (medium) {
-            if (bvh) hipLaunchKernelGGL((photon_query_kernel<true, true>), g, b, lds, stream, qq);
-            else hipLaunchKernelGGL((photon_query_kernel<true, false>), g, b, lds, stream, qq);
-        } else {
-            if (bvh) hipLaunchKernelGGL((photon_query_kernel<false, true>), g, b, lds, stream, qq);
-            else hipLaunchKernelGGL((photon_query_kernel<false, false>), g, b, lds, stream, qq);
-        }
+        launch_query(qq, medium, bvh, gg, pm->kind, nb, lds, stream);
         return hipGetLastError();
     };
     int bpc = int(std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / std::max<size_t>(lds, 1))));

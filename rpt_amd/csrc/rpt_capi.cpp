@@ -1243,6 +1243,37 @@ int rpt_scene_commit(rpt_scene* s, int device) {
             if (pleaf.size() >= BVH_INDEX_MASK) return fail(RPT_ERR_UNSUPPORTED, "too many primitives");
         }
     }
+    // world boxes of the scanned bounded records, in scan order (SceneView::pbox)
+    std::vector<AabbScan> pbox;
+    {
+        auto push_box = [&](const float lo[3], const float hi[3]) {
+            AabbScan b;
+            float l[3], h[3];
+            for (int a = 0; a < 3; a++) {
+                const float pad = 1e-5f * (std::fabs(lo[a]) + std::fabs(hi[a]) + (hi[a] - lo[a])) + 1e-7f;
+                l[a] = lo[a] - pad;
+                h[a] = hi[a] + pad;
+            }
+            b.lo = F4{l[0], l[1], l[2], 0.f};
+            b.hi = F4{h[0], h[1], h[2], 0.f};
+            pbox.push_back(b);
+        };
+        for (const PBox& b : box_sph) push_box(b.lo, b.hi);
+        for (const PBox& b : box_cub) push_box(b.lo, b.hi);
+        for (const AabbScan& b : aabb) { const float lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z}; push_box(lo, hi); }
+        size_t i = 0;
+        for (int axis = 0; axis < 3; axis++)
+            for (size_t k = 0; k < rect_axis[axis].size(); k++, i++) {   // the scanned rectangles (shell faces are gone)
+                const RectScan& r = rect[i];
+                float lo[3], hi[3];
+                lo[axis] = hi[axis] = r.a.x;
+                lo[(axis + 1) % 3] = r.a.y; hi[(axis + 1) % 3] = r.a.z;
+                lo[(axis + 2) % 3] = r.a.w; hi[(axis + 2) % 3] = r.b.x;
+                push_box(lo, hi);
+            }
+        for (const PBox& b : box_tri) push_box(b.lo, b.hi);
+    }
+    size_t o_pbox = reserve(pbox.size() * sizeof(AabbScan));
     size_t o_pleaf = reserve(pleaf.size() * sizeof(uint32_t));
     size_t o_shell = reserve(sizeof(ShellScan));
     size_t o_inst = reserve(insts.size() * sizeof(InstRec));
@@ -1264,6 +1295,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     put(o_pln, pln.data(), pln.size() * sizeof(PlaneScan));    put(o_plns, pln_sh.data(), pln_sh.size() * sizeof(PlaneShade));
     put(o_tri, tri.data(), tri.size() * sizeof(TriScan));      put(o_tris, tri_sh.data(), tri_sh.size() * sizeof(TriShade));
     put(o_aabb, aabb.data(), aabb.size() * sizeof(AabbScan));
+    put(o_pbox, pbox.data(), pbox.size() * sizeof(AabbScan));
     put(o_pleaf, pleaf.data(), pleaf.size() * sizeof(uint32_t));
     put(o_shell, &shell, sizeof(ShellScan));
     put(o_inst, insts.data(), insts.size() * sizeof(InstRec));
@@ -1289,6 +1321,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     v.rect = (const RectScan*)(base + o_rect);  v.rect_sh = (const RectShade*)(base + o_rects);
     v.n_rect_x = uint32_t(rect_axis[0].size()); v.n_rect_y = uint32_t(rect_axis[1].size()); v.n_rect_z = uint32_t(rect_axis[2].size());
     v.shell = (const ShellScan*)(base + o_shell); v.has_shell = has_shell ? 1u : 0u;
+    v.pbox = (const AabbScan*)(base + o_pbox);
     v.nodes = (const BvhNode*)(base + o_nodes); v.btri = (const TriScan*)(base + o_btri);      v.btri_sh = (const TriShade*)(base + o_btris);
     v.meshes = (const MeshRef*)(base + o_mesh); v.n_mesh = uint32_t(meshes.size());
     v.pleaf = (const uint32_t*)(base + o_pleaf); v.n_nodes = uint32_t(nodes.size());
