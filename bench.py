@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 N_SIMD = 1024              # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues every 2 clocks per SIMD
+N_XCD = 8                  # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs: / 8 = the launch's clock cycles
 
 SCENE_FILES = {"C2": "examples/cornell.rs", "C3": "examples/volumetric_pathtrace_lampshade.rs",
                "C4": "examples/volumetric_beamphoton_lampshade.rs", "C5": "examples/dragon.rs layout, procedural 100,352-triangle mesh"}
@@ -147,7 +148,7 @@ def issue_view(pmc, k_ms):
     per issued VALU instruction, share of wave cycles spent waiting in s_waitcnt."""
     if not pmc or "SQ_INSTS_VALU" not in pmc or "GRBM_GUI_ACTIVE" not in pmc:
         return None, None, None
-    slots = N_SIMD * pmc["GRBM_GUI_ACTIVE"] / 2.0
+    slots = N_SIMD * (pmc["GRBM_GUI_ACTIVE"] / N_XCD) / 2.0
     issue = pmc["SQ_INSTS_VALU"] / slots
     lanes = None
     if pmc.get("SQ_THREAD_CYCLES_VALU") and pmc.get("SQ_ACTIVE_INST_VALU"):

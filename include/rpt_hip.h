@@ -167,7 +167,11 @@ int rpt_get_timing_mean(rpt_scene*, double* render_ms, double* resolve_ms, int32
  * `iterations` and the "chunk_spp" option): samples per work item and work items (= partial-sum slab entries of
  * 16 bytes) per pixel. */
 int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_chunks);
-/* Runtime options (all optional): "counters" 0/1, "chunk_spp" (samples per work item, 0 = auto),
+/* Options.  Every scene has its own set: a copy of the process defaults taken by rpt_scene_create, changed with
+ * rpt_scene_set_option (before rpt_scene_commit for the options the commit reads, at any time for the others; nothing
+ * a commit or render reads is process-global, so scenes with different options may be driven from different host
+ * threads).  rpt_set_option changes the defaults, i.e. the scenes created afterwards (and what rpt_render_chunking
+ * reports).  Names (all optional): "counters" 0/1, "chunk_spp" (samples per work item, 0 = auto),
  * "blocks_per_cu" (persistent grid size), "timing" 0/1, "scene_bvh_min" (read by rpt_scene_commit:
  * number of bounded primitives + BVH meshes from which one scene-level BVH replaces the linear
  * object scan, default 64), "instancing" 0/1 (read by rpt_scene_commit: store a mesh that several
@@ -184,6 +188,7 @@ int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_ch
  * a scene that still does not fit is refused with RPT_ERR_UNSUPPORTED);
  * returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);
+int rpt_scene_set_option(rpt_scene*, const char* name, int64_t value);
 
 /* ---- Buffer on the device (src/buffer.rs:5-97): the samples of each pixel are kept as running
  * sums, so image() = box filter (Filter::Box(radius), :76-97) + color_bytes (src/color.rs:18-24)

@@ -95,6 +95,7 @@ SYMBOLS = [
     ("rpt_get_timing_mean", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("rpt_render_chunking", C.c_int, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("rpt_set_option", C.c_int, [C.c_char_p, C.c_int64]),
+    ("rpt_scene_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("rpt_buffer_create", _P, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]),
     ("rpt_buffer_destroy", None, [_P]),
     ("rpt_buffer_add_samples", C.c_int, [_P, _P]),

@@ -15,6 +15,7 @@ renderer.rs:163), `Renderer.shard(rank, count)` (multi-GPU tiles) and `Renderer.
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 
@@ -39,10 +40,20 @@ def shard_pixels(width, height, rank, count):
     return np.sort(np.concatenate(out)) if out else np.zeros(0, dtype=np.uint32)
 
 
+_LIVE_SCENES = weakref.WeakSet()   # Scene objects that hold a device handle
+
+
 def set_option(name, value):
-    """rpt_set_option: "counters", "timing", "chunk_spp", "blocks_per_cu", "scene_bvh_min", "instancing" and
-    "room_shell" (read at commit)."""
-    _lib.check(_lib.load().rpt_set_option(name.encode(), int(value)))
+    """Process-wide convenience over the C ABI's per-scene options: sets the default for scenes created from now on
+    (rpt_set_option) and the option of every scene this process has on a device (rpt_scene_set_option), so that
+    `set_option("counters", 1)` acts on the renderer at hand as it always did.  Options read by rpt_scene_commit
+    ("scene_bvh_min", "instancing", "room_shell", "bvh_leaf_max", "bvh_max_depth") only matter before a scene's
+    first render; use Scene.set_option to give one scene its own value."""
+    lib = _lib.load()
+    _lib.check(lib.rpt_set_option(name.encode(), int(value)))
+    for sc in list(_LIVE_SCENES):
+        if sc._handle is not None:
+            _lib.check(lib.rpt_scene_set_option(sc._handle, name.encode(), int(value)))
 
 
 __all__ = [
@@ -386,6 +397,7 @@ class Scene:
         self.objects, self.lights, self.media = [], [], []
         self.environment = Environment((0, 0, 0))
         self._handle = None
+        self._options = {}
 
     @staticmethod
     def new():
@@ -411,6 +423,13 @@ class Scene:
             self.add(Light.Object(Object(shape.clone()).material(material)))
         else:
             raise TypeError(f"cannot add {type(node).__name__} to a Scene")
+
+    def set_option(self, name, value):
+        """rpt_scene_set_option: this scene's own value of an option (see rpt_hip.h), whatever other scenes use."""
+        self._options[name] = int(value)
+        if self._handle is not None:
+            _lib.check(_lib.load().rpt_scene_set_option(self._handle, name.encode(), int(value)))
+        return self
 
     # ---- lowering onto the C ABI
     def _commit(self, device):
@@ -442,11 +461,14 @@ class Scene:
                 _lib.check(lib.rpt_scene_set_environment_hdri(h, env.hdri.shape[1], env.hdri.shape[0], _dp(env.hdri)))
             else:
                 _lib.check(lib.rpt_scene_set_environment_color(h, _dp(env.color)))
+            for name, value in self._options.items():
+                _lib.check(lib.rpt_scene_set_option(h, name.encode(), value))
             _lib.check(lib.rpt_scene_commit(h, device))
         except Exception:
             lib.rpt_scene_destroy(h)
             raise
         self._handle, self._device = h, device
+        _LIVE_SCENES.add(self)
         return h
 
     def close(self):

@@ -36,8 +36,8 @@ int run_persistent(rpt_scene* s, const rpt_render_params* prm, const rptg::Rende
 int serialize_with_other_streams(rpt_scene* s, hipStream_t st);  // for launches with per-scene scratch outside the launch set
 int fetch_counters(rpt_scene* s, const rptg::RenderArgs& a);  // after the stream has been synchronised
 double* scratch_out(rpt_scene* s, size_t bytes);  // cached device frame for the host-buffer entry points
-int64_t option_photon_skip();  // rpt_set_option("photon_skip"): diagnostic bit mask for the camera pass
-int64_t option_photon_block_lists();  // rpt_set_option("photon_block_lists"): per-block candidate lists on (default) / off
+int64_t option_photon_skip(rpt_scene* s);  // option "photon_skip" of the scene: diagnostic bit mask for the camera pass
+int64_t option_photon_block_lists(rpt_scene* s);  // option "photon_block_lists": per-block candidate lists on (default) / off
 }  // namespace rpti
 
 #define RPTI_HIP_TRY(expr)                                                                          \

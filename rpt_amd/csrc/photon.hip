@@ -1505,7 +1505,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     q.s_nodes = pm->surf.nodes; q.s_ph = pm->surf.sorted; q.n_s = pm->surf.n;
     q.v_nodes = pm->vol.nodes; q.v_ph = pm->vol.sorted; q.n_v = pm->vol.n;
     q.kind = uint32_t(pm->kind);
-    q.skip = uint32_t(rpti::option_photon_skip());
+    q.skip = uint32_t(rpti::option_photon_skip(s));
     q.gather_size = uint32_t(gather_size);
     q.gather_size_volume = pm->kind == RPT_PHOTON_MAP ? uint32_t(gather_size_volume) : 0u;  // only the point-point estimate gathers in the volume
     const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_nodes != 0;
@@ -1532,7 +1532,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         }
         q.gather = pm->d_gather;
     }
-    if (pm->kind == RPT_PHOTON_POINT_BEAM && medium && pm->vol.n && rpti::option_photon_block_lists()) {
+    if (pm->kind == RPT_PHOTON_POINT_BEAM && medium && pm->vol.n && rpti::option_photon_block_lists(s)) {
         const size_t words = size_t(rpti::scene_dev(s).n_cus) * size_t(bpc) * 4u * kCandCap;
         if (words > pm->cand_words) {
             (void)hipFree(pm->d_cand);

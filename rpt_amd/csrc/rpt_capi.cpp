@@ -9,6 +9,7 @@
 #include <functional>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -46,23 +47,46 @@ uint64_t seed_mix(uint64_t seed) {
             return fail(RPT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));       \
     } while (0)
 
-static int64_t g_opt_counters = 0;
-static int64_t g_opt_chunk_spp = 0;  // 0 = auto: ceil(iterations / 64) clamped to [2, 32]
-static int64_t g_opt_blocks_per_cu = 0;  // 0 = occupancy query
-static int64_t g_opt_timing = 0;
-static int64_t g_opt_room_shell = 1;  // fold rectangles that are the faces of one box into a single slab test
-static int64_t g_opt_photon_skip = 0;
-static int64_t g_opt_photon_block_lists = 1;
-namespace rpti {
-int64_t option_photon_skip() { return g_opt_photon_skip; }
-int64_t option_photon_block_lists() { return g_opt_photon_block_lists; }
+// Options.  Every scene carries its own set, copied from the process defaults when it is created
+// (rpt_scene_create) and changed with rpt_scene_set_option; rpt_set_option changes the defaults, i.e. the scenes
+// created afterwards.  Nothing a render or commit reads is process-global, so scenes with different options can
+// be driven from different host threads.
+struct rpt_options {
+    int64_t counters = 0;
+    int64_t chunk_spp = 0;          // 0 = auto: ceil(iterations / 64) clamped to [2, 32]
+    int64_t blocks_per_cu = 0;      // 0 = occupancy query
+    int64_t timing = 0;
+    int64_t room_shell = 1;         // fold rectangles that are the faces of one box into a single slab test
+    int64_t photon_skip = 0;
+    int64_t photon_block_lists = 1;
+    int64_t instancing = 1;         // meshes shared by several shapes are stored once and instanced
+    int64_t bvh_leaf_max = 4;       // triangles per leaf of a mesh tree (read by rpt_scene_commit)
+    int64_t bvh_max_depth = 20;     // a mesh tree deeper than this is rebuilt balanced (read by rpt_scene_commit)
+    int64_t defer_stop = 16;        // still-walking lanes below which a wave leaves the walk (the rest resume later)
+    int64_t defer_lanes = 32;       // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
+    int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built
+};
+static rpt_options g_defaults;
+static std::mutex g_defaults_mutex;
+static int set_option_in(rpt_options& o, const char* name, int64_t value) {
+    if (!name) return fail(RPT_ERR_INVALID, "null option name");
+    const std::string s(name);
+    if (s == "counters") o.counters = value;
+    else if (s == "chunk_spp") { if (value < 0) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 0 (0 = auto)"); o.chunk_spp = value; }
+    else if (s == "blocks_per_cu") o.blocks_per_cu = value;
+    else if (s == "timing") o.timing = value;
+    else if (s == "room_shell") o.room_shell = value;
+    else if (s == "photon_skip") o.photon_skip = value;
+    else if (s == "photon_block_lists") o.photon_block_lists = value;
+    else if (s == "instancing") o.instancing = value;
+    else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); o.defer_lanes = value; }
+    else if (s == "bvh_leaf_max") { if (value < 1 || value > 16) return fail(RPT_ERR_INVALID, "bvh_leaf_max must be 1..16"); o.bvh_leaf_max = value; }
+    else if (s == "bvh_max_depth") { if (value < 1 || value > 31) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..31"); o.bvh_max_depth = value; }
+    else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
+    else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); o.scene_bvh_min = value; }
+    else return fail(RPT_ERR_INVALID, "unknown option: " + s);
+    return RPT_OK;
 }
-static int64_t g_opt_instancing = 1;     // meshes shared by several shapes are stored once and instanced
-static int64_t g_opt_bvh_leaf_max = 4;    // triangles per leaf of a mesh tree (read by rpt_scene_commit)
-static int64_t g_opt_bvh_max_depth = 20;  // a mesh tree deeper than this is rebuilt balanced (read by rpt_scene_commit)
-static int64_t g_opt_defer_stop = 16;     // still-walking lanes below which a wave leaves the walk (the rest resume later)
-static int64_t g_opt_defer_lanes = 32;    // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
-static int64_t g_opt_scene_bvh_min = 64;  // bounded primitives + BVH meshes from which the scene-level BVH is built
 
 // ---------------------------------------------------------------------------- fp64 helpers
 namespace {
@@ -381,6 +405,7 @@ struct rpt_scene {
     uint32_t hdri_w = 0, hdri_h = 0;
     std::vector<float> hdri;  // w*h*4
     bool committed = false;
+    rpt_options opt;  // this scene's options (rpt_scene_set_option; starts as a copy of the process defaults)
     int device = 0;
     int n_cus = 256;
     // device memory
@@ -502,26 +527,20 @@ int rpt_device_count(void) {
 }
 
 int rpt_set_option(const char* name, int64_t value) {
-    if (!name) return fail(RPT_ERR_INVALID, "null option name");
-    std::string s(name);
-    if (s == "counters") g_opt_counters = value;
-    else if (s == "chunk_spp") { if (value < 0) return fail(RPT_ERR_INVALID, "chunk_spp must be >= 0 (0 = auto)"); g_opt_chunk_spp = value; }
-    else if (s == "blocks_per_cu") g_opt_blocks_per_cu = value;
-    else if (s == "timing") g_opt_timing = value;
-    else if (s == "room_shell") g_opt_room_shell = value;
-    else if (s == "photon_skip") g_opt_photon_skip = value;
-    else if (s == "photon_block_lists") g_opt_photon_block_lists = value;
-    else if (s == "instancing") g_opt_instancing = value;
-    else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); g_opt_defer_lanes = value; }
-    else if (s == "bvh_leaf_max") { if (value < 1 || value > 16) return fail(RPT_ERR_INVALID, "bvh_leaf_max must be 1..16"); g_opt_bvh_leaf_max = value; }
-    else if (s == "bvh_max_depth") { if (value < 1 || value > 31) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..31"); g_opt_bvh_max_depth = value; }
-    else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); g_opt_defer_stop = value; }
-    else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); g_opt_scene_bvh_min = value; }
-    else return fail(RPT_ERR_INVALID, "unknown option " + s);
-    return RPT_OK;
+    std::lock_guard<std::mutex> lock(g_defaults_mutex);
+    return set_option_in(g_defaults, name, value);
+}
+int rpt_scene_set_option(rpt_scene* s, const char* name, int64_t value) {
+    if (!s) return fail(RPT_ERR_INVALID, "null scene");
+    return set_option_in(s->opt, name, value);
 }
 
-rpt_scene* rpt_scene_create(void) { return new rpt_scene(); }
+rpt_scene* rpt_scene_create(void) {
+    rpt_scene* s = new rpt_scene();
+    std::lock_guard<std::mutex> lock(g_defaults_mutex);
+    s->opt = g_defaults;
+    return s;
+}
 
 void rpt_scene_destroy(rpt_scene* s) {
     if (!s) return;
@@ -716,18 +735,16 @@ static void push_tri(const double* t, const Xf& x, uint32_t obj, std::vector<Tri
     shade.push_back(sh);
 }
 
-int rpt_scene_commit(rpt_scene* s, int device) {
-    if (!s) return fail(RPT_ERR_INVALID, "null scene");
-    if (s->committed) return fail(RPT_ERR_STATE, "scene already committed");
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(RPT_ERR_INVALID, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(RPT_ERR_UNSUPPORTED, std::string("built for gfx950 (MI355X), device is ") + prop.gcnArchName);
-    s->n_cus = prop.multiProcessorCount;
+// ---------------------------------------------------------------------------- commit
+// rpt_scene_commit = flatten_objects (records of every object + one tree per large mesh) -> flatten_lights ->
+// fold_shell (flatten-time specialisation of the wall rectangles) -> mark_twin_ranges -> build_scene_tree ->
+// collect_scan_boxes -> upload.  Everything before `upload` is pure host code over the fp64 scene;
+// tests/host/flatten_harness.cpp runs the whole sequence with malloc-backed HIP stubs under ASan / UBSan.
+namespace {
+struct PBox { float lo[3], hi[3]; };   // world-space box of a bounded primitive
+struct Flattener {
+    rpt_scene* s;
+    explicit Flattener(rpt_scene* scene) : s(scene) {}
 
     std::vector<XfScan> sph, cub;
     std::vector<XfShade> sph_sh, cub_sh;
@@ -746,10 +763,25 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     std::vector<LightXf> lxf;
     std::vector<LightPart> lparts;
 
-    // World-space boxes of the bounded primitives, for the scene-level BVH.
-    struct PBox { float lo[3], hi[3]; };
+    // world-space boxes of the bounded primitives (scene-level tree, scan boxes)
     std::vector<PBox> box_sph, box_cub, box_tri, box_mesh;
-    auto xf_box = [](const Xf& x, bool sphere) {  // unit sphere / unit cube under an affine map
+    std::vector<InstRec> insts;
+    std::vector<PBox> box_inst;
+    std::unordered_map<const std::vector<double>*, uint32_t> mesh_uses;
+    std::unordered_map<const std::vector<double>*, std::pair<MeshRef, PBox>> shared;
+    int mesh_depth = 0, top_depth = 0;  // deepest mesh tree / the scene-level tree: their sum must fit the walk's stack
+    // what the later stages leave
+    ShellScan shell{};
+    bool has_shell = false;
+    std::vector<RectShade> shell_sh;   // shade records of the folded rectangles, in face order
+    std::vector<RectScan> rect;        // the scanned rectangles, sorted by axis
+    std::vector<RectShade> rect_sh;    // ... their shade records, followed by shell_sh
+    std::vector<uint32_t> pleaf;
+    uint32_t top_root = 0;
+    bool scene_bvh = false;
+    std::vector<AabbScan> pbox;
+
+    static PBox xf_box(const Xf& x, bool sphere) {  // unit sphere / unit cube under an affine map
         PBox b;
         for (int i = 0; i < 3; i++) {
             double h = 0.0;
@@ -760,8 +792,8 @@ int rpt_scene_commit(rpt_scene* s, int device) {
             b.hi[i] = float(x.M[i][3] + h);
         }
         return b;
-    };
-    auto tri_box = [](const double* t, const Xf& x) {
+    }
+    static PBox tri_box(const double* t, const Xf& x) {
         PBox b;
         D3 v[3] = {x.point(d3(t)), x.point(d3(t + 3)), x.point(d3(t + 6))};
         for (int a = 0; a < 3; a++) {
@@ -771,14 +803,9 @@ int rpt_scene_commit(rpt_scene* s, int device) {
             b.hi[a] = std::nextafter(float(hi), std::numeric_limits<float>::infinity());
         }
         return b;
-    };
-    std::vector<InstRec> insts;
-    std::vector<PBox> box_inst;
-    std::unordered_map<const std::vector<double>*, uint32_t> mesh_uses;
-    std::unordered_map<const std::vector<double>*, std::pair<MeshRef, PBox>> shared;
-    int mesh_depth = 0, top_depth = 0;  // deepest mesh tree / the scene-level tree: their sum must fit the walk's stack
+    }
     // Triangles of one mesh under `x` (identity for a shared mesh) + its two-box tree, appended to btri / nodes.
-    auto add_bvh_mesh = [&](const std::vector<double>& mt, const Xf& x, uint32_t obj, PBox& box) {
+    MeshRef add_bvh_mesh(const std::vector<double>& mt, const Xf& x, uint32_t obj, PBox& box) {
         const uint64_t nt = mt.size() / 18;
         std::vector<TriScan> ms;
         std::vector<TriShade> mh;
@@ -807,14 +834,14 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         int depth = 0;
         {
             BvhBuilder b{bt, tmp};
-            b.leaf_max = uint32_t(g_opt_bvh_leaf_max);
+            b.leaf_max = uint32_t(s->opt.bvh_leaf_max);
             b.build(0, 0, uint32_t(nt), 0);
             depth = b.max_depth;
         }
-        if (depth > g_opt_bvh_max_depth) {  // a chain-like SAH tree: the walk's stack could not hold it
+        if (depth > s->opt.bvh_max_depth) {  // a chain-like SAH tree: the walk's stack could not hold it
             tmp.assign(1, TmpNode{});
             BvhBuilder b{bt, tmp};
-            b.leaf_max = uint32_t(g_opt_bvh_leaf_max);
+            b.leaf_max = uint32_t(s->opt.bvh_leaf_max);
             b.balanced = true;
             b.build(0, 0, uint32_t(nt), 0);
             depth = b.max_depth;
@@ -850,8 +877,8 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         nodes.insert(nodes.end(), local.begin(), local.end());
         for (int a = 0; a < 3; a++) { box.lo[a] = tmp[0].lo[a]; box.hi[a] = tmp[0].hi[a]; }
         return mr;
-    };
-    std::function<void(const HShape&, const Xf&, uint32_t)> emit = [&](const HShape& shape, const Xf& x, uint32_t obj) {
+    }
+    void emit(const HShape& shape, const Xf& x, uint32_t obj) {
         switch (shape.d.kind) {
             case RPT_SHAPE_GROUP: {  // KdTree<Box<dyn Bounded>>: children become primitives of this object
                 for (const HShape& c : shape.children) {
@@ -916,7 +943,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                             box_tri.push_back(tri_box(&shape.T()[i * 18], x));
                         }
                     }
-                } else if (g_opt_instancing && mesh_uses[shape.mesh.get()] >= 2) {
+                } else if (s->opt.instancing && mesh_uses[shape.mesh.get()] >= 2) {
                     // shared mesh: one local-space tree, one InstRec per use
                     auto it = shared.find(shape.mesh.get());
                     if (it == shared.end()) {
@@ -955,435 +982,475 @@ int rpt_scene_commit(rpt_scene* s, int device) {
                 }
             }
         }
-    };
-    // meshes referenced by more than one shape (Arc<Mesh> in the reference) are instanced
-    std::function<void(const HShape&)> count_uses = [&](const HShape& shape) {
-        if (shape.d.kind == RPT_SHAPE_MESH && shape.T().size() / 18 > kLinearTriMax) mesh_uses[shape.mesh.get()]++;
-        for (const HShape& c : shape.children) count_uses(c);
-    };
-    for (const HObject& o : s->objects) count_uses(o.shape);
-    for (size_t oi = 0; oi < s->objects.size(); oi++) {
-        const HObject& o = s->objects[oi];
-        Xf x;
-        make_xf(o.shape.d, x);
-        Material gm;
-        gm.albedo_emit = F4{float(o.mat.albedo[0]), float(o.mat.albedo[1]), float(o.mat.albedo[2]), float(o.mat.emittance)};
-        gm.params = F4{bits_f(uint32_t(o.mat.kind)), float(o.mat.shininess), float(o.mat.ior), 0.f};
-        mats.push_back(gm);
-        emit(o.shape, x, uint32_t(oi));
     }
-    if (tri.size() >= BVH_INDEX_MASK || btri.size() >= BVH_INDEX_MASK || nodes.size() >= (1u << 30))
-        return fail(RPT_ERR_UNSUPPORTED, "too many triangles");
-
-    for (const HLight& hl : s->lights) {
-        Light L{};
-        L.kind = uint32_t(hl.kind);
-        L.twin_object = -1;
-        L.color = F4{float(hl.color[0]), float(hl.color[1]), float(hl.color[2]), 0.f};
-        if (hl.kind == L_OBJECT) {
-            const HObject& o = hl.obj;
-            for (size_t j = 0; j < s->objects.size(); j++)
-                if (same_shape(o.shape, s->objects[j].shape)) { L.twin_object = int32_t(j); break; }
-            // material.color() * material.emittance() (src/light.rs:41, material.rs:100-113)
-            bool has = o.mat.kind == RPT_MAT_LAMBERTIAN || o.mat.kind == RPT_MAT_PHONG;
-            double e = has ? o.mat.emittance : 0.0;
-            L.color = F4{float(has ? o.mat.albedo[0] * e : 0.0), float(has ? o.mat.albedo[1] * e : 0.0),
-                         float(has ? o.mat.albedo[2] * e : 0.0), 0.f};
-            L.albedo = F4{float(has ? o.mat.albedo[0] : 0.0), float(has ? o.mat.albedo[1] : 0.0),
-                          float(has ? o.mat.albedo[2] : 0.0), 0.f};
-            // leaf shape -> LightXf (+ triangles); group -> parts tree (children contiguous, nested groups appended)
-            std::function<LightPart(const HShape&, const Xf&)> light_part = [&](const HShape& shp, const Xf& x) -> LightPart {
-                LightPart part{};
-                if (shp.d.kind == RPT_SHAPE_GROUP) {
-                    part.shape = LS_GROUP;
-                    part.first = uint32_t(lparts.size());
-                    part.count = uint32_t(shp.children.size());
-                    lparts.resize(lparts.size() + shp.children.size());
-                    for (size_t c = 0; c < shp.children.size(); c++) {
-                        Xf cx;
-                        compose_xf(x, shp.children[c].d, cx);
-                        const LightPart child = light_part(shp.children[c], cx);  // may grow lparts: index, not reference
-                        lparts[part.first + c] = child;
-                    }
-                    return part;
-                }
-                LightXf gx;
-                for (int r = 0; r < 3; r++) {
-                    gx.fwd[r] = F4{float(x.M[r][0]), float(x.M[r][1]), float(x.M[r][2]), float(x.M[r][3])};
-                    gx.inv[r] = F4{float(x.Minv[r][0]), float(x.Minv[r][1]), float(x.Minv[r][2]), float(x.Minv[r][3])};
-                    gx.nrm[r] = F4{float(x.N[r][0]), float(x.N[r][1]), float(x.N[r][2]), 0.f};
-                    gx.lin[r] = F4{float(x.L[r][0]), float(x.L[r][1]), float(x.L[r][2]), 0.f};
-                }
-                gx.nrm[0].w = float(x.det);
-                gx.nrm[1].w = x.has ? 1.f : 0.f;
-                part.xf = uint32_t(lxf.size());
-                lxf.push_back(gx);
-                if (shp.d.kind == RPT_SHAPE_MESH) {
-                    part.shape = LS_MESH;
-                    part.first = uint32_t(ltris.size());
-                    const uint64_t nt = shp.T().size() / 18;
-                    part.count = uint32_t(nt);
-                    for (uint64_t i = 0; i < nt; i++) {
-                        const double* t = &shp.T()[i * 18];
-                        D3 a = d3(t), b = d3(t + 3), c = d3(t + 6);
-                        D3 cr = cross(b - a, c - a);
-                        double area = 0.5 * std::sqrt(dot(cr, cr));  // local-space area (src/shape/mesh.rs:93)
-                        LightTri lt;
-                        lt.v1 = f4(x.point(a), 1.0 / area);
-                        lt.v2 = f4(x.point(b), 0);
-                        lt.v3 = f4(x.point(c), 0);
-                        lt.n1 = f4(d3(t + 9), 0);   // local normals; Transformed::sample maps them per sample
-                        lt.n2 = f4(d3(t + 12), 0);
-                        lt.n3 = f4(d3(t + 15), 0);
-                        ltris.push_back(lt);
-                    }
-                } else {
-                    part.shape = shp.d.kind == RPT_SHAPE_SPHERE ? LS_SPHERE : LS_CUBE;
-                }
-                return part;
-            };
+    // (1) the records of every object, and one two-box tree per large mesh
+    int flatten_objects() {
+        // meshes referenced by more than one shape (Arc<Mesh> in the reference) are instanced
+        std::function<void(const HShape&)> count_uses = [&](const HShape& shape) {
+            if (shape.d.kind == RPT_SHAPE_MESH && shape.T().size() / 18 > kLinearTriMax) mesh_uses[shape.mesh.get()]++;
+            for (const HShape& c : shape.children) count_uses(c);
+        };
+        for (const HObject& o : s->objects) count_uses(o.shape);
+        for (size_t oi = 0; oi < s->objects.size(); oi++) {
+            const HObject& o = s->objects[oi];
             Xf x;
             make_xf(o.shape.d, x);
-            const LightPart root = light_part(o.shape, x);
-            L.shape = root.shape;
-            L.first = root.first;
-            L.count = root.count;
-            L.xf = root.xf;
+            Material gm;
+            gm.albedo_emit = F4{float(o.mat.albedo[0]), float(o.mat.albedo[1]), float(o.mat.albedo[2]), float(o.mat.emittance)};
+            gm.params = F4{bits_f(uint32_t(o.mat.kind)), float(o.mat.shininess), float(o.mat.ior), 0.f};
+            mats.push_back(gm);
+            emit(o.shape, x, uint32_t(oi));
         }
-        lights.push_back(L);
-    }
+        if (tri.size() >= BVH_INDEX_MASK || btri.size() >= BVH_INDEX_MASK || nodes.size() >= (1u << 30))
+            return fail(RPT_ERR_UNSUPPORTED, "too many triangles");
 
-    // ---- one arena for every array
-    auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
-    size_t off = 0;
-    auto reserve = [&](size_t bytes) {
-        size_t o = off;
-        off += align(std::max<size_t>(bytes, 16));
-        return o;
-    };
-    size_t o_sph = reserve(sph.size() * sizeof(XfScan)), o_sphs = reserve(sph_sh.size() * sizeof(XfShade));
-    size_t o_cub = reserve(cub.size() * sizeof(XfScan)), o_cubs = reserve(cub_sh.size() * sizeof(XfShade));
-    size_t o_pln = reserve(pln.size() * sizeof(PlaneScan)), o_plns = reserve(pln_sh.size() * sizeof(PlaneShade));
-    size_t o_tri = reserve(tri.size() * sizeof(TriScan)), o_tris = reserve(tri_sh.size() * sizeof(TriShade));
-    // ---- box shell: rectangles that are exactly the faces of the box around all rectangles (the walls of a
-    // room) leave the scanned list and are answered by one slab test; linear-scan scenes only
-    const size_t n_items_total = sph.size() + cub.size() + aabb.size() + tri.size() + insts.size() + meshes.size() +
-                                 rect_axis[0].size() + rect_axis[1].size() + rect_axis[2].size();
-    const bool will_bvh = n_items_total >= size_t(std::max<int64_t>(2, g_opt_scene_bvh_min)) || !insts.empty();
-    ShellScan shell{};
-    bool has_shell = false;
-    std::vector<RectShade> shell_sh;              // shade records of the folded rectangles, in face order
-    {
-        const float inf = std::numeric_limits<float>::infinity();
-        float blo[3] = {inf, inf, inf}, bhi[3] = {-inf, -inf, -inf};
-        for (int a = 0; a < 3; a++)
-            for (const RectScan& r : rect_axis[a]) {
-                const float lo[3] = {r.a.x, r.a.y, r.a.w}, hi[3] = {r.a.x, r.a.z, r.b.x};  // axis, u, v
-                for (int k = 0; k < 3; k++) {
-                    blo[(a + k) % 3] = std::min(blo[(a + k) % 3], lo[k]);
-                    bhi[(a + k) % 3] = std::max(bhi[(a + k) % 3], hi[k]);
-                }
+        return RPT_OK;
+    }
+    // (2) the light list in scene order (it fixes the RNG draw order) and the samplers' data
+    void flatten_lights() {
+        for (const HLight& hl : s->lights) {
+            Light L{};
+            L.kind = uint32_t(hl.kind);
+            L.twin_object = -1;
+            L.color = F4{float(hl.color[0]), float(hl.color[1]), float(hl.color[2]), 0.f};
+            if (hl.kind == L_OBJECT) {
+                const HObject& o = hl.obj;
+                for (size_t j = 0; j < s->objects.size(); j++)
+                    if (same_shape(o.shape, s->objects[j].shape)) { L.twin_object = int32_t(j); break; }
+                // material.color() * material.emittance() (src/light.rs:41, material.rs:100-113)
+                bool has = o.mat.kind == RPT_MAT_LAMBERTIAN || o.mat.kind == RPT_MAT_PHONG;
+                double e = has ? o.mat.emittance : 0.0;
+                L.color = F4{float(has ? o.mat.albedo[0] * e : 0.0), float(has ? o.mat.albedo[1] * e : 0.0),
+                             float(has ? o.mat.albedo[2] * e : 0.0), 0.f};
+                L.albedo = F4{float(has ? o.mat.albedo[0] : 0.0), float(has ? o.mat.albedo[1] : 0.0),
+                              float(has ? o.mat.albedo[2] : 0.0), 0.f};
+                // leaf shape -> LightXf (+ triangles); group -> parts tree (children contiguous, nested groups appended)
+                std::function<LightPart(const HShape&, const Xf&)> light_part = [&](const HShape& shp, const Xf& x) -> LightPart {
+                    LightPart part{};
+                    if (shp.d.kind == RPT_SHAPE_GROUP) {
+                        part.shape = LS_GROUP;
+                        part.first = uint32_t(lparts.size());
+                        part.count = uint32_t(shp.children.size());
+                        lparts.resize(lparts.size() + shp.children.size());
+                        for (size_t c = 0; c < shp.children.size(); c++) {
+                            Xf cx;
+                            compose_xf(x, shp.children[c].d, cx);
+                            const LightPart child = light_part(shp.children[c], cx);  // may grow lparts: index, not reference
+                            lparts[part.first + c] = child;
+                        }
+                        return part;
+                    }
+                    LightXf gx;
+                    for (int r = 0; r < 3; r++) {
+                        gx.fwd[r] = F4{float(x.M[r][0]), float(x.M[r][1]), float(x.M[r][2]), float(x.M[r][3])};
+                        gx.inv[r] = F4{float(x.Minv[r][0]), float(x.Minv[r][1]), float(x.Minv[r][2]), float(x.Minv[r][3])};
+                        gx.nrm[r] = F4{float(x.N[r][0]), float(x.N[r][1]), float(x.N[r][2]), 0.f};
+                        gx.lin[r] = F4{float(x.L[r][0]), float(x.L[r][1]), float(x.L[r][2]), 0.f};
+                    }
+                    gx.nrm[0].w = float(x.det);
+                    gx.nrm[1].w = x.has ? 1.f : 0.f;
+                    part.xf = uint32_t(lxf.size());
+                    lxf.push_back(gx);
+                    if (shp.d.kind == RPT_SHAPE_MESH) {
+                        part.shape = LS_MESH;
+                        part.first = uint32_t(ltris.size());
+                        const uint64_t nt = shp.T().size() / 18;
+                        part.count = uint32_t(nt);
+                        for (uint64_t i = 0; i < nt; i++) {
+                            const double* t = &shp.T()[i * 18];
+                            D3 a = d3(t), b = d3(t + 3), c = d3(t + 6);
+                            D3 cr = cross(b - a, c - a);
+                            double area = 0.5 * std::sqrt(dot(cr, cr));  // local-space area (src/shape/mesh.rs:93)
+                            LightTri lt;
+                            lt.v1 = f4(x.point(a), 1.0 / area);
+                            lt.v2 = f4(x.point(b), 0);
+                            lt.v3 = f4(x.point(c), 0);
+                            lt.n1 = f4(d3(t + 9), 0);   // local normals; Transformed::sample maps them per sample
+                            lt.n2 = f4(d3(t + 12), 0);
+                            lt.n3 = f4(d3(t + 15), 0);
+                            ltris.push_back(lt);
+                        }
+                    } else {
+                        part.shape = shp.d.kind == RPT_SHAPE_SPHERE ? LS_SPHERE : LS_CUBE;
+                    }
+                    return part;
+                };
+                Xf x;
+                make_xf(o.shape.d, x);
+                const LightPart root = light_part(o.shape, x);
+                L.shape = root.shape;
+                L.first = root.first;
+                L.count = root.count;
+                L.xf = root.xf;
             }
-        int face_of[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}}, n_faces = 0;  // index into rect_axis[a]
-        if (!will_bvh && g_opt_room_shell)
+            lights.push_back(L);
+        }
+
+    }
+    // (3) flatten-time specialisation of the wall rectangles, then the final rectangle arrays
+    void fold_shell() {
+        // ---- box shell: rectangles that are exactly the faces of the box around all rectangles (the walls of a
+        // room) leave the scanned list and are answered by one slab test; linear-scan scenes only
+        const size_t n_items_total = sph.size() + cub.size() + aabb.size() + tri.size() + insts.size() + meshes.size() +
+                                     rect_axis[0].size() + rect_axis[1].size() + rect_axis[2].size();
+        const bool will_bvh = n_items_total >= size_t(std::max<int64_t>(2, s->opt.scene_bvh_min)) || !insts.empty();
+        {
+            const float inf = std::numeric_limits<float>::infinity();
+            float blo[3] = {inf, inf, inf}, bhi[3] = {-inf, -inf, -inf};
             for (int a = 0; a < 3; a++)
-                for (size_t i = 0; i < rect_axis[a].size(); i++) {
-                    const RectScan& r = rect_axis[a][i];
-                    const int u = (a + 1) % 3, w = (a + 2) % 3;
-                    if (r.a.y != blo[u] || r.a.z != bhi[u] || r.a.w != blo[w] || r.b.x != bhi[w]) continue;
+                for (const RectScan& r : rect_axis[a]) {
+                    const float lo[3] = {r.a.x, r.a.y, r.a.w}, hi[3] = {r.a.x, r.a.z, r.b.x};  // axis, u, v
+                    for (int k = 0; k < 3; k++) {
+                        blo[(a + k) % 3] = std::min(blo[(a + k) % 3], lo[k]);
+                        bhi[(a + k) % 3] = std::max(bhi[(a + k) % 3], hi[k]);
+                    }
+                }
+            int face_of[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}}, n_faces = 0;  // index into rect_axis[a]
+            if (!will_bvh && s->opt.room_shell)
+                for (int a = 0; a < 3; a++)
+                    for (size_t i = 0; i < rect_axis[a].size(); i++) {
+                        const RectScan& r = rect_axis[a][i];
+                        const int u = (a + 1) % 3, w = (a + 2) % 3;
+                        if (r.a.y != blo[u] || r.a.z != bhi[u] || r.a.w != blo[w] || r.b.x != bhi[w]) continue;
+                        for (int side = 0; side < 2; side++)
+                            if (r.a.x == (side ? bhi[a] : blo[a]) && face_of[a][side] < 0 && blo[a] < bhi[a]) {
+                                face_of[a][side] = int(i);
+                                n_faces++;
+                                break;
+                            }
+                    }
+            if (n_faces >= 3) {
+                has_shell = true;
+                shell.lo = F4{blo[0], blo[1], blo[2], 0.f};
+                shell.hi = F4{bhi[0], bhi[1], bhi[2], 0.f};
+                for (int k = 0; k < 8; k++) shell.face[k] = CODE_MISS;
+                size_t n_scanned = 0;
+                for (int a = 0; a < 3; a++) n_scanned += rect_axis[a].size();
+                n_scanned -= size_t(n_faces);
+                for (int a = 0; a < 3; a++) {  // take the members out (higher index first, so indices stay valid)
+                    int order[2] = {0, 1};
+                    if (face_of[a][0] >= 0 && face_of[a][1] >= 0 && face_of[a][0] < face_of[a][1]) { order[0] = 1; order[1] = 0; }
+                    RectShade keep[2];
+                    for (int k = 0; k < 2; k++) {
+                        const int side = order[k];
+                        if (face_of[a][side] < 0) continue;
+                        keep[side] = rect_sh_axis[a][size_t(face_of[a][side])];
+                        rect_axis[a].erase(rect_axis[a].begin() + face_of[a][side]);
+                        rect_sh_axis[a].erase(rect_sh_axis[a].begin() + face_of[a][side]);
+                    }
                     for (int side = 0; side < 2; side++)
-                        if (r.a.x == (side ? bhi[a] : blo[a]) && face_of[a][side] < 0 && blo[a] < bhi[a]) {
-                            face_of[a][side] = int(i);
-                            n_faces++;
-                            break;
+                        if (face_of[a][side] >= 0) {
+                            shell.face[2 * a + side] = (K_RECT << 28) | uint32_t(n_scanned + shell_sh.size());
+                            shell_sh.push_back(keep[side]);
                         }
                 }
-        if (n_faces >= 3) {
-            has_shell = true;
-            shell.lo = F4{blo[0], blo[1], blo[2], 0.f};
-            shell.hi = F4{bhi[0], bhi[1], bhi[2], 0.f};
-            for (int k = 0; k < 8; k++) shell.face[k] = CODE_MISS;
-            size_t n_scanned = 0;
-            for (int a = 0; a < 3; a++) n_scanned += rect_axis[a].size();
-            n_scanned -= size_t(n_faces);
-            for (int a = 0; a < 3; a++) {  // take the members out (higher index first, so indices stay valid)
-                int order[2] = {0, 1};
-                if (face_of[a][0] >= 0 && face_of[a][1] >= 0 && face_of[a][0] < face_of[a][1]) { order[0] = 1; order[1] = 0; }
-                RectShade keep[2];
-                for (int k = 0; k < 2; k++) {
-                    const int side = order[k];
-                    if (face_of[a][side] < 0) continue;
-                    keep[side] = rect_sh_axis[a][size_t(face_of[a][side])];
-                    rect_axis[a].erase(rect_axis[a].begin() + face_of[a][side]);
-                    rect_sh_axis[a].erase(rect_sh_axis[a].begin() + face_of[a][side]);
-                }
-                for (int side = 0; side < 2; side++)
-                    if (face_of[a][side] >= 0) {
-                        shell.face[2 * a + side] = (K_RECT << 28) | uint32_t(n_scanned + shell_sh.size());
-                        shell_sh.push_back(keep[side]);
-                    }
             }
         }
-    }
-    std::vector<RectScan> rect;
-    std::vector<RectShade> rect_sh;
-    for (int a = 0; a < 3; a++) {
-        rect.insert(rect.end(), rect_axis[a].begin(), rect_axis[a].end());
-        rect_sh.insert(rect_sh.end(), rect_sh_axis[a].begin(), rect_sh_axis[a].end());
-    }
-    rect_sh.insert(rect_sh.end(), shell_sh.begin(), shell_sh.end());  // hit codes of shell faces point here
-    // ---- shadow test shortcut: when the primitives of a light's twin object form one contiguous range of
-    // hit codes, "the closest hit belongs to the twin" is a range compare instead of a shade-record load
-    for (Light& L : lights) {
-        L.twin_lo = 1u;
-        L.twin_hi = 0u;
-        if (L.kind != L_OBJECT || L.twin_object < 0) continue;
-        const uint32_t tw = uint32_t(L.twin_object);
-        std::vector<uint32_t> codes;
-        bool other = false;  // pieces a range cannot describe
-        auto same = [&](float w) { return bits_u(w) == tw; };
-        for (size_t i = 0; i < sph_sh.size(); i++) if (same(sph_sh[i].r0.w)) codes.push_back((K_SPHERE << 28) | uint32_t(i));
-        for (size_t i = 0; i < cub_sh.size(); i++) if (same(cub_sh[i].r0.w)) codes.push_back((K_CUBE << 28) | uint32_t(i));
-        for (size_t i = 0; i < pln_sh.size(); i++) if (same(pln_sh[i].unit_n_obj.w)) codes.push_back((K_PLANE << 28) | uint32_t(i));
-        for (size_t i = 0; i < tri_sh.size(); i++) if (same(tri_sh[i].n1.w)) codes.push_back((K_TRI << 28) | uint32_t(i));
-        for (size_t i = 0; i < aabb.size(); i++) if (same(aabb[i].lo.w)) codes.push_back((K_AABB << 28) | uint32_t(i));
-        for (size_t i = 0; i < rect_sh.size(); i++) if (same(rect_sh[i].n_obj.w)) codes.push_back((K_RECT << 28) | uint32_t(i));
-        for (const MeshRef& m : meshes) if (m.object == tw) other = true;
-        for (const InstRec& r : insts) if (same(r.n0.w)) other = true;
-        if (other || codes.empty()) continue;
-        bool contiguous = true;
-        for (size_t i = 1; i < codes.size(); i++) contiguous = contiguous && codes[i] == codes[i - 1] + 1u;
-        if (contiguous) { L.twin_lo = codes.front(); L.twin_hi = codes.back(); }
-    }
-
-    // ---- scene-level BVH over bounded primitives and mesh roots (many-primitive scenes only)
-    std::vector<uint32_t> pleaf;
-    uint32_t top_root = 0;
-    bool scene_bvh = false;
-    {
-        std::vector<BTri> items;
-        std::vector<uint32_t> codes;   // by item: primitive code, or K_BVHTRI << 28 | mesh index for a mesh root
-        auto add_item = [&](const float lo[3], const float hi[3], uint32_t code) {
-            BTri it;
-            for (int a = 0; a < 3; a++) { it.lo[a] = lo[a]; it.hi[a] = hi[a]; it.c[a] = 0.5f * (lo[a] + hi[a]); }
-            it.idx = uint32_t(codes.size());
-            items.push_back(it);
-            codes.push_back(code);
-        };
-        for (size_t i = 0; i < sph.size(); i++) add_item(box_sph[i].lo, box_sph[i].hi, (K_SPHERE << 28) | uint32_t(i));
-        for (size_t i = 0; i < cub.size(); i++) add_item(box_cub[i].lo, box_cub[i].hi, (K_CUBE << 28) | uint32_t(i));
-        for (size_t i = 0; i < aabb.size(); i++) {
-            float lo[3] = {aabb[i].lo.x, aabb[i].lo.y, aabb[i].lo.z}, hi[3] = {aabb[i].hi.x, aabb[i].hi.y, aabb[i].hi.z};
-            add_item(lo, hi, (K_AABB << 28) | uint32_t(i));
+        for (int a = 0; a < 3; a++) {
+            rect.insert(rect.end(), rect_axis[a].begin(), rect_axis[a].end());
+            rect_sh.insert(rect_sh.end(), rect_sh_axis[a].begin(), rect_sh_axis[a].end());
         }
+        rect_sh.insert(rect_sh.end(), shell_sh.begin(), shell_sh.end());  // hit codes of shell faces point here
+    }
+    // (4) hit-code ranges of the lights' twin objects
+    void mark_twin_ranges() {
+        // ---- shadow test shortcut: when the primitives of a light's twin object form one contiguous range of
+        // hit codes, "the closest hit belongs to the twin" is a range compare instead of a shade-record load
+        for (Light& L : lights) {
+            L.twin_lo = 1u;
+            L.twin_hi = 0u;
+            if (L.kind != L_OBJECT || L.twin_object < 0) continue;
+            const uint32_t tw = uint32_t(L.twin_object);
+            std::vector<uint32_t> codes;
+            bool other = false;  // pieces a range cannot describe
+            auto same = [&](float w) { return bits_u(w) == tw; };
+            for (size_t i = 0; i < sph_sh.size(); i++) if (same(sph_sh[i].r0.w)) codes.push_back((K_SPHERE << 28) | uint32_t(i));
+            for (size_t i = 0; i < cub_sh.size(); i++) if (same(cub_sh[i].r0.w)) codes.push_back((K_CUBE << 28) | uint32_t(i));
+            for (size_t i = 0; i < pln_sh.size(); i++) if (same(pln_sh[i].unit_n_obj.w)) codes.push_back((K_PLANE << 28) | uint32_t(i));
+            for (size_t i = 0; i < tri_sh.size(); i++) if (same(tri_sh[i].n1.w)) codes.push_back((K_TRI << 28) | uint32_t(i));
+            for (size_t i = 0; i < aabb.size(); i++) if (same(aabb[i].lo.w)) codes.push_back((K_AABB << 28) | uint32_t(i));
+            for (size_t i = 0; i < rect_sh.size(); i++) if (same(rect_sh[i].n_obj.w)) codes.push_back((K_RECT << 28) | uint32_t(i));
+            for (const MeshRef& m : meshes) if (m.object == tw) other = true;
+            for (const InstRec& r : insts) if (same(r.n0.w)) other = true;
+            if (other || codes.empty()) continue;
+            bool contiguous = true;
+            for (size_t i = 1; i < codes.size(); i++) contiguous = contiguous && codes[i] == codes[i - 1] + 1u;
+            if (contiguous) { L.twin_lo = codes.front(); L.twin_hi = codes.back(); }
+        }
+
+    }
+    // (5) the scene-level tree (many-primitive scenes only)
+    int build_scene_tree() {
+        // ---- scene-level BVH over bounded primitives and mesh roots (many-primitive scenes only)
         {
+            std::vector<BTri> items;
+            std::vector<uint32_t> codes;   // by item: primitive code, or K_BVHTRI << 28 | mesh index for a mesh root
+            auto add_item = [&](const float lo[3], const float hi[3], uint32_t code) {
+                BTri it;
+                for (int a = 0; a < 3; a++) { it.lo[a] = lo[a]; it.hi[a] = hi[a]; it.c[a] = 0.5f * (lo[a] + hi[a]); }
+                it.idx = uint32_t(codes.size());
+                items.push_back(it);
+                codes.push_back(code);
+            };
+            for (size_t i = 0; i < sph.size(); i++) add_item(box_sph[i].lo, box_sph[i].hi, (K_SPHERE << 28) | uint32_t(i));
+            for (size_t i = 0; i < cub.size(); i++) add_item(box_cub[i].lo, box_cub[i].hi, (K_CUBE << 28) | uint32_t(i));
+            for (size_t i = 0; i < aabb.size(); i++) {
+                float lo[3] = {aabb[i].lo.x, aabb[i].lo.y, aabb[i].lo.z}, hi[3] = {aabb[i].hi.x, aabb[i].hi.y, aabb[i].hi.z};
+                add_item(lo, hi, (K_AABB << 28) | uint32_t(i));
+            }
+            {
+                size_t i = 0;
+                for (int axis = 0; axis < 3; axis++)
+                    for (size_t k = 0; k < rect_axis[axis].size(); k++, i++) {
+                        const RectScan& r = rect[i];
+                        float lo[3], hi[3];
+                        lo[axis] = hi[axis] = r.a.x;
+                        lo[(axis + 1) % 3] = r.a.y; hi[(axis + 1) % 3] = r.a.z;
+                        lo[(axis + 2) % 3] = r.a.w; hi[(axis + 2) % 3] = r.b.x;
+                        add_item(lo, hi, (K_RECT << 28) | uint32_t(i));
+                    }
+            }
+            for (size_t i = 0; i < tri.size(); i++) add_item(box_tri[i].lo, box_tri[i].hi, (K_TRI << 28) | uint32_t(i));
+            for (size_t i = 0; i < insts.size(); i++) add_item(box_inst[i].lo, box_inst[i].hi, (K_INST << 28) | uint32_t(i));
+            std::vector<uint8_t> solo(items.size(), 0);
+            for (size_t i = 0; i < meshes.size(); i++) {
+                add_item(box_mesh[i].lo, box_mesh[i].hi, (K_BVHTRI << 28) | uint32_t(i));
+                solo.push_back(1);
+            }
+            if (items.size() >= size_t(std::max<int64_t>(2, s->opt.scene_bvh_min)) || !insts.empty()) {  // instances live in the tree only
+                scene_bvh = true;
+                std::vector<TmpNode> tmp;
+                tmp.reserve(2 * items.size());
+                // a mesh tree hangs below a leaf of this one (spliced in, or walked as an instance on the same stack)
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    tmp.assign(1, TmpNode{});
+                    BvhBuilder b{items, tmp};
+                    b.leaf_max = 2;
+                    b.solo = &solo;
+                    b.balanced = attempt == 1;
+                    b.build(0, 0, uint32_t(items.size()), 0);
+                    top_depth = b.max_depth + 1;
+                    if (top_depth + mesh_depth <= 31) break;
+                }
+                if (top_depth + mesh_depth > 31)
+                    return fail(RPT_ERR_UNSUPPORTED, "scene tree + mesh tree are deeper than the traversal stack (32 levels)");
+                std::vector<uint32_t> remap(tmp.size(), 0);
+                uint32_t n_inner = 0;
+                for (size_t k = 0; k < tmp.size(); k++)
+                    if (tmp[k].count == 0) remap[k] = n_inner++;
+                top_root = uint32_t(nodes.size());
+                std::vector<BvhNode> local(n_inner);
+                auto entry = [&](uint32_t k) -> uint32_t {
+                    const TmpNode& c = tmp[k];
+                    if (c.count == 0) return top_root + remap[k];
+                    const uint32_t c0 = codes[items[c.left_or_first].idx];
+                    if ((c0 >> 28) == K_BVHTRI) return meshes[c0 & 0x0FFFFFFFu].root;  // always alone in its leaf
+                    const uint32_t first = uint32_t(pleaf.size());
+                    for (uint32_t i = 0; i < c.count; i++) pleaf.push_back(codes[items[c.left_or_first + i].idx]);
+                    return BVH_LEAF | BVH_PRIMS | ((c.count - 1u) << 26) | first;
+                };
+                for (size_t k = 0; k < tmp.size(); k++) {
+                    if (tmp[k].count != 0) continue;
+                    BvhNode& w = local[remap[k]];
+                    uint32_t l = tmp[k].left_or_first;
+                    for (int a = 0; a < 3; a++) {
+                        w.lo0[a] = tmp[l].lo[a]; w.hi0[a] = tmp[l].hi[a];
+                        w.lo1[a] = tmp[l + 1].lo[a]; w.hi1[a] = tmp[l + 1].hi[a];
+                    }
+                    w.e0 = entry(l);
+                    w.e1 = entry(l + 1);
+                    w.pad0 = w.pad1 = 0;
+                }
+                nodes.insert(nodes.end(), local.begin(), local.end());
+                if (pleaf.size() >= BVH_INDEX_MASK) return fail(RPT_ERR_UNSUPPORTED, "too many primitives");
+            }
+        }
+        return RPT_OK;
+    }
+    // (6) boxes of the scanned records, for ball-limited queries
+    void collect_scan_boxes() {
+        // world boxes of the scanned bounded records, in scan order (SceneView::pbox)
+        {
+            auto push_box = [&](const float lo[3], const float hi[3]) {
+                AabbScan b;
+                float l[3], h[3];
+                for (int a = 0; a < 3; a++) {
+                    const float pad = 1e-5f * (std::fabs(lo[a]) + std::fabs(hi[a]) + (hi[a] - lo[a])) + 1e-7f;
+                    l[a] = lo[a] - pad;
+                    h[a] = hi[a] + pad;
+                }
+                b.lo = F4{l[0], l[1], l[2], 0.f};
+                b.hi = F4{h[0], h[1], h[2], 0.f};
+                pbox.push_back(b);
+            };
+            for (const PBox& b : box_sph) push_box(b.lo, b.hi);
+            for (const PBox& b : box_cub) push_box(b.lo, b.hi);
+            for (const AabbScan& b : aabb) { const float lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z}; push_box(lo, hi); }
             size_t i = 0;
             for (int axis = 0; axis < 3; axis++)
-                for (size_t k = 0; k < rect_axis[axis].size(); k++, i++) {
+                for (size_t k = 0; k < rect_axis[axis].size(); k++, i++) {   // the scanned rectangles (shell faces are gone)
                     const RectScan& r = rect[i];
                     float lo[3], hi[3];
                     lo[axis] = hi[axis] = r.a.x;
                     lo[(axis + 1) % 3] = r.a.y; hi[(axis + 1) % 3] = r.a.z;
                     lo[(axis + 2) % 3] = r.a.w; hi[(axis + 2) % 3] = r.b.x;
-                    add_item(lo, hi, (K_RECT << 28) | uint32_t(i));
+                    push_box(lo, hi);
                 }
-        }
-        for (size_t i = 0; i < tri.size(); i++) add_item(box_tri[i].lo, box_tri[i].hi, (K_TRI << 28) | uint32_t(i));
-        for (size_t i = 0; i < insts.size(); i++) add_item(box_inst[i].lo, box_inst[i].hi, (K_INST << 28) | uint32_t(i));
-        std::vector<uint8_t> solo(items.size(), 0);
-        for (size_t i = 0; i < meshes.size(); i++) {
-            add_item(box_mesh[i].lo, box_mesh[i].hi, (K_BVHTRI << 28) | uint32_t(i));
-            solo.push_back(1);
-        }
-        if (items.size() >= size_t(std::max<int64_t>(2, g_opt_scene_bvh_min)) || !insts.empty()) {  // instances live in the tree only
-            scene_bvh = true;
-            std::vector<TmpNode> tmp;
-            tmp.reserve(2 * items.size());
-            // a mesh tree hangs below a leaf of this one (spliced in, or walked as an instance on the same stack)
-            for (int attempt = 0; attempt < 2; attempt++) {
-                tmp.assign(1, TmpNode{});
-                BvhBuilder b{items, tmp};
-                b.leaf_max = 2;
-                b.solo = &solo;
-                b.balanced = attempt == 1;
-                b.build(0, 0, uint32_t(items.size()), 0);
-                top_depth = b.max_depth + 1;
-                if (top_depth + mesh_depth <= 31) break;
-            }
-            if (top_depth + mesh_depth > 31)
-                return fail(RPT_ERR_UNSUPPORTED, "scene tree + mesh tree are deeper than the traversal stack (32 levels)");
-            std::vector<uint32_t> remap(tmp.size(), 0);
-            uint32_t n_inner = 0;
-            for (size_t k = 0; k < tmp.size(); k++)
-                if (tmp[k].count == 0) remap[k] = n_inner++;
-            top_root = uint32_t(nodes.size());
-            std::vector<BvhNode> local(n_inner);
-            auto entry = [&](uint32_t k) -> uint32_t {
-                const TmpNode& c = tmp[k];
-                if (c.count == 0) return top_root + remap[k];
-                const uint32_t c0 = codes[items[c.left_or_first].idx];
-                if ((c0 >> 28) == K_BVHTRI) return meshes[c0 & 0x0FFFFFFFu].root;  // always alone in its leaf
-                const uint32_t first = uint32_t(pleaf.size());
-                for (uint32_t i = 0; i < c.count; i++) pleaf.push_back(codes[items[c.left_or_first + i].idx]);
-                return BVH_LEAF | BVH_PRIMS | ((c.count - 1u) << 26) | first;
-            };
-            for (size_t k = 0; k < tmp.size(); k++) {
-                if (tmp[k].count != 0) continue;
-                BvhNode& w = local[remap[k]];
-                uint32_t l = tmp[k].left_or_first;
-                for (int a = 0; a < 3; a++) {
-                    w.lo0[a] = tmp[l].lo[a]; w.hi0[a] = tmp[l].hi[a];
-                    w.lo1[a] = tmp[l + 1].lo[a]; w.hi1[a] = tmp[l + 1].hi[a];
-                }
-                w.e0 = entry(l);
-                w.e1 = entry(l + 1);
-                w.pad0 = w.pad1 = 0;
-            }
-            nodes.insert(nodes.end(), local.begin(), local.end());
-            if (pleaf.size() >= BVH_INDEX_MASK) return fail(RPT_ERR_UNSUPPORTED, "too many primitives");
+            for (const PBox& b : box_tri) push_box(b.lo, b.hi);
         }
     }
-    // world boxes of the scanned bounded records, in scan order (SceneView::pbox)
-    std::vector<AabbScan> pbox;
-    {
-        auto push_box = [&](const float lo[3], const float hi[3]) {
-            AabbScan b;
-            float l[3], h[3];
-            for (int a = 0; a < 3; a++) {
-                const float pad = 1e-5f * (std::fabs(lo[a]) + std::fabs(hi[a]) + (hi[a] - lo[a])) + 1e-7f;
-                l[a] = lo[a] - pad;
-                h[a] = hi[a] + pad;
-            }
-            b.lo = F4{l[0], l[1], l[2], 0.f};
-            b.hi = F4{h[0], h[1], h[2], 0.f};
-            pbox.push_back(b);
+    // (7) one arena for every array, the SceneView over it, statistics, per-launch scratch
+    int upload(int device) {
+        // ---- one arena for every array
+        auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
+        size_t off = 0;
+        auto reserve = [&](size_t bytes) {
+            size_t o = off;
+            off += align(std::max<size_t>(bytes, 16));
+            return o;
         };
-        for (const PBox& b : box_sph) push_box(b.lo, b.hi);
-        for (const PBox& b : box_cub) push_box(b.lo, b.hi);
-        for (const AabbScan& b : aabb) { const float lo[3] = {b.lo.x, b.lo.y, b.lo.z}, hi[3] = {b.hi.x, b.hi.y, b.hi.z}; push_box(lo, hi); }
-        size_t i = 0;
-        for (int axis = 0; axis < 3; axis++)
-            for (size_t k = 0; k < rect_axis[axis].size(); k++, i++) {   // the scanned rectangles (shell faces are gone)
-                const RectScan& r = rect[i];
-                float lo[3], hi[3];
-                lo[axis] = hi[axis] = r.a.x;
-                lo[(axis + 1) % 3] = r.a.y; hi[(axis + 1) % 3] = r.a.z;
-                lo[(axis + 2) % 3] = r.a.w; hi[(axis + 2) % 3] = r.b.x;
-                push_box(lo, hi);
+        size_t o_sph = reserve(sph.size() * sizeof(XfScan)), o_sphs = reserve(sph_sh.size() * sizeof(XfShade));
+        size_t o_cub = reserve(cub.size() * sizeof(XfScan)), o_cubs = reserve(cub_sh.size() * sizeof(XfShade));
+        size_t o_pln = reserve(pln.size() * sizeof(PlaneScan)), o_plns = reserve(pln_sh.size() * sizeof(PlaneShade));
+        size_t o_tri = reserve(tri.size() * sizeof(TriScan)), o_tris = reserve(tri_sh.size() * sizeof(TriShade));
+        size_t o_pbox = reserve(pbox.size() * sizeof(AabbScan));
+        size_t o_pleaf = reserve(pleaf.size() * sizeof(uint32_t));
+        size_t o_shell = reserve(sizeof(ShellScan));
+        size_t o_inst = reserve(insts.size() * sizeof(InstRec));
+        size_t o_aabb = reserve(aabb.size() * sizeof(AabbScan));
+        size_t o_rect = reserve(rect.size() * sizeof(RectScan)), o_rects = reserve(rect_sh.size() * sizeof(RectShade));
+        size_t o_nodes = reserve(nodes.size() * sizeof(BvhNode));
+        size_t o_btri = reserve(btri.size() * sizeof(TriScan)), o_btris = reserve(btri_sh.size() * sizeof(TriShade));
+        size_t o_mesh = reserve(meshes.size() * sizeof(MeshRef));
+        size_t o_mats = reserve(mats.size() * sizeof(Material));
+        size_t o_lights = reserve(lights.size() * sizeof(Light));
+        size_t o_ltris = reserve(ltris.size() * sizeof(LightTri));
+        size_t o_lxf = reserve(lxf.size() * sizeof(LightXf));
+        size_t o_lparts = reserve(lparts.size() * sizeof(LightPart));
+        size_t o_hdri = reserve(s->hdri.size() * sizeof(float));
+        std::vector<char> host(off, 0);
+        auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
+        put(o_sph, sph.data(), sph.size() * sizeof(XfScan));       put(o_sphs, sph_sh.data(), sph_sh.size() * sizeof(XfShade));
+        put(o_cub, cub.data(), cub.size() * sizeof(XfScan));       put(o_cubs, cub_sh.data(), cub_sh.size() * sizeof(XfShade));
+        put(o_pln, pln.data(), pln.size() * sizeof(PlaneScan));    put(o_plns, pln_sh.data(), pln_sh.size() * sizeof(PlaneShade));
+        put(o_tri, tri.data(), tri.size() * sizeof(TriScan));      put(o_tris, tri_sh.data(), tri_sh.size() * sizeof(TriShade));
+        put(o_aabb, aabb.data(), aabb.size() * sizeof(AabbScan));
+        put(o_pbox, pbox.data(), pbox.size() * sizeof(AabbScan));
+        put(o_pleaf, pleaf.data(), pleaf.size() * sizeof(uint32_t));
+        put(o_shell, &shell, sizeof(ShellScan));
+        put(o_inst, insts.data(), insts.size() * sizeof(InstRec));
+        put(o_rect, rect.data(), rect.size() * sizeof(RectScan));  put(o_rects, rect_sh.data(), rect_sh.size() * sizeof(RectShade));
+        put(o_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
+        put(o_btri, btri.data(), btri.size() * sizeof(TriScan));   put(o_btris, btri_sh.data(), btri_sh.size() * sizeof(TriShade));
+        put(o_mesh, meshes.data(), meshes.size() * sizeof(MeshRef));
+        put(o_mats, mats.data(), mats.size() * sizeof(Material));
+        put(o_lights, lights.data(), lights.size() * sizeof(Light));
+        put(o_ltris, ltris.data(), ltris.size() * sizeof(LightTri));
+        put(o_lxf, lxf.data(), lxf.size() * sizeof(LightXf));
+        put(o_lparts, lparts.data(), lparts.size() * sizeof(LightPart));
+        put(o_hdri, s->hdri.data(), s->hdri.size() * sizeof(float));
+        HIP_TRY(hipMalloc(&s->arena, off));
+        HIP_TRY(hipMemcpy(s->arena, host.data(), off, hipMemcpyHostToDevice));
+        char* base = static_cast<char*>(s->arena);
+        SceneView& v = s->view;
+        v.sph = (const XfScan*)(base + o_sph);      v.sph_sh = (const XfShade*)(base + o_sphs);    v.n_sph = uint32_t(sph.size());
+        v.cub = (const XfScan*)(base + o_cub);      v.cub_sh = (const XfShade*)(base + o_cubs);    v.n_cub = uint32_t(cub.size());
+        v.pln = (const PlaneScan*)(base + o_pln);   v.pln_sh = (const PlaneShade*)(base + o_plns); v.n_pln = uint32_t(pln.size());
+        v.tri = (const TriScan*)(base + o_tri);     v.tri_sh = (const TriShade*)(base + o_tris);   v.n_tri = uint32_t(tri.size());
+        v.aabb = (const AabbScan*)(base + o_aabb);  v.n_aabb = uint32_t(aabb.size());
+        v.rect = (const RectScan*)(base + o_rect);  v.rect_sh = (const RectShade*)(base + o_rects);
+        v.n_rect_x = uint32_t(rect_axis[0].size()); v.n_rect_y = uint32_t(rect_axis[1].size()); v.n_rect_z = uint32_t(rect_axis[2].size());
+        v.shell = (const ShellScan*)(base + o_shell); v.has_shell = has_shell ? 1u : 0u;
+        v.pbox = (const AabbScan*)(base + o_pbox);
+        v.nodes = (const BvhNode*)(base + o_nodes); v.btri = (const TriScan*)(base + o_btri);      v.btri_sh = (const TriShade*)(base + o_btris);
+        v.meshes = (const MeshRef*)(base + o_mesh); v.n_mesh = uint32_t(meshes.size());
+        v.pleaf = (const uint32_t*)(base + o_pleaf); v.n_nodes = uint32_t(nodes.size());
+        v.scene_bvh = scene_bvh ? 1u : 0u;          v.top_root = top_root;
+        v.inst = (const InstRec*)(base + o_inst);   v.n_inst = uint32_t(insts.size());
+        v.mats = (const Material*)(base + o_mats);  v.n_obj = uint32_t(mats.size());
+        v.lights = (const Light*)(base + o_lights); v.n_lights = uint32_t(lights.size());
+        v.ltris = (const LightTri*)(base + o_ltris); v.lxf = (const LightXf*)(base + o_lxf);
+        v.lparts = (const LightPart*)(base + o_lparts); v.n_lparts = uint32_t(lparts.size());
+        v.has_medium = s->media.empty() ? 0u : 1u;
+        v.medium_kind = 0;
+        v.sigma_a = v.sigma_s = 0.f;
+        v.medium_emission = 0.f;
+        v.medium_phase = 0.f;
+        for (int i = 0; i < 3; i++) v.medium_color[i] = v.medium_color_hi[i] = 0.f;
+        if (!s->media.empty()) {  // only media[0] is used (src/renderer.rs:190)
+            const HMedium& m = s->media[0];
+            v.medium_kind = uint32_t(m.kind);
+            v.sigma_a = float(m.absorption);
+            v.sigma_s = float(m.scattering);
+            const double pi = 3.14159265358979323846;
+            if (m.kind == RPT_MEDIUM_HOMOGENEOUS_ISOTROPIC) {  // src/medium.rs:80-96
+                D3 c = hex_color(0xD2B48C);
+                v.medium_color[0] = v.medium_color_hi[0] = float(c.x);
+                v.medium_color[1] = v.medium_color_hi[1] = float(c.y);
+                v.medium_color[2] = v.medium_color_hi[2] = float(c.z);
+                v.medium_emission = 0.f;
+                v.medium_phase = float(1.0 / (4.0 * pi));
+            } else {  // colored_glowing_fog, src/medium.rs:99-122 (phase `1.0 / 4.0 * pi`, sic)
+                D3 lo = hex_color(0x0000FF), hi = hex_color(0xFF0000);
+                v.medium_color[0] = float(lo.x); v.medium_color[1] = float(lo.y); v.medium_color[2] = float(lo.z);
+                v.medium_color_hi[0] = float(hi.x); v.medium_color_hi[1] = float(hi.y); v.medium_color_hi[2] = float(hi.z);
+                v.medium_emission = 10.f;
+                v.medium_phase = float(1.0 / 4.0 * pi);
             }
-        for (const PBox& b : box_tri) push_box(b.lo, b.hi);
-    }
-    size_t o_pbox = reserve(pbox.size() * sizeof(AabbScan));
-    size_t o_pleaf = reserve(pleaf.size() * sizeof(uint32_t));
-    size_t o_shell = reserve(sizeof(ShellScan));
-    size_t o_inst = reserve(insts.size() * sizeof(InstRec));
-    size_t o_aabb = reserve(aabb.size() * sizeof(AabbScan));
-    size_t o_rect = reserve(rect.size() * sizeof(RectScan)), o_rects = reserve(rect_sh.size() * sizeof(RectShade));
-    size_t o_nodes = reserve(nodes.size() * sizeof(BvhNode));
-    size_t o_btri = reserve(btri.size() * sizeof(TriScan)), o_btris = reserve(btri_sh.size() * sizeof(TriShade));
-    size_t o_mesh = reserve(meshes.size() * sizeof(MeshRef));
-    size_t o_mats = reserve(mats.size() * sizeof(Material));
-    size_t o_lights = reserve(lights.size() * sizeof(Light));
-    size_t o_ltris = reserve(ltris.size() * sizeof(LightTri));
-    size_t o_lxf = reserve(lxf.size() * sizeof(LightXf));
-    size_t o_lparts = reserve(lparts.size() * sizeof(LightPart));
-    size_t o_hdri = reserve(s->hdri.size() * sizeof(float));
-    std::vector<char> host(off, 0);
-    auto put = [&](size_t o, const void* src, size_t bytes) { if (bytes) std::memcpy(host.data() + o, src, bytes); };
-    put(o_sph, sph.data(), sph.size() * sizeof(XfScan));       put(o_sphs, sph_sh.data(), sph_sh.size() * sizeof(XfShade));
-    put(o_cub, cub.data(), cub.size() * sizeof(XfScan));       put(o_cubs, cub_sh.data(), cub_sh.size() * sizeof(XfShade));
-    put(o_pln, pln.data(), pln.size() * sizeof(PlaneScan));    put(o_plns, pln_sh.data(), pln_sh.size() * sizeof(PlaneShade));
-    put(o_tri, tri.data(), tri.size() * sizeof(TriScan));      put(o_tris, tri_sh.data(), tri_sh.size() * sizeof(TriShade));
-    put(o_aabb, aabb.data(), aabb.size() * sizeof(AabbScan));
-    put(o_pbox, pbox.data(), pbox.size() * sizeof(AabbScan));
-    put(o_pleaf, pleaf.data(), pleaf.size() * sizeof(uint32_t));
-    put(o_shell, &shell, sizeof(ShellScan));
-    put(o_inst, insts.data(), insts.size() * sizeof(InstRec));
-    put(o_rect, rect.data(), rect.size() * sizeof(RectScan));  put(o_rects, rect_sh.data(), rect_sh.size() * sizeof(RectShade));
-    put(o_nodes, nodes.data(), nodes.size() * sizeof(BvhNode));
-    put(o_btri, btri.data(), btri.size() * sizeof(TriScan));   put(o_btris, btri_sh.data(), btri_sh.size() * sizeof(TriShade));
-    put(o_mesh, meshes.data(), meshes.size() * sizeof(MeshRef));
-    put(o_mats, mats.data(), mats.size() * sizeof(Material));
-    put(o_lights, lights.data(), lights.size() * sizeof(Light));
-    put(o_ltris, ltris.data(), ltris.size() * sizeof(LightTri));
-    put(o_lxf, lxf.data(), lxf.size() * sizeof(LightXf));
-    put(o_lparts, lparts.data(), lparts.size() * sizeof(LightPart));
-    put(o_hdri, s->hdri.data(), s->hdri.size() * sizeof(float));
-    HIP_TRY(hipMalloc(&s->arena, off));
-    HIP_TRY(hipMemcpy(s->arena, host.data(), off, hipMemcpyHostToDevice));
-    char* base = static_cast<char*>(s->arena);
-    SceneView& v = s->view;
-    v.sph = (const XfScan*)(base + o_sph);      v.sph_sh = (const XfShade*)(base + o_sphs);    v.n_sph = uint32_t(sph.size());
-    v.cub = (const XfScan*)(base + o_cub);      v.cub_sh = (const XfShade*)(base + o_cubs);    v.n_cub = uint32_t(cub.size());
-    v.pln = (const PlaneScan*)(base + o_pln);   v.pln_sh = (const PlaneShade*)(base + o_plns); v.n_pln = uint32_t(pln.size());
-    v.tri = (const TriScan*)(base + o_tri);     v.tri_sh = (const TriShade*)(base + o_tris);   v.n_tri = uint32_t(tri.size());
-    v.aabb = (const AabbScan*)(base + o_aabb);  v.n_aabb = uint32_t(aabb.size());
-    v.rect = (const RectScan*)(base + o_rect);  v.rect_sh = (const RectShade*)(base + o_rects);
-    v.n_rect_x = uint32_t(rect_axis[0].size()); v.n_rect_y = uint32_t(rect_axis[1].size()); v.n_rect_z = uint32_t(rect_axis[2].size());
-    v.shell = (const ShellScan*)(base + o_shell); v.has_shell = has_shell ? 1u : 0u;
-    v.pbox = (const AabbScan*)(base + o_pbox);
-    v.nodes = (const BvhNode*)(base + o_nodes); v.btri = (const TriScan*)(base + o_btri);      v.btri_sh = (const TriShade*)(base + o_btris);
-    v.meshes = (const MeshRef*)(base + o_mesh); v.n_mesh = uint32_t(meshes.size());
-    v.pleaf = (const uint32_t*)(base + o_pleaf); v.n_nodes = uint32_t(nodes.size());
-    v.scene_bvh = scene_bvh ? 1u : 0u;          v.top_root = top_root;
-    v.inst = (const InstRec*)(base + o_inst);   v.n_inst = uint32_t(insts.size());
-    v.mats = (const Material*)(base + o_mats);  v.n_obj = uint32_t(mats.size());
-    v.lights = (const Light*)(base + o_lights); v.n_lights = uint32_t(lights.size());
-    v.ltris = (const LightTri*)(base + o_ltris); v.lxf = (const LightXf*)(base + o_lxf);
-    v.lparts = (const LightPart*)(base + o_lparts); v.n_lparts = uint32_t(lparts.size());
-    v.has_medium = s->media.empty() ? 0u : 1u;
-    v.medium_kind = 0;
-    v.sigma_a = v.sigma_s = 0.f;
-    v.medium_emission = 0.f;
-    v.medium_phase = 0.f;
-    for (int i = 0; i < 3; i++) v.medium_color[i] = v.medium_color_hi[i] = 0.f;
-    if (!s->media.empty()) {  // only media[0] is used (src/renderer.rs:190)
-        const HMedium& m = s->media[0];
-        v.medium_kind = uint32_t(m.kind);
-        v.sigma_a = float(m.absorption);
-        v.sigma_s = float(m.scattering);
-        const double pi = 3.14159265358979323846;
-        if (m.kind == RPT_MEDIUM_HOMOGENEOUS_ISOTROPIC) {  // src/medium.rs:80-96
-            D3 c = hex_color(0xD2B48C);
-            v.medium_color[0] = v.medium_color_hi[0] = float(c.x);
-            v.medium_color[1] = v.medium_color_hi[1] = float(c.y);
-            v.medium_color[2] = v.medium_color_hi[2] = float(c.z);
-            v.medium_emission = 0.f;
-            v.medium_phase = float(1.0 / (4.0 * pi));
-        } else {  // colored_glowing_fog, src/medium.rs:99-122 (phase `1.0 / 4.0 * pi`, sic)
-            D3 lo = hex_color(0x0000FF), hi = hex_color(0xFF0000);
-            v.medium_color[0] = float(lo.x); v.medium_color[1] = float(lo.y); v.medium_color[2] = float(lo.z);
-            v.medium_color_hi[0] = float(hi.x); v.medium_color_hi[1] = float(hi.y); v.medium_color_hi[2] = float(hi.z);
-            v.medium_emission = 10.f;
-            v.medium_phase = float(1.0 / 4.0 * pi);
         }
-    }
-    for (int i = 0; i < 3; i++) v.env[i] = float(s->env[i]);
-    v.hdri = (const F4*)(base + o_hdri);
-    v.hdri_w = s->hdri_w;
-    v.hdri_h = s->hdri_h;
-    s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size() + aabb.size() + rect.size() + (has_shell ? 1 : 0);
-    s->stats[0] = sph.size(); s->stats[1] = cub.size(); s->stats[2] = pln.size(); s->stats[3] = tri.size();
-    s->stats[4] = aabb.size(); s->stats[5] = rect_sh.size(); s->stats[6] = btri.size(); s->stats[7] = nodes.size();
-    // scan-record bytes every closest-hit query walks (the uniform part of the algorithmic bytes)
-    s->stats[8] = 48 * (sph.size() + cub.size() + tri.size()) + 16 * pln.size() + 32 * (aabb.size() + rect.size());
-    s->stats[9] = off;
-    s->stats[10] = scene_bvh ? 1 : 0;
-    s->stats[11] = pleaf.size();
-    s->stats[14] = has_shell ? shell_sh.size() : 0;
-    s->stats[15] = uint64_t(top_depth + mesh_depth);
-    s->stats[12] = insts.size();
-    s->stats[13] = shared.size();
+        for (int i = 0; i < 3; i++) v.env[i] = float(s->env[i]);
+        v.hdri = (const F4*)(base + o_hdri);
+        v.hdri_w = s->hdri_w;
+        v.hdri_h = s->hdri_h;
+        s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size() + aabb.size() + rect.size() + (has_shell ? 1 : 0);
+        s->stats[0] = sph.size(); s->stats[1] = cub.size(); s->stats[2] = pln.size(); s->stats[3] = tri.size();
+        s->stats[4] = aabb.size(); s->stats[5] = rect_sh.size(); s->stats[6] = btri.size(); s->stats[7] = nodes.size();
+        // scan-record bytes every closest-hit query walks (the uniform part of the algorithmic bytes)
+        s->stats[8] = 48 * (sph.size() + cub.size() + tri.size()) + 16 * pln.size() + 32 * (aabb.size() + rect.size());
+        s->stats[9] = off;
+        s->stats[10] = scene_bvh ? 1 : 0;
+        s->stats[11] = pleaf.size();
+        s->stats[14] = has_shell ? shell_sh.size() : 0;
+        s->stats[15] = uint64_t(top_depth + mesh_depth);
+        s->stats[12] = insts.size();
+        s->stats[13] = shared.size();
 
-    for (auto& ls : s->sets) {
-        HIP_TRY(hipMalloc((void**)&ls.d_queue, 256));
-        HIP_TRY(hipEventCreateWithFlags(&ls.done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ls.launched, hipEventDisableTiming));
+        for (auto& ls : s->sets) {
+            HIP_TRY(hipMalloc((void**)&ls.d_queue, 256));
+            HIP_TRY(hipEventCreateWithFlags(&ls.done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ls.launched, hipEventDisableTiming));
+        }
+        HIP_TRY(hipMalloc((void**)&s->d_counters, 64 * sizeof(unsigned long long)));
+        s->device = device;
+        s->committed = true;
+        return RPT_OK;
     }
-    HIP_TRY(hipMalloc((void**)&s->d_counters, 64 * sizeof(unsigned long long)));
-    s->device = device;
-    s->committed = true;
-    return RPT_OK;
+};
+}  // namespace
+
+int rpt_scene_commit(rpt_scene* s, int device) {
+    if (!s) return fail(RPT_ERR_INVALID, "null scene");
+    if (s->committed) return fail(RPT_ERR_STATE, "scene already committed");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(RPT_ERR_INVALID, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RPT_ERR_UNSUPPORTED, std::string("built for gfx950 (MI355X), device is ") + prop.gcnArchName);
+    s->n_cus = prop.multiProcessorCount;
+
+    Flattener f(s);
+    int rc = f.flatten_objects();
+    if (rc) return rc;
+    f.flatten_lights();
+    f.fold_shell();
+    f.mark_twin_ranges();
+    rc = f.build_scene_tree();
+    if (rc) return rc;
+    f.collect_scan_boxes();
+    return f.upload(device);
 }
 
 // ---------------------------------------------------------------------------- render
@@ -1406,15 +1473,20 @@ extern "C" int64_t rpt_shard_tiles(uint32_t width, uint32_t height, uint32_t sha
 // Samples per work item.  Small items keep the persistent grid's tail short when a GPU owns only 1/8 of the
 // tiles; the value depends on `iterations` alone so that the fp32 partial sums, and hence the image bits, do not
 // change with the shard count.  At most 64 chunks per pixel.
-static uint32_t chunk_rule(uint32_t iterations, uint32_t min_chunk, uint32_t fixed_chunk) {
+static uint32_t chunk_rule(int64_t opt_chunk_spp, uint32_t iterations, uint32_t min_chunk, uint32_t fixed_chunk) {
     if (fixed_chunk) return fixed_chunk;
-    const int64_t chunk = g_opt_chunk_spp > 0 ? g_opt_chunk_spp
+    const int64_t chunk = opt_chunk_spp > 0 ? opt_chunk_spp
                                               : std::min<int64_t>(32, std::max<int64_t>(std::max<int64_t>(2, min_chunk), (int64_t(iterations) + 63) / 64));
     return uint32_t(std::min<int64_t>(chunk, iterations));
 }
 int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_chunks) {
     if (iterations == 0) return fail(RPT_ERR_INVALID, "empty render");
-    const uint32_t c = chunk_rule(iterations, 0, 0);
+    int64_t opt;
+    {
+        std::lock_guard<std::mutex> lock(g_defaults_mutex);
+        opt = g_defaults.chunk_spp;
+    }
+    const uint32_t c = chunk_rule(opt, iterations, 0, 0);
     if (chunk_spp) *chunk_spp = c;
     if (n_chunks) *n_chunks = (iterations + c - 1) / c;
     return RPT_OK;
@@ -1449,7 +1521,7 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     a.max_bounces = prm->max_bounces;
     a.iterations = iterations;
     a.sample_offset = sample_offset;
-    a.chunk_spp = chunk_rule(iterations, min_chunk, fixed_chunk);
+    a.chunk_spp = chunk_rule(s->opt.chunk_spp, iterations, min_chunk, fixed_chunk);
     a.n_chunks = (iterations + a.chunk_spp - 1) / a.chunk_spp;
     a.seed_mixed = seed_mix(seed);
 
@@ -1492,10 +1564,10 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     ls.used = true;
     a.slab = ls.d_slab;
     a.queue = ls.d_queue;
-    a.counters = g_opt_counters ? s->d_counters : nullptr;
+    a.counters = s->opt.counters ? s->d_counters : nullptr;
     a.lds_stack = s->view.n_nodes ? 1u : 0u;
-    a.defer_lanes = uint32_t(g_opt_defer_lanes);
-    a.defer_stop = uint32_t(std::min(g_opt_defer_stop, g_opt_defer_lanes));
+    a.defer_lanes = uint32_t(s->opt.defer_lanes);
+    a.defer_stop = uint32_t(std::min(s->opt.defer_stop, s->opt.defer_lanes));
     return RPT_OK;
 }
 
@@ -1529,7 +1601,7 @@ extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm
         // pull), so the counter starts behind those batches
         if (indexed_start) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.queue, int(uint32_t(n_blocks) * 4u * 64u), 1, st));
         hipEvent_t* ev = nullptr;
-        if (g_opt_timing) {
+        if (s->opt.timing) {
             const size_t slot = s->ev_count % rpt_scene::kTimedLaunches;
             while (s->evs.size() < 3 * (slot + 1)) {
                 hipEvent_t e = nullptr;
@@ -1552,7 +1624,7 @@ extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm
     return RPT_OK;
 }
 static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st) {
-    int bpc = int(g_opt_blocks_per_cu);
+    int bpc = int(s->opt.blocks_per_cu);
     if (bpc <= 0) {
         HIP_TRY(render_occupancy(a.sc.has_medium != 0, bvh_mode(a.sc), &bpc));
         if (bpc < 1) bpc = 1;
@@ -1567,6 +1639,8 @@ extern "C++" rpti::SceneDev rpti::scene_dev(rpt_scene* s) {
     return SceneDev{s->committed, s->device, s->n_cus, s->view, first};
 }
 extern "C++" void*& rpti::photon_slot(rpt_scene* s) { return s->photon; }
+extern "C++" int64_t rpti::option_photon_skip(rpt_scene* s) { return s->opt.photon_skip; }
+extern "C++" int64_t rpti::option_photon_block_lists(rpt_scene* s) { return s->opt.photon_block_lists; }
 extern "C++" double* rpti::scratch_out(rpt_scene* s, size_t bytes) {
     if (bytes > s->out_cap) {
         if (s->d_out) (void)hipFree(s->d_out);

@@ -70,6 +70,12 @@ def test_argument_validation_needs_no_gpu():
         rc = lib.rpt_render_sample(h, C.byref(cam), C.byref(prm), 1, 0, 0, out.ctypes.data_as(C.c_void_p))
         assert rc == -2 and b"commit" in lib.rpt_last_error()                         # render before commit
         assert lib.rpt_set_option(b"no_such_option", 1) == -1
+        # options are per scene: same names, same validation, no effect on the process defaults
+        assert lib.rpt_scene_set_option(h, b"chunk_spp", 8) == 0 and lib.rpt_scene_set_option(h, b"defer_lanes", 16) == 0
+        assert lib.rpt_scene_set_option(h, b"defer_lanes", 65) == -1 and lib.rpt_scene_set_option(h, b"nope", 1) == -1
+        assert lib.rpt_scene_set_option(None, b"chunk_spp", 8) == -1
+        c, n = C.c_uint32(), C.c_uint32()
+        assert lib.rpt_render_chunking(256, C.byref(c), C.byref(n)) == 0 and (c.value, n.value) == (4, 64)   # the default rule
     finally:
         lib.rpt_scene_destroy(h)
 

@@ -63,6 +63,28 @@ def test_chunk_option_changes_rounding_only_and_is_validated():
         rpt_amd.set_option("no_such_option", 1)
 
 
+def test_options_belong_to_a_scene():
+    """rpt_scene_set_option: two scenes of one process with different options do not see each other's (the C ABI has
+    no process-global render state); the process default set by rpt_set_option reaches scenes created afterwards."""
+    import rpt_amd
+    a, cam, cfg = scenes.cornell()
+    b, _, _ = scenes.cornell()
+    ra = Renderer(a, cam).width(64).height(64).max_bounces(2).seed(1)
+    rb = Renderer(b, cam).width(64).height(64).max_bounces(2).seed(1)
+    a.set_option("counters", 1).set_option("chunk_spp", 16)
+    img_a, img_b = ra.sample_array(32), rb.sample_array(32)
+    assert ra.counters()["samples"] == 64 * 64 * 32 and rb.counters()["samples"] == 0
+    assert not np.array_equal(img_a, img_b) and np.allclose(img_a, img_b, rtol=1e-4, atol=1e-6)   # 2 chunks vs 16: fp32 sum order
+    rpt_amd.set_option("chunk_spp", 16)      # the convenience setter: default + every live scene
+    try:
+        rb._sample_offset = 0
+        assert np.array_equal(rb.sample_array(32), img_a)
+        c, _, _ = scenes.cornell()
+        assert np.array_equal(Renderer(c, cam).width(64).height(64).max_bounces(2).seed(1).sample_array(32), img_a)
+    finally:
+        rpt_amd.set_option("chunk_spp", 0)
+
+
 def test_render_argument_errors():
     scene, cam, cfg = scenes.cornell()
     r = Renderer(scene, cam).width(0).height(4)

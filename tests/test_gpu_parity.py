@@ -438,9 +438,9 @@ def test_cpp_mirror_example_renders_the_same_bytes_as_the_python_mirror():
 # (config, pixels in the subset, rel-RMS bound vs the robust oracle, vs the literal oracle, bound on the mean bias vs literal)
 # The last column is the known delta to rpt itself: the reference's 1e-12 shadow / t_min
 # epsilons lose energy to fp64 self-hits and false shadow rejections, which the fp32 policy does not reproduce; measured
-# +0.77 % (C2), +0.16 % (C3) in round 1.  The bounds sit just above the measured values so that the gap cannot grow unseen.
+# +0.77 % (C2), +0.16 % (C3), -0.002 % (C5: small coordinates, the 1e-12 tests rarely misfire).  The bounds sit just above the measured values so that the gap cannot grow unseen.
 @pytest.mark.parametrize("name,npix,tol_robust,tol_literal,bias_literal", [
-    ("C2", 4096, 2e-3, 2e-2, (6.5e-3, 9.0e-3)), ("C3", 2048, 2e-3, 3e-2, (0.5e-3, 2.5e-3)), ("C5", 1024, 5e-3, 5e-2, (-5e-3, 1.5e-2))])
+    ("C2", 4096, 2e-3, 2e-2, (6.5e-3, 9.0e-3)), ("C3", 2048, 2e-3, 3e-2, (0.5e-3, 2.5e-3)), ("C5", 1024, 2e-3, 2e-3, (-5e-4, 5e-4))])
 def test_full_size_configs_match_oracle_on_a_pixel_subset(name, npix, tol_robust, tol_literal, bias_literal):
     """The full BASELINE configuration (C2 512x512x64, C3 1024x1024x256, C5 2048x2048x1024 over the 100,352-triangle
     mesh) on the GPU; the fp64 oracle renders the same seed on a random pixel subset (it is ~1000x slower).  Both
