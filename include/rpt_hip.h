@@ -184,7 +184,7 @@ int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_ch
  * them when fewer than this many are still walking, default 16; the image does not depend on either),
  * "bvh_leaf_max" (read by rpt_scene_commit: triangles per leaf of a mesh tree, default 4 -- C5: 49.8 / 43.1 / 41.1 /
  * 41.1 / 41.7 ms for 1 / 2 / 4 / 6 / 8), "bvh_max_depth" (read by rpt_scene_commit: a mesh tree that the SAH builder makes deeper than this is rebuilt
- * with object-median splits, default 20 -- the traversal stack holds 32 levels for scene tree + mesh tree;
+ * with object-median splits, default and maximum 20 -- the traversal stack holds 21 entries per mesh tree, 32 for scene tree + mesh tree;
  * a scene that still does not fit is refused with RPT_ERR_UNSUPPORTED);
  * returns RPT_ERR_INVALID for unknown names. */
 int rpt_set_option(const char* name, int64_t value);

@@ -490,13 +490,13 @@ struct WalkState {
     uint32_t cur, sp, mesh;
 };
 RPT_DEV WalkState walk_begin(const SceneView& sc) { return WalkState{uload(&sc.meshes[0]).root, 0u, 0u}; }
+// `cap`: rows of the stack column (a mesh tree is at most bvh_max_depth = 20 levels deep: it pushes at most 19 entries).
 template <bool COUNT>
 RPT_DEV void walk_meshes_resumable(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t* stk,
                                    uint32_t stride, WalkState& w, uint32_t min_active, AnyHit any, uint32_t& c_nodes,
-                                   uint32_t& c_tris) {
+                                   uint32_t& c_tris, uint32_t cap = 32u) {
     const BvhNode* nodes = sc.nodes;
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
-    const uint32_t cap = 32u;
     uint32_t cur = w.cur, sp = w.sp, mesh = w.mesh;
     while (uint32_t(__popcll(__ballot(cur != kWalkDone))) >= min_active) {
         while (!(cur & BVH_LEAF)) {  // kWalkDone has the leaf bit set, so finished lanes fall through

@@ -52,6 +52,9 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 #ifndef RPT_MIN_WAVES
 #define RPT_MIN_WAVES 4       // waves per SIMD the BVH instantiations are compiled for (128 VGPRs)
 #endif
+#ifndef RPT_MIN_WAVES_MESH
+#define RPT_MIN_WAVES_MESH 4  // per-mesh-tree instantiations (BVH = 1)
+#endif
 #ifndef RPT_MIN_WAVES_SCAN
 #define RPT_MIN_WAVES_SCAN 5  // linear-scan instantiations (BVH = 0): 96 VGPRs; the kernel is latency-bound
 #endif
@@ -77,7 +80,7 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 // GROUPS: some Light::Object is a KdTree group (per-lane leaf sampler).  A separate instantiation: the extra
 // sampler copy costs the plain kernels 6 % through register allocation alone, and a call costs 6x.
 template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false>
-__global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT_MIN_WAVES_MESH : RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
     extern __shared__ uint32_t dyn_lds[];
     const SceneView& sc = a.sc;
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
@@ -97,7 +100,9 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
     // ds instruction instead of a trip to L2 (register spills of that build ran at 39 GB of HBM writes per launch).
     // The tree-walking instantiations (128 VGPRs, 32 KB of LDS stack per block) park only the five values that
     // are read once per sample: 4 blocks x (32 + 5) KB still fit the CU's 160 KB.
-    constexpr uint32_t kStateBase = BVH ? 32u * 256u : 0u;  // dwords: after the traversal stack
+    // rows of the traversal stack: scene tree + mesh tree need up to 32; a mesh tree alone is at most 20 levels deep
+    constexpr uint32_t kStackRows = BVH == 1 ? 21u : 32u;
+    constexpr uint32_t kStateBase = BVH ? kStackRows * 256u : 0u;  // dwords: after the traversal stack
     uint32_t* const ls = dyn_lds + kStateBase + threadIdx.x;  // [slots][256] dwords, one column per lane
     enum { S_SLAB = 0, S_END = 1, S_PIX = 2, S_XN = 3, S_YN = 4, S_S = 5, S_ACC = 6, S_P = 9, S_Q = 12, S_RC = 15, S_MAT = 18, S_N = 24 };
     auto in_lds = [](int k) { return BVH == 0 || k <= S_YN; };
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : RPT_MIN_WAVES)
                         any = AnyHit{lo <= hi ? v_dist * (1.f - 1e-3f) : -kInf, lo, hi};
                     }
                     walk_meshes_resumable<COUNT>(sc, qo, qd, ray_tmin(qo), q_t, q_code, stk, stride, walk,
-                                                 idle ? 1u : a.defer_stop, any, c_nodes, c_btris);
+                                                 idle ? 1u : a.defer_stop, any, c_nodes, c_btris, kStackRows);
                     if (walk.cur == kWalkDone) {
                         phase = shadow ? PH_HAVES : PH_HAVEP;
                         SECT(16);
@@ -716,10 +721,11 @@ __global__ void debug_camera_kernel(const CameraG cam, uint32_t w, uint32_t h, u
 static constexpr size_t kStackBytes = 32u * 256u * sizeof(uint32_t);
 static constexpr size_t kStateBytes = 18u * 256u * sizeof(uint32_t);      // LDS-resident lane state of the scan instantiations
 static constexpr size_t kStateBytesBvh = 5u * 256u * sizeof(uint32_t);   // ... of the tree-walking ones (behind the stack)
+static constexpr size_t kMeshTreeBytes = (21u + 5u) * 256u * sizeof(uint32_t);   // per-mesh-tree kernels: 21 stack rows + lane state
 
 template <bool M, int B, bool C>
 static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t stream) {
-    const size_t lds = B ? kStackBytes + kStateBytesBvh : kStateBytes;
+    const size_t lds = B == 1 ? kMeshTreeBytes : B ? kStackBytes + kStateBytesBvh : kStateBytes;
     // group lights have no counters build: the section counters stay zero for such scenes
     if (a.sc.n_lparts) hipLaunchKernelGGL((render_kernel<M, B, false, true>), dim3(n_blocks), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((render_kernel<M, B, C>), dim3(n_blocks), dim3(256), lds, stream, a);
@@ -742,7 +748,7 @@ hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu) {
     const void* f;
     if (medium) f = bvh == 2 ? (const void*)render_kernel<true, 2, false> : bvh == 1 ? (const void*)render_kernel<true, 1, false> : (const void*)render_kernel<true, 0, false>;
     else f = bvh == 2 ? (const void*)render_kernel<false, 2, false> : bvh == 1 ? (const void*)render_kernel<false, 1, false> : (const void*)render_kernel<false, 0, false>;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, 256, bvh ? kStackBytes + kStateBytesBvh : kStateBytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, 256, bvh == 1 ? kMeshTreeBytes : bvh ? kStackBytes + kStateBytesBvh : kStateBytes);
 }
 hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipStream_t stream) {
     uint32_t blocks = (a.n_owned + 255u) / 256u;

@@ -81,7 +81,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "instancing") o.instancing = value;
     else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); o.defer_lanes = value; }
     else if (s == "bvh_leaf_max") { if (value < 1 || value > 16) return fail(RPT_ERR_INVALID, "bvh_leaf_max must be 1..16"); o.bvh_leaf_max = value; }
-    else if (s == "bvh_max_depth") { if (value < 1 || value > 31) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..31"); o.bvh_max_depth = value; }
+    else if (s == "bvh_max_depth") { if (value < 1 || value > 20) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..20"); o.bvh_max_depth = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); o.scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option: " + s);
@@ -1003,6 +1003,8 @@ struct Flattener {
         }
         if (tri.size() >= BVH_INDEX_MASK || btri.size() >= BVH_INDEX_MASK || nodes.size() >= (1u << 30))
             return fail(RPT_ERR_UNSUPPORTED, "too many triangles");
+        // the walk's stack column holds 21 entries in the per-mesh-tree kernels (a tree of depth d pushes at most d - 1)
+        if (mesh_depth > 20) return fail(RPT_ERR_UNSUPPORTED, "a mesh tree is deeper than 20 levels even when rebuilt balanced (mesh too large)");
 
         return RPT_OK;
     }
