@@ -424,7 +424,6 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
             float xi = rng.range(0.f, 1.f);
             dmed = -__logf(xi) * inv_sigma_t;
         }
-        const V wo = -normalize(rd);
         const float tmin = ray_tmin(ro);
         // A hit beyond the sampled medium distance cannot change the event (dmed < t, or a miss with dmed < 400,
         // is a medium event either way, src/renderer.rs:197-243): the search interval ends there, which culls
@@ -499,7 +498,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                         if (ev_medium) {
                             E = fma3(albedo_med * sc.medium_phase, I * mcol, E);
                         } else {
-                            V f = bsdf(mat, n, wo, wi);
+                            V f = bsdf(mat, n, -normalize(rd), wi);   // (wo is only needed at surface events: derived where used)
                             E = fma3(dot(wi, n), f * I, E);
                         }
                     }
@@ -527,6 +526,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
             if (bounce) {
                 float pdf;
                 SECT(13);
+                const V wo = -normalize(rd);
                 bounce = sample_f(mat, n, wo, rng, wi, pdf);
                 if (bounce) {
                     V f = bsdf(mat, n, wo, wi);
