@@ -77,6 +77,91 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
             }                                                                                    \
         }                                                                                        \
     } while (0)
+// ---- The stages of a path vertex, shared by the two loop bodies of render_kernel (the parked-walk state machine of the
+// per-mesh-tree flavour and the lock-step body of the others): what they compute is one thing, when they run another.
+// Distance sample of a new vertex and the interval its closest-hit query has to search (Medium::sample_d,
+// src/medium.rs:133-146).  A hit beyond the sampled medium distance cannot change the event (dmed < t, or a miss with
+// dmed < 400, is a medium event either way, src/renderer.rs:197-243): the search ends there, which culls most of a
+// tree walk in fog.  The margin keeps the `dmed < t` comparison below the one that decides.
+template <bool MEDIUM>
+RPT_DEV void stage_distance(Rng& rng, float inv_sigma_t, float& dmed, float& t) {
+    dmed = kInf;
+    if (MEDIUM) {
+        float xi = rng.range(0.f, 1.f);
+        dmed = -__logf(xi) * inv_sigma_t;
+    }
+    t = (MEDIUM && dmed < 400.f) ? dmed * (1.f + 1e-6f) : kInf;
+}
+// The event at a medium point or a surface hit: position, what shading needs, emission (src/renderer.rs:207-216,
+// 243-255, 289-299).
+template <bool COUNT>
+RPT_DEV void stage_event(const RenderArgs& a, V ro, V rd, uint32_t depth, bool medium, float dmed, float t, uint32_t code,
+                         uint32_t inst, V& x, V& n, V& mcol, Mat& mat, V& E) {
+    const SceneView& sc = a.sc;
+    if (medium) {
+        SECT(5);
+        x = fma3(dmed, rd, ro);
+        bool hi = sc.medium_kind == 1u && x.y > 250.f;
+        mcol = hi ? mk(sc.medium_color_hi[0], sc.medium_color_hi[1], sc.medium_color_hi[2])
+                  : mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);
+        E = (depth == 0) ? sc.medium_emission * mcol : mk(0, 0, 0);
+    } else {
+        uint32_t obj;
+        SECT(6);
+        finalize_hit(sc, ro, rd, ray_tmin(ro), t, code, inst, n, obj);
+        mat = load_mat(sc, obj);
+        x = fma3(t, rd, ro);
+        E = (depth == 0) ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
+    }
+}
+// The shadow test of an object light and its term of E (src/renderer.rs:347-353, 395-404).  Reference: contributes
+// iff the closest hit along wi lies at dist_to_light (|hit - dist| < 1e-12).  fp32 equivalent: the closest hit
+// belongs to the scene object that IS this light, at the sampled distance (rel. tol 1e-3).
+RPT_DEV void stage_light_term(const SceneView& sc, const Light& L, float albedo_med, V rd, bool medium, float ts, uint32_t cs,
+                              uint32_t is, float dist, V I, V wi, V n, V mcol, const Mat& mat, V& E) {
+    const bool twin = (L.twin_lo <= L.twin_hi) ? (cs >= L.twin_lo && cs <= L.twin_hi)   // wave-uniform choice
+                                               : (cs != CODE_MISS && code_object(sc, cs, is) == uint32_t(L.twin_object));
+    if (cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) && twin) {
+        if (medium) {
+            E = fma3(albedo_med * sc.medium_phase, I * mcol, E);
+        } else {
+            V f = bsdf(mat, n, -normalize(rd), wi);   // (wo is only needed at surface events: derived where used)
+            E = fma3(dot(wi, n), f * I, E);
+        }
+    }
+}
+// Continue or end: Russian roulette / max_bounces, phase or BSDF sample, path weight (src/renderer.rs:222-232, 262-281, 301-313)
+template <bool MEDIUM, bool COUNT>
+RPT_DEV bool stage_bounce(const RenderArgs& a, float albedo_med, V rd, uint32_t depth, bool medium, V n, V mcol, const Mat& mat,
+                          Rng& rng, V& wi, V& k) {
+    bool bounce;
+    SECT(10);
+    if (medium) {
+        SECT(11);
+        bounce = rng.uniform() < 0.8f;
+        if (bounce) {
+            float ax = rng.range(-1.f, 1.f), ay = rng.range(-1.f, 1.f), az = rng.range(-1.f, 1.f);
+            wi = normalize(mk(ax, ay, az));        // src/medium.rs:87-93 (cube, then normalise)
+            k = (albedo_med * 1.25f) * mcol;       // (scat/ext) / ph_p * phase / rr_p, ph_p == phase
+        }
+    } else {
+        SECT(12);
+        bounce = MEDIUM ? (rng.uniform() < 0.8f) : (depth < a.max_bounces);  // :222 / :301
+        if (bounce) {
+            float pdf;
+            SECT(13);
+            const V wo = -normalize(rd);
+            bounce = sample_f(mat, n, wo, rng, wi, pdf);
+            if (bounce) {
+                V f = bsdf(mat, n, wo, wi);
+                float wgt = fabsf(dot(wi, n)) * rcp(MEDIUM ? pdf * 0.8f : pdf);
+                k = wgt * f;
+            }
+        }
+    }
+    return bounce && !is_zero(k);
+}
+
 // GROUPS: some Light::Object is a KdTree group (per-lane leaf sampler).  A separate instantiation: the extra
 // sampler copy costs the plain kernels 6 % through register allocation alone, and a call costs 6x.
 template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false>
@@ -257,13 +342,8 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
             if (alive && phase == PH_NEW) {
                 if (COUNT) c_vertices++;
                 SECT(2);
-                v_dmed = kInf;
-                if (MEDIUM) {  // Medium::sample_d, src/medium.rs:133-146
-                    float xi = rng.range(0.f, 1.f);
-                    v_dmed = -__logf(xi) * inv_sigma_t;
-                }
+                stage_distance<MEDIUM>(rng, inv_sigma_t, v_dmed, q_t);
                 const float tmin = ray_tmin(ro);
-                q_t = (MEDIUM && v_dmed < 400.f) ? v_dmed * (1.f + 1e-6f) : kInf;  // see the undeferred body below
                 q_code = CODE_MISS;
                 q_inst = 0;
                 scan_prims(sc, ro, rd, tmin, q_t, q_code);
@@ -282,21 +362,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                     need_path = true;
                     phase = PH_NEW;
                 } else {
-                    if (v_medium) {
-                        SECT(5);
-                        v_x = fma3(v_dmed, rd, ro);
-                        bool hi = sc.medium_kind == 1u && v_x.y > 250.f;
-                        v_mcol = hi ? mk(sc.medium_color_hi[0], sc.medium_color_hi[1], sc.medium_color_hi[2])
-                                    : mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);
-                        v_E = (depth == 0) ? sc.medium_emission * v_mcol : mk(0, 0, 0);
-                    } else {
-                        uint32_t obj;
-                        SECT(6);
-                        finalize_hit(sc, ro, rd, ray_tmin(ro), q_t, q_code, q_inst, v_n, obj);
-                        v_mat = load_mat(sc, obj);
-                        v_x = fma3(q_t, rd, ro);
-                        v_E = (depth == 0) ? mat_emit(v_mat) * mat_color(v_mat) : mk(0, 0, 0);
-                    }
+                    stage_event<COUNT>(a, ro, rd, depth, v_medium, v_dmed, q_t, q_code, q_inst, v_x, v_n, v_mcol, v_mat, v_E);
                     v_li = 0;
                     phase = PH_LIGHT;
                 }
@@ -332,51 +398,18 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                 }
                 if (alive && phase == PH_HAVES && v_li == l) {
                     SECT(9);
-                    const bool twin = (L.twin_lo <= L.twin_hi) ? (q_code >= L.twin_lo && q_code <= L.twin_hi)
-                                                               : (q_code != CODE_MISS && code_object(sc, q_code, q_inst) == uint32_t(L.twin_object));
-                    if (q_code != CODE_MISS && q_t >= v_dist * (1.f - 1e-3f) && twin) {
-                        if (v_medium) {
-                            v_E = fma3(albedo_med * sc.medium_phase, v_I * v_mcol, v_E);
-                        } else {
-                            V f = bsdf(v_mat, v_n, -normalize(rd), v_wi);
-                            v_E = fma3(dot(v_wi, v_n), f * v_I, v_E);
-                        }
-                    }
+                    stage_light_term(sc, L, albedo_med, rd, v_medium, q_t, q_code, q_inst, v_dist, v_I, v_wi, v_n, v_mcol, v_mat, v_E);
                     v_li = l + 1u;
                     phase = PH_LIGHT;
                 }
             }
             // ---- C: continue or end the path
             if (alive && phase == PH_LIGHT && v_li >= sc.n_lights) {
-                bool bounce;
                 V wi = mk(0, 0, 1), k = mk(0, 0, 0);
-                SECT(10);
-                if (v_medium) {  // src/renderer.rs:262-281
-                    SECT(11);
-                    bounce = rng.uniform() < 0.8f;
-                    if (bounce) {
-                        float ax = rng.range(-1.f, 1.f), ay = rng.range(-1.f, 1.f), az = rng.range(-1.f, 1.f);
-                        wi = normalize(mk(ax, ay, az));
-                        k = (albedo_med * 1.25f) * v_mcol;
-                    }
-                } else {
-                    SECT(12);
-                    bounce = MEDIUM ? (rng.uniform() < 0.8f) : (depth < a.max_bounces);
-                    if (bounce) {
-                        float pdf;
-                        SECT(13);
-                        const V wo = -normalize(rd);
-                        bounce = sample_f(v_mat, v_n, wo, rng, wi, pdf);
-                        if (bounce) {
-                            V f = bsdf(v_mat, v_n, wo, wi);
-                            float wgt = fabsf(dot(wi, v_n)) * rcp(MEDIUM ? pdf * 0.8f : pdf);
-                            k = wgt * f;
-                        }
-                    }
-                }
+                const bool cont = stage_bounce<MEDIUM, COUNT>(a, albedo_med, rd, depth, v_medium, v_n, v_mcol, v_mat, rng, wi, k);
                 SECT(14);
                 P = fma3(Q, v_E, P);
-                if (bounce && !is_zero(k)) {
+                if (cont) {
                     if (!MEDIUM) Rc = vmin(Rc, fma3(100.f, Q, P));
                     Q = Q * k;
                     ro = v_x;
@@ -419,16 +452,9 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
         // ---- one path vertex (one trace_ray invocation, src/renderer.rs:187-322)
         if (COUNT) c_vertices++;
         SECT(2);
-        float dmed = kInf;
-        if (MEDIUM) {  // Medium::sample_d, src/medium.rs:133-146
-            float xi = rng.range(0.f, 1.f);
-            dmed = -__logf(xi) * inv_sigma_t;
-        }
+        float dmed, t;
+        stage_distance<MEDIUM>(rng, inv_sigma_t, dmed, t);
         const float tmin = ray_tmin(ro);
-        // A hit beyond the sampled medium distance cannot change the event (dmed < t, or a miss with dmed < 400,
-        // is a medium event either way, src/renderer.rs:197-243): the search interval ends there, which culls
-        // most of a tree walk in fog.  The margin keeps the `dmed < t` comparison below the one that decides.
-        float t = (MEDIUM && dmed < 400.f) ? dmed * (1.f + 1e-6f) : kInf;
         uint32_t code = CODE_MISS, inst = 0;
         closest_hit<BVH, COUNT>(sc, ro, rd, tmin, t, code, inst, stk, stride, c_nodes, c_btris);
         if (COUNT) c_rays++;
@@ -451,21 +477,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
 
         V x, n = mk(0, 1, 0), mcol = mk(0, 0, 0), E;
         Mat mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
-        if (ev_medium) {  // src/renderer.rs:243-255
-            SECT(5);
-            x = fma3(dmed, rd, ro);
-            bool hi = sc.medium_kind == 1u && x.y > 250.f;
-            mcol = hi ? mk(sc.medium_color_hi[0], sc.medium_color_hi[1], sc.medium_color_hi[2])
-                      : mk(sc.medium_color[0], sc.medium_color[1], sc.medium_color[2]);
-            E = (depth == 0) ? sc.medium_emission * mcol : mk(0, 0, 0);
-        } else {  // src/renderer.rs:207-216, 289-299
-            uint32_t obj;
-            SECT(6);
-            finalize_hit(sc, ro, rd, tmin, t, code, inst, n, obj);
-            mat = load_mat(sc, obj);
-            x = fma3(t, rd, ro);
-            E = (depth == 0) ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
-        }
+        stage_event<COUNT>(a, ro, rd, depth, ev_medium, dmed, t, code, inst, x, n, mcol, mat, E);
 
         // ---- next-event estimation: sample_lights / sample_lights_for_media
         //      (src/renderer.rs:362-409 / 325-359); lights in scene order fix the draw order.
@@ -480,9 +492,6 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                 illuminate_object<GROUPS>(sc, L, x, rng, I, wi, dist);
                 if (L.twin_object >= 0) {
                     SECT(8);
-                    // Reference: contributes iff the closest hit along wi lies at dist_to_light
-                    // (|hit - dist| < 1e-12).  fp32 equivalent: the closest hit belongs to the
-                    // scene object that IS this light, at the sampled distance (rel. tol 1e-3).
                     float ts = dist * (1.f + 1e-3f);
                     uint32_t cs = CODE_MISS, is = 0;
                     // tree-walking scenes: any hit in front of the light on something other than its twin settles the test
@@ -491,17 +500,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                                                      AnyHit{range ? dist * (1.f - 1e-3f) : -kInf, L.twin_lo, L.twin_hi});
                     if (COUNT) c_rays++;
                     SECT(9);
-                    const bool twin = (L.twin_lo <= L.twin_hi) ? (cs >= L.twin_lo && cs <= L.twin_hi)   // wave-uniform choice
-                                                               : (cs != CODE_MISS && code_object(sc, cs, is) == uint32_t(L.twin_object));
-                    bool vis = cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) && twin;
-                    if (vis) {
-                        if (ev_medium) {
-                            E = fma3(albedo_med * sc.medium_phase, I * mcol, E);
-                        } else {
-                            V f = bsdf(mat, n, -normalize(rd), wi);   // (wo is only needed at surface events: derived where used)
-                            E = fma3(dot(wi, n), f * I, E);
-                        }
-                    }
+                    stage_light_term(sc, L, albedo_med, rd, ev_medium, ts, cs, is, dist, I, wi, n, mcol, mat, E);
                 }
             }
             // Point / Directional lights can never satisfy the reference's test (dist is the
@@ -509,37 +508,13 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
         }
 
         // ---- continue or end the path
-        bool bounce;
         V wi = mk(0, 0, 1), k = mk(0, 0, 0);
-        SECT(10);
-        if (ev_medium) {  // src/renderer.rs:262-281
-            SECT(11);
-            bounce = rng.uniform() < 0.8f;
-            if (bounce) {
-                float ax = rng.range(-1.f, 1.f), ay = rng.range(-1.f, 1.f), az = rng.range(-1.f, 1.f);
-                wi = normalize(mk(ax, ay, az));        // src/medium.rs:87-93 (cube, then normalise)
-                k = (albedo_med * 1.25f) * mcol;       // (scat/ext) / ph_p * phase / rr_p, ph_p == phase
-            }
-        } else {
-            SECT(12);
-            bounce = MEDIUM ? (rng.uniform() < 0.8f) : (depth < a.max_bounces);  // :222 / :301
-            if (bounce) {
-                float pdf;
-                SECT(13);
-                const V wo = -normalize(rd);
-                bounce = sample_f(mat, n, wo, rng, wi, pdf);
-                if (bounce) {
-                    V f = bsdf(mat, n, wo, wi);
-                    float wgt = fabsf(dot(wi, n)) * rcp(MEDIUM ? pdf * 0.8f : pdf);
-                    k = wgt * f;
-                }
-            }
-        }
+        const bool cont = stage_bounce<MEDIUM, COUNT>(a, albedo_med, rd, depth, ev_medium, n, mcol, mat, rng, wi, k);
         SECT(14);
         if constexpr (BVH == 0) {
             const V q = ldv(S_Q, Q);
             const V pn = fma3(q, E, ldv(S_P, P));
-            if (bounce && !is_zero(k)) {
+            if (cont) {
                 stv(S_P, P, pn);
                 if (!MEDIUM) stv(S_RC, Rc, vmin(ldv(S_RC, Rc), fma3(100.f, q, pn)));  // FIREFLY_CLAMP, src/renderer.rs:311-313
                 stv(S_Q, Q, q * k);
@@ -552,7 +527,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
             }
         } else {
             P = fma3(Q, E, P);
-            if (bounce && !is_zero(k)) {
+            if (cont) {
                 if (!MEDIUM) Rc = vmin(Rc, fma3(100.f, Q, P));  // FIREFLY_CLAMP, src/renderer.rs:311-313
                 Q = Q * k;
                 ro = x;
