@@ -654,8 +654,24 @@ struct Mat {
     uint32_t kind;
     float shin, ior;
 };
-RPT_DEV Mat load_mat(const SceneView& sc, uint32_t obj) {
-    const Material m = sc.mats[obj];
+// Small per-scene tables that every lane indexes on its own -- the material of the object it hit, the triangle of the
+// light it samples -- staged in LDS by the render kernel (a ds_read instead of a dependent global load in the middle of a
+// stage).  A table that does not fit stays in global memory (count 0 here); kernels that stage nothing pass LdsTables{}.
+struct LdsTables {
+    const F4* mats = nullptr;    // [n_mats] Material records
+    uint32_t n_mats = 0;
+    const F4* ltris = nullptr;   // [n_ltris] LightTri records
+    uint32_t n_ltris = 0;
+};
+static constexpr uint32_t kLdsMats = 32, kLdsLtris = 8;   // 32 x 32 B + 8 x 96 B = 1.75 KB per block
+RPT_DEV Mat load_mat(const SceneView& sc, uint32_t obj, const LdsTables& tab = LdsTables{}) {
+    Material m;
+    if (obj < tab.n_mats) {   // wave-uniform in effect: either every object's material is staged or none
+        m.albedo_emit = tab.mats[2u * obj];
+        m.params = tab.mats[2u * obj + 1u];
+    } else {
+        m = sc.mats[obj];
+    }
     return Mat{xyz(m.albedo_emit), m.albedo_emit.w, __float_as_uint(m.params.x), m.params.y, m.params.z};
 }
 RPT_DEV V mat_color(const Mat& m) { return (m.kind <= 1u) ? m.albedo : mk(0.f, 0.f, 0.f); }   // src/material.rs:107
@@ -772,14 +788,20 @@ template <> struct LightXfRows<false> {
 // One leaf shape of a Light::Object (Sphere/Cube/Mesh::sample under Transformed::sample, src/shape.rs:140-151).
 template <bool UNIFORM>
 RPT_DEV void sample_light_leaf(const SceneView& sc, uint32_t shape, uint32_t first, uint32_t count, const LightXf* xp,
-                               V pos, Rng& rng, V& v, V& n, float& p) {
+                               V pos, Rng& rng, V& v, V& n, float& p, const LdsTables& tab = LdsTables{}) {
     V vl, nl;
     const LightXfRows<UNIFORM> x(xp);
     const bool xf = x.nrm(1).w != 0.f;
     const bool mesh = shape == LS_MESH;
     if (mesh) {
         uint32_t idx = rng.index(count);
-        const LightTri tr = sc.ltris[first + idx];
+        LightTri tr;
+        if (first + idx < tab.n_ltris) {
+            const F4* q = tab.ltris + 6u * (first + idx);
+            tr.v1 = q[0]; tr.v2 = q[1]; tr.v3 = q[2]; tr.n1 = q[3]; tr.n2 = q[4]; tr.n3 = q[5];
+        } else {
+            tr = sc.ltris[first + idx];
+        }
         float u = rng.uniform(), vv = rng.uniform();
         while (u + vv > 1.f) {
             u = rng.uniform();
@@ -829,9 +851,10 @@ RPT_DEV void sample_light_leaf(const SceneView& sc, uint32_t shape, uint32_t fir
 // Shape::sample of a Light::Object.  A KdTree group (src/kdtree.rs:141-146) samples a uniformly chosen child and
 // divides its pdf by the child count, nested groups repeat that: every lane descends to its own leaf.
 template <bool GROUPS>
-RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng& rng, V& v, V& n, float& p) {
+RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng& rng, V& v, V& n, float& p,
+                                const LdsTables& tab = LdsTables{}) {
     if (!GROUPS || L.shape != LS_GROUP) {  // wave-uniform
-        sample_light_leaf<true>(sc, L.shape, L.first, L.count, &sc.lxf[L.xf], pos, rng, v, n, p);
+        sample_light_leaf<true>(sc, L.shape, L.first, L.count, &sc.lxf[L.xf], pos, rng, v, n, p, tab);
         return;
     }
     uint32_t shape = LS_GROUP, first = L.first, count = L.count, xfi = 0;
@@ -842,15 +865,15 @@ RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng&
         const LightPart part = sc.lparts[first + idx];
         shape = part.shape; first = part.first; count = part.count; xfi = part.xf;
     }
-    sample_light_leaf<false>(sc, shape, first, count, &sc.lxf[xfi], pos, rng, v, n, p);
+    sample_light_leaf<false>(sc, shape, first, count, &sc.lxf[xfi], pos, rng, v, n, p, tab);
     p *= pick;
 }
 template <bool GROUPS>
 RPT_DEV void illuminate_object(const SceneView& sc, const Light& L, V pos, Rng& rng, V& intensity, V& wi,
-                               float& dist) {
+                               float& dist, const LdsTables& tab = LdsTables{}) {
     V v, n;
     float p;
-    sample_light_shape<GROUPS>(sc, L, pos, rng, v, n, p);
+    sample_light_shape<GROUPS>(sc, L, pos, rng, v, n, p, tab);
     V disp = v - pos;
     float len2 = dot(disp, disp);
     float ilen = rsq(len2);

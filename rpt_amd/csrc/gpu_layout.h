@@ -167,6 +167,7 @@ struct SceneView {
     const Material* mats;  uint32_t n_obj;   // one material record per scene object
     const Light* lights;   uint32_t n_lights;
     const LightTri* ltris; const LightXf* lxf; const LightPart* lparts; uint32_t n_lparts;  // n_lparts != 0: some Light::Object is a group
+    uint32_t n_ltris;
     // medium (media[0]); has_medium = 0: surface-only branch
     uint32_t has_medium, medium_kind;
     float sigma_a, sigma_s;

@@ -95,8 +95,8 @@ RPT_DEV void stage_distance(Rng& rng, float inv_sigma_t, float& dmed, float& t) 
 // The event at a medium point or a surface hit: position, what shading needs, emission (src/renderer.rs:207-216,
 // 243-255, 289-299).
 template <bool COUNT>
-RPT_DEV void stage_event(const RenderArgs& a, V ro, V rd, uint32_t depth, bool medium, float dmed, float t, uint32_t code,
-                         uint32_t inst, V& x, V& n, V& mcol, Mat& mat, V& E) {
+RPT_DEV void stage_event(const RenderArgs& a, const LdsTables& tab, V ro, V rd, uint32_t depth, bool medium, float dmed, float t,
+                         uint32_t code, uint32_t inst, V& x, V& n, V& mcol, Mat& mat, V& E) {
     const SceneView& sc = a.sc;
     if (medium) {
         SECT(5);
@@ -109,7 +109,7 @@ RPT_DEV void stage_event(const RenderArgs& a, V ro, V rd, uint32_t depth, bool m
         uint32_t obj;
         SECT(6);
         finalize_hit(sc, ro, rd, ray_tmin(ro), t, code, inst, n, obj);
-        mat = load_mat(sc, obj);
+        mat = load_mat(sc, obj, tab);
         x = fma3(t, rd, ro);
         E = (depth == 0) ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
     }
@@ -190,6 +190,19 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
     constexpr uint32_t kStateBase = BVH ? kStackRows * 256u : 0u;  // dwords: after the traversal stack
     uint32_t* const ls = dyn_lds + kStateBase + threadIdx.x;  // [slots][256] dwords, one column per lane
     enum { S_SLAB = 0, S_END = 1, S_PIX = 2, S_XN = 3, S_YN = 4, S_S = 5, S_ACC = 6, S_P = 9, S_Q = 12, S_RC = 15, S_MAT = 18, S_N = 24 };
+    // Material and light-triangle tables of small scenes, staged once per block behind the lane state
+    constexpr uint32_t kTabBase = kStateBase + (BVH == 0 ? 18u : 5u) * 256u;   // dwords
+    LdsTables tab;
+    {
+        const F4* const t4 = reinterpret_cast<const F4*>(dyn_lds + kTabBase);
+        F4* const w4 = reinterpret_cast<F4*>(dyn_lds + kTabBase);
+        const uint32_t nm = sc.n_obj <= kLdsMats ? sc.n_obj : 0u, nl = sc.n_ltris <= kLdsLtris ? sc.n_ltris : 0u;
+        for (uint32_t i = threadIdx.x; i < 2u * nm; i += 256u) w4[i] = reinterpret_cast<const F4*>(sc.mats)[i];
+        for (uint32_t i = threadIdx.x; i < 6u * nl; i += 256u) w4[2u * kLdsMats + i] = reinterpret_cast<const F4*>(sc.ltris)[i];
+        __syncthreads();
+        tab.mats = t4; tab.n_mats = nm;
+        tab.ltris = t4 + 2u * kLdsMats; tab.n_ltris = nl;
+    }
     auto in_lds = [](int k) { return BVH == 0 || k <= S_YN; };
     V acc_r = mk(0, 0, 0);
     uint32_t slab_idx_r = 0, s_r = 0, s_end_r = 0, pix_r = 0;
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                     need_path = true;
                     phase = PH_NEW;
                 } else {
-                    stage_event<COUNT>(a, ro, rd, depth, v_medium, v_dmed, q_t, q_code, q_inst, v_x, v_n, v_mcol, v_mat, v_E);
+                    stage_event<COUNT>(a, tab, ro, rd, depth, v_medium, v_dmed, q_t, q_code, q_inst, v_x, v_n, v_mcol, v_mat, v_E);
                     v_li = 0;
                     phase = PH_LIGHT;
                 }
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                         v_E = fma3(xyz(L.color), v_medium ? v_mcol : mat_color(v_mat), v_E);
                     } else if (L.kind == L_OBJECT) {
                         SECT(7);
-                        illuminate_object<GROUPS>(sc, L, v_x, rng, v_I, v_wi, v_dist);
+                        illuminate_object<GROUPS>(sc, L, v_x, rng, v_I, v_wi, v_dist, tab);
                         if (L.twin_object >= 0) {  // the shadow query (see the undeferred body)
                             SECT(8);
                             const float tm = ray_tmin(v_x);
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
 
         V x, n = mk(0, 1, 0), mcol = mk(0, 0, 0), E;
         Mat mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
-        stage_event<COUNT>(a, ro, rd, depth, ev_medium, dmed, t, code, inst, x, n, mcol, mat, E);
+        stage_event<COUNT>(a, tab, ro, rd, depth, ev_medium, dmed, t, code, inst, x, n, mcol, mat, E);
 
         // ---- next-event estimation: sample_lights / sample_lights_for_media
         //      (src/renderer.rs:362-409 / 325-359); lights in scene order fix the draw order.
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                 V I, wi;
                 float dist;
                 SECT(7);
-                illuminate_object<GROUPS>(sc, L, x, rng, I, wi, dist);
+                illuminate_object<GROUPS>(sc, L, x, rng, I, wi, dist, tab);
                 if (L.twin_object >= 0) {
                     SECT(8);
                     float ts = dist * (1.f + 1e-3f);
@@ -694,9 +707,10 @@ __global__ void debug_camera_kernel(const CameraG cam, uint32_t w, uint32_t h, u
 
 // ------------------------------------------------------------------ launchers
 static constexpr size_t kStackBytes = 32u * 256u * sizeof(uint32_t);
-static constexpr size_t kStateBytes = 18u * 256u * sizeof(uint32_t);      // LDS-resident lane state of the scan instantiations
-static constexpr size_t kStateBytesBvh = 5u * 256u * sizeof(uint32_t);   // ... of the tree-walking ones (behind the stack)
-static constexpr size_t kMeshTreeBytes = (21u + 5u) * 256u * sizeof(uint32_t);   // per-mesh-tree kernels: 21 stack rows + lane state
+static constexpr size_t kTabBytes = (2u * 32u + 6u * 8u) * 16u;   // LdsTables: 32 materials + 8 light triangles
+static constexpr size_t kStateBytes = 18u * 256u * sizeof(uint32_t) + kTabBytes;      // LDS-resident lane state of the scan instantiations
+static constexpr size_t kStateBytesBvh = 5u * 256u * sizeof(uint32_t) + kTabBytes;   // ... of the tree-walking ones (behind the stack)
+static constexpr size_t kMeshTreeBytes = (21u + 5u) * 256u * sizeof(uint32_t) + kTabBytes;   // per-mesh-tree kernels: 21 stack rows + lane state
 
 template <bool M, int B, bool C>
 static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t stream) {

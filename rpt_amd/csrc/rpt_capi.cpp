@@ -1373,6 +1373,7 @@ struct Flattener {
         v.lights = (const Light*)(base + o_lights); v.n_lights = uint32_t(lights.size());
         v.ltris = (const LightTri*)(base + o_ltris); v.lxf = (const LightXf*)(base + o_lxf);
         v.lparts = (const LightPart*)(base + o_lparts); v.n_lparts = uint32_t(lparts.size());
+        v.n_ltris = uint32_t(ltris.size());
         v.has_medium = s->media.empty() ? 0u : 1u;
         v.medium_kind = 0;
         v.sigma_a = v.sigma_s = 0.f;
