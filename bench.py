@@ -217,8 +217,8 @@ def parse_args(argv):
     ap.add_argument("--photons", type=int, default=0, help="C4 only: photons shot per step (default: the config's 1,000,000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=0, choices=(0, 1, 2),
-                    help="HIP streams the consecutive steps alternate between (2: the start of a step overlaps the tail of the "
-                         "previous one; 0 = 1 stream on one GPU, where the per-launch kernel time is the figure of merit, 2 on several)")
+                    help="HIP streams the consecutive steps alternate between (2, the default: the start of a step overlaps the tail "
+                         "of the previous one, as consecutive batches of an iterative render do; 1: strictly one launch at a time)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl) even with one rank, to rehearse the N > 1 code path")
     ap.add_argument("--dryrun-cpu", action="store_true",
@@ -272,7 +272,7 @@ def main(argv=None):
     # the timed region.
     frames = [torch.zeros(width * height * 3, dtype=torch.float64, device="cuda") for _ in range(2)]
     if args.streams == 0:
-        args.streams = 2 if world > 1 else 1
+        args.streams = 2   # consecutive steps alternate between two streams: the start of one overlaps the tail of the other
     streams = [torch.cuda.Stream() for _ in range(2)]
     d_out = frames[0]
     pending = [None, None]
@@ -370,9 +370,14 @@ def main(argv=None):
     overlapped = args.streams == 2 and not photon
     k_src = "HIP events around each launch"
     if overlapped:
-        # two launches are in flight: the events of one span its wait for the CUs the other still holds, so the
-        # per-launch figure is the step time (an upper bound of the kernel's own time; the resolve is inside it)
-        k_ms, k_src = ms_per_step, "step time (launches overlap on two streams)"
+        # two launches were in flight during the timed region: the events of one span its wait for the CUs the other
+        # still holds.  The kernel's own duration is measured on a few launches that follow each other on one stream
+        # (the host-resident pass above has already read, and thereby reset, the event ring).
+        for _ in range(3):
+            r._sample_offset = 0
+            r.sample_device(spp, frames[0].data_ptr(), stream)
+        torch.cuda.synchronize()
+        k_ms, k_src = r.timing_mean()[0], "HIP events around 3 launches on one stream, after the timed region (its launches overlap on two)"
     pmc, pmc_path = pmc_profile(args.workload, width, height, spp, world, n_photons)
     issue, lanes, wait = issue_view(pmc, k_ms)
     compulsory = n_owned_px * 12.0   # fp32 RGB per owned pixel, written once
