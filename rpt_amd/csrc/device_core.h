@@ -383,14 +383,28 @@ RPT_DEV void scan_prims(const SceneView& sc, V o, V d, float tmin, float& tbest,
         if (t >= 0.f && t < tbest) { tbest = t; code = (K_SPHERE << 28) | i; }
     }
     bit += sc.n_sph;
-    for (uint32_t i = 0; i < sc.n_cub; i++) {
-        if (!on(i)) continue;
-        const XfScan x = uload(&sc.cub[i]);
-        V ol, dl;
-        to_local(x, o, d, ol, dl);
-        uint32_t f;
-        float t = hit_cube<false>(ol, dl, tmin, f);
-        if (t >= 0.f && t < tbest) { tbest = t; code = (K_CUBE << 28) | i; }
+    {   // two records per iteration: independent instruction streams for the scheduler (unmasked scans)
+        uint32_t i = 0;
+        if (!MASKED)
+            for (; i + 1u < sc.n_cub; i += 2u) {
+                const XfScan x0 = uload(&sc.cub[i]), x1 = uload(&sc.cub[i + 1u]);
+                V ol0, dl0, ol1, dl1;
+                to_local(x0, o, d, ol0, dl0);
+                to_local(x1, o, d, ol1, dl1);
+                uint32_t f;
+                const float t0 = hit_cube<false>(ol0, dl0, tmin, f), t1 = hit_cube<false>(ol1, dl1, tmin, f);
+                if (t0 >= 0.f && t0 < tbest) { tbest = t0; code = (K_CUBE << 28) | i; }
+                if (t1 >= 0.f && t1 < tbest) { tbest = t1; code = (K_CUBE << 28) | (i + 1u); }
+            }
+        for (; i < sc.n_cub; i++) {
+            if (!on(i)) continue;
+            const XfScan x = uload(&sc.cub[i]);
+            V ol, dl;
+            to_local(x, o, d, ol, dl);
+            uint32_t f;
+            float t = hit_cube<false>(ol, dl, tmin, f);
+            if (t >= 0.f && t < tbest) { tbest = t; code = (K_CUBE << 28) | i; }
+        }
     }
     bit += sc.n_cub;
     for (uint32_t i = 0; i < sc.n_pln; i++) {
@@ -402,12 +416,23 @@ RPT_DEV void scan_prims(const SceneView& sc, V o, V d, float tmin, float& tbest,
     if (sc.n_aabb + n_rect + sc.has_shell != 0) {  // wave-uniform: these kinds share one reciprocal direction per ray
         const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
         if (sc.has_shell) hit_shell(uload(sc.shell), o, inv, tmin, tbest, code);
-        for (uint32_t i = 0; i < sc.n_aabb; i++) {
-            if (!on(i)) continue;
-            const AabbScan b = uload(&sc.aabb[i]);
-            uint32_t f;
-            float t = hit_aabb<false>(b.lo, b.hi, o, inv, tmin, f);
-            if (t >= 0.f && t < tbest) { tbest = t; code = (K_AABB << 28) | i; }
+        {
+            uint32_t i = 0;
+            if (!MASKED)
+                for (; i + 1u < sc.n_aabb; i += 2u) {
+                    const AabbScan b0 = uload(&sc.aabb[i]), b1 = uload(&sc.aabb[i + 1u]);
+                    uint32_t f;
+                    const float t0 = hit_aabb<false>(b0.lo, b0.hi, o, inv, tmin, f), t1 = hit_aabb<false>(b1.lo, b1.hi, o, inv, tmin, f);
+                    if (t0 >= 0.f && t0 < tbest) { tbest = t0; code = (K_AABB << 28) | i; }
+                    if (t1 >= 0.f && t1 < tbest) { tbest = t1; code = (K_AABB << 28) | (i + 1u); }
+                }
+            for (; i < sc.n_aabb; i++) {
+                if (!on(i)) continue;
+                const AabbScan b = uload(&sc.aabb[i]);
+                uint32_t f;
+                float t = hit_aabb<false>(b.lo, b.hi, o, inv, tmin, f);
+                if (t >= 0.f && t < tbest) { tbest = t; code = (K_AABB << 28) | i; }
+            }
         }
         bit += sc.n_aabb;
         uint32_t i = 0;
