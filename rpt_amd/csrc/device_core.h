@@ -59,6 +59,18 @@ RPT_DEV T uload(const T* p) {
     return out;
 }
 
+// The scene view as it lies in the kernel-argument segment.  EVERY kernel of this library takes its arguments as one
+// struct that begins with the SceneView (RenderArgs, QueryArgs, ShootArgs, intersect_kernel's first parameter: static
+// asserts next to each), so kernarg + 0 is the view.  Reading a field through this pointer -- constant address space,
+// behind an opaque copy of the pointer -- is a scalar load at the place of use; read as a plain kernel argument it is
+// hoisted to the kernel's entry and held in a scalar register for the kernel's whole life.
+typedef const __attribute__((address_space(4))) SceneView* KernargView;
+RPT_DEV KernargView kernarg_scene() {
+    KernargView kv = (KernargView)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kv));
+    return kv;
+}
+
 // ------------------------------------------------------------------ RNG
 // xoshiro128+ seeded through splitmix64 from (seed, pixel, sample); bit-identical to the
 // oracle's Rng.  Replaces StdRng::from_entropy() per row (src/renderer.rs:163).
@@ -371,7 +383,13 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
 // MASKED: bit i of `mask` (wave-uniform) says whether bounded record i -- numbered in scan order: spheres, cubes,
 // boxes, rectangles, triangles, as in SceneView::pbox -- can be hit at all; planes and the shell are always tested.
 template <bool MASKED = false>
-RPT_DEV void scan_prims(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint64_t mask = ~0ull) {
+RPT_DEV void scan_prims(const SceneView& scene, V o, V d, float tmin, float& tbest, uint32_t& code, uint64_t mask = ~0ull) {
+    // The scene view is a kernel argument (every caller passes its kernarg struct): its fields are read HERE, through the
+    // constant address space, behind an opaque copy of the pointer.  Read as plain kernel arguments they are all hoisted to
+    // the kernel's entry and held in scalar registers for its whole life -- the render kernels have ~110 such values, the
+    // compiler parks the overflow in VGPR lanes, and 14 % of their VALU instructions were v_readlane / v_writelane.
+    const auto& sc = *kernarg_scene();
+    (void)scene;
     uint32_t bit = 0;  // wave-uniform record number
     auto on = [&](uint32_t i) { return !MASKED || ((mask >> ((bit + i) & 63u)) & 1ull) != 0ull; };
     for (uint32_t i = 0; i < sc.n_sph; i++) {
