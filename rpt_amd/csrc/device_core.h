@@ -277,9 +277,10 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
 // One primitive of a BVH_PRIMS leaf (per lane: kinds may differ between lanes).  `stk`/`cap`:
 // the part of the lane's stack column above the caller's entries, for the nested walk of an instance.
 template <bool COUNT>
-RPT_DEV void hit_prim(const SceneView& sc, uint32_t pc, V o, V d, V inv, float tmin, float& tbest, uint32_t& code,
+RPT_DEV void hit_prim(const SceneView& scene_, uint32_t pc, V o, V d, V inv, float tmin, float& tbest, uint32_t& code,
                       uint32_t& inst, uint32_t* stk, uint32_t stride, uint32_t cap, uint32_t& c_nodes,
                       uint32_t& c_tris) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     const uint32_t kind = pc >> 28, i = pc & 0x0FFFFFFFu;
     float t = -1.f;
     if (kind == K_INST) {
@@ -288,7 +289,7 @@ RPT_DEV void hit_prim(const SceneView& sc, uint32_t pc, V o, V d, V inv, float t
         const V dl = mk(dot3(r.r0, d), dot3(r.r1, d), dot3(r.r2, d));   // not renormalised: t is shared
         uint32_t c2 = CODE_MISS, unused = 0;
         float tb = tbest;
-        bvh_traverse<COUNT, false>(sc, __float_as_uint(r.n1.w), ol, dl, tmin, tb, c2, unused, stk, stride, cap, c_nodes,
+        bvh_traverse<COUNT, false>(scene_, __float_as_uint(r.n1.w), ol, dl, tmin, tb, c2, unused, stk, stride, cap, c_nodes,
                                    c_tris);
         if (c2 != CODE_MISS) { tbest = tb; code = (K_INSTTRI << 28) | (c2 & 0x0FFFFFFFu); inst = i; }
         return;
@@ -321,9 +322,10 @@ RPT_DEV void hit_prim(const SceneView& sc, uint32_t pc, V o, V d, V inv, float t
 }
 
 template <bool COUNT, bool PRIMS, bool ANY>
-RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tmin, float& tbest, uint32_t& code,
+RPT_DEV void bvh_traverse(const SceneView& scene_, uint32_t root, V o, V d, float tmin, float& tbest, uint32_t& code,
                           uint32_t& inst, uint32_t* stk, uint32_t stride, uint32_t cap, uint32_t& c_nodes,
                           uint32_t& c_tris, AnyHit any) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     const BvhNode* nodes = sc.nodes;
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
     const uint32_t kDone = 0xFFFFFFFFu;  // a 32-item prim leaf at the last index never occurs
@@ -357,7 +359,7 @@ RPT_DEV void bvh_traverse(const SceneView& sc, uint32_t root, V o, V d, float tm
             if (PRIMS && (cur & BVH_PRIMS)) {
                 for (uint32_t i = 0; i < count; i++) {
                     if (COUNT) c_tris++;
-                    hit_prim<COUNT>(sc, sc.pleaf[first + i], o, d, inv, tmin, tbest, code, inst, stk + sp * stride, stride,
+                    hit_prim<COUNT>(scene_, sc.pleaf[first + i], o, d, inv, tmin, tbest, code, inst, stk + sp * stride, stride,
                                     cap - sp, c_nodes, c_tris);
                 }
             } else {
@@ -486,7 +488,8 @@ RPT_DEV void scan_prims(const SceneView& scene, V o, V d, float tmin, float& tbe
 // Which scanned records can a query touch that stays inside the ball (c, r) of each live lane?  Wave-uniform mask
 // for scan_prims<true> (the union over the lanes: one lane's ball reaching a box keeps that record for all of them).
 // Scenes with more than 64 bounded scan records do not occur (from 64 on, the scene-level tree takes over).
-RPT_DEV uint64_t scan_mask_for_ball(const SceneView& sc, bool live, V c, float r) {
+RPT_DEV uint64_t scan_mask_for_ball(const SceneView& scene_, bool live, V c, float r) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     const uint32_t n = sc.n_sph + sc.n_cub + sc.n_aabb + sc.n_rect_x + sc.n_rect_y + sc.n_rect_z + sc.n_tri;
     if (n > 64u) return ~0ull;
     const float r2 = r * r;
@@ -502,7 +505,8 @@ RPT_DEV uint64_t scan_mask_for_ball(const SceneView& sc, bool live, V c, float r
 }
 // Would a walk of the per-mesh trees visit anything?  The two child boxes of every mesh root against the
 // interval the scan left (scalar loads: the roots are wave-uniform).
-RPT_DEV bool mesh_roots_hit(const SceneView& sc, V o, V d, float tmin, float tbest) {
+RPT_DEV bool mesh_roots_hit(const SceneView& scene_, V o, V d, float tmin, float tbest) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
     bool need = false;
     for (uint32_t i = 0; i < sc.n_mesh; i++) {
@@ -516,12 +520,13 @@ RPT_DEV bool mesh_roots_hit(const SceneView& sc, V o, V d, float tmin, float tbe
     return need;
 }
 template <bool COUNT, bool ANY>
-RPT_DEV void walk_meshes(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
+RPT_DEV void walk_meshes(const SceneView& scene_, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
                          uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris, AnyHit any) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     for (uint32_t i = 0; i < sc.n_mesh; i++) {
         const MeshRef m = uload(&sc.meshes[i]);
         if (ANY && code != CODE_MISS && any.blocks(tbest, code)) break;  // (per lane) already occluded
-        bvh_traverse<COUNT, false, ANY>(sc, m.root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
+        bvh_traverse<COUNT, false, ANY>(scene_, m.root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
     }
 }
 // The same walk as a resumable one (deferred walks of the render kernel): the lane's position -- current entry,
@@ -532,12 +537,13 @@ static const uint32_t kWalkDone = 0xFFFFFFFFu;  // has the leaf bit set; a 32-it
 struct WalkState {
     uint32_t cur, sp, mesh;
 };
-RPT_DEV WalkState walk_begin(const SceneView& sc) { return WalkState{uload(&sc.meshes[0]).root, 0u, 0u}; }
+RPT_DEV WalkState walk_begin(const SceneView&) { return WalkState{uload(&kernarg_scene()->meshes[0]).root, 0u, 0u}; }
 // `cap`: rows of the stack column (a mesh tree is at most bvh_max_depth = 20 levels deep: it pushes at most 19 entries).
 template <bool COUNT>
-RPT_DEV void walk_meshes_resumable(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t* stk,
+RPT_DEV void walk_meshes_resumable(const SceneView& scene_, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t* stk,
                                    uint32_t stride, WalkState& w, uint32_t min_active, AnyHit any, uint32_t& c_nodes,
                                    uint32_t& c_tris, uint32_t cap = 32u) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     const BvhNode* nodes = sc.nodes;
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
     uint32_t cur = w.cur, sp = w.sp, mesh = w.mesh;
@@ -594,25 +600,27 @@ RPT_DEV void walk_meshes_resumable(const SceneView& sc, V o, V d, float tmin, fl
 
 // BVH: 0 = no tree in the scene, 1 = per-mesh trees only, 2 = scene-level tree possible.
 template <int BVH, bool COUNT, bool ANY = false>
-RPT_DEV void closest_hit(const SceneView& sc, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
+RPT_DEV void closest_hit(const SceneView& scene_, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
                          uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris,
                          AnyHit any = AnyHit{-kInf, 1u, 0u}) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     if (BVH == 2 && sc.scene_bvh) {  // wave-uniform: planes (unbounded) are scanned, everything else is in the tree
         for (uint32_t i = 0; i < sc.n_pln; i++) {
             const F4 nv = uload(&sc.pln[i]).nv;
             float t = hit_plane(nv, o, d, tmin);
             if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
         }
-        bvh_traverse<COUNT, true, ANY>(sc, sc.top_root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
+        bvh_traverse<COUNT, true, ANY>(scene_, sc.top_root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
         return;
     }
-    scan_prims(sc, o, d, tmin, tbest, code);
-    if (BVH) walk_meshes<COUNT, ANY>(sc, o, d, tmin, tbest, code, inst, stk, stride, c_nodes, c_tris, any);
+    scan_prims(scene_, o, d, tmin, tbest, code);
+    if (BVH) walk_meshes<COUNT, ANY>(scene_, o, d, tmin, tbest, code, inst, stk, stride, c_nodes, c_tris, any);
 }
 
 // Normal and object of the winning primitive (per lane).
-RPT_DEV void finalize_hit(const SceneView& sc, V o, V d, float tmin, float t, uint32_t code, uint32_t inst, V& n,
+RPT_DEV void finalize_hit(const SceneView& scene_, V o, V d, float tmin, float t, uint32_t code, uint32_t inst, V& n,
                           uint32_t& obj) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     uint32_t kind = code >> 28, idx = code & 0x0FFFFFFFu;
     if (kind == K_INSTTRI) {  // src/shape/mesh.rs:78 in the instance's space, then src/shape.rs:131-134
         const InstRec r = sc.inst[inst];
@@ -707,7 +715,8 @@ struct LdsTables {
     uint32_t n_ltris = 0;
 };
 static constexpr uint32_t kLdsMats = 32, kLdsLtris = 8;   // 32 x 32 B + 8 x 96 B = 1.75 KB per block
-RPT_DEV Mat load_mat(const SceneView& sc, uint32_t obj, const LdsTables& tab = LdsTables{}) {
+RPT_DEV Mat load_mat(const SceneView& scene_, uint32_t obj, const LdsTables& tab = LdsTables{}) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     Material m;
     if (obj < tab.n_mats) {   // wave-uniform in effect: either every object's material is staged or none
         m.albedo_emit = tab.mats[2u * obj];
@@ -830,8 +839,9 @@ template <> struct LightXfRows<false> {
 };
 // One leaf shape of a Light::Object (Sphere/Cube/Mesh::sample under Transformed::sample, src/shape.rs:140-151).
 template <bool UNIFORM>
-RPT_DEV void sample_light_leaf(const SceneView& sc, uint32_t shape, uint32_t first, uint32_t count, const LightXf* xp,
+RPT_DEV void sample_light_leaf(const SceneView& scene_, uint32_t shape, uint32_t first, uint32_t count, const LightXf* xp,
                                V pos, Rng& rng, V& v, V& n, float& p, const LdsTables& tab = LdsTables{}) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     V vl, nl;
     const LightXfRows<UNIFORM> x(xp);
     const bool xf = x.nrm(1).w != 0.f;
@@ -894,10 +904,11 @@ RPT_DEV void sample_light_leaf(const SceneView& sc, uint32_t shape, uint32_t fir
 // Shape::sample of a Light::Object.  A KdTree group (src/kdtree.rs:141-146) samples a uniformly chosen child and
 // divides its pdf by the child count, nested groups repeat that: every lane descends to its own leaf.
 template <bool GROUPS>
-RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng& rng, V& v, V& n, float& p,
+RPT_DEV void sample_light_shape(const SceneView& scene_, const Light& L, V pos, Rng& rng, V& v, V& n, float& p,
                                 const LdsTables& tab = LdsTables{}) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     if (!GROUPS || L.shape != LS_GROUP) {  // wave-uniform
-        sample_light_leaf<true>(sc, L.shape, L.first, L.count, &sc.lxf[L.xf], pos, rng, v, n, p, tab);
+        sample_light_leaf<true>(scene_, L.shape, L.first, L.count, &sc.lxf[L.xf], pos, rng, v, n, p, tab);
         return;
     }
     uint32_t shape = LS_GROUP, first = L.first, count = L.count, xfi = 0;
@@ -908,7 +919,7 @@ RPT_DEV void sample_light_shape(const SceneView& sc, const Light& L, V pos, Rng&
         const LightPart part = sc.lparts[first + idx];
         shape = part.shape; first = part.first; count = part.count; xfi = part.xf;
     }
-    sample_light_leaf<false>(sc, shape, first, count, &sc.lxf[xfi], pos, rng, v, n, p, tab);
+    sample_light_leaf<false>(scene_, shape, first, count, &sc.lxf[xfi], pos, rng, v, n, p, tab);
     p *= pick;
 }
 template <bool GROUPS>
@@ -929,7 +940,8 @@ RPT_DEV void illuminate_object(const SceneView& sc, const Light& L, V pos, Rng& 
 
 // ------------------------------------------------------------------ environment
 // Environment::get_color, src/environment.rs:72-77; Hdri::get_color / bilinear_sample :25-52.
-RPT_DEV V env_color(const SceneView& sc, V dir) {
+RPT_DEV V env_color(const SceneView& scene_, V dir) {
+    const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     if (sc.hdri_w == 0) return mk(sc.env[0], sc.env[1], sc.env[2]);
     const V d = normalize(dir);
     const float azimuth = atan2f(d.z, d.x) + kPi;
