@@ -70,6 +70,27 @@ RPT_DEV KernargView kernarg_scene() {
     asm volatile("" : "+s"(kv));
     return kv;
 }
+// A sub-struct of the kernel arguments by value (dword loads through the constant address space).
+template <class T>
+RPT_DEV T kernarg_load(const __attribute__((address_space(4))) T* p) {
+    static_assert(sizeof(T) % 4 == 0, "kernel-argument structs are dword multiples");
+    typedef const __attribute__((address_space(4))) uint32_t* Q;
+    Q q = (Q)p;
+    uint32_t raw[sizeof(T) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) raw[i] = q[i];
+    T out;
+    __builtin_memcpy(&out, raw, sizeof(T));
+    return out;
+}
+// The same for a kernel's whole argument struct T (it lies at kernarg + 0).
+template <class T>
+RPT_DEV const __attribute__((address_space(4))) T* kernarg_args() {
+    typedef const __attribute__((address_space(4))) T* P;
+    P p = (P)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
 
 // ------------------------------------------------------------------ RNG
 // xoshiro128+ seeded through splitmix64 from (seed, pixel, sample); bit-identical to the

@@ -254,9 +254,10 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
         // (One atomic per lane-pull saturated the counter at ~80 M dequeues/s: profiles/r01.)
         bool want = alive && need_path && item_done;
         if (__any(want)) {
+            const auto& ka = *kernarg_args<RenderArgs>();   // item bookkeeping reads its arguments here, not from registers held since kernel entry
             SECT(0);
             if (want && have_item) {
-                reinterpret_cast<float4*>(a.slab)[ldu(S_SLAB, slab_idx_r)] =
+                reinterpret_cast<float4*>(ka.slab)[ldu(S_SLAB, slab_idx_r)] =
                     make_float4(ldf(S_ACC + 0, acc_r.x), ldf(S_ACC + 1, acc_r.y), ldf(S_ACC + 2, acc_r.z), 0.f);
                 have_item = false;
             }
@@ -276,23 +277,23 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                         base = (unsigned long long)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 64ull;
                         first_batch = false;
                     } else if (!drained && (threadIdx.x & 63u) == 0) {
-                        base = atomicAdd(a.queue, 64ull);
+                        base = atomicAdd(ka.queue, 64ull);
                     }
                     const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(base));
                     const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(base >> 32));
-                    if (hi != 0 || lo >= a.n_items) {
+                    if (hi != 0 || lo >= ka.n_items) {
                         drained = true;  // queue exhausted: the waiting lanes retire
                         if (want) alive = false;
                         break;
                     }
                     pool_next = lo;
-                    pool_end = min(lo + 64u, a.n_items);
+                    pool_end = min(lo + 64u, ka.n_items);
                     // a batch is 64-aligned and n_owned is a multiple of 1024: its 64 items are one 8x8 pixel
                     // block of one chunk, so the decode (two divisions, a table load) is done once, wave-uniformly
-                    pool_chunk = lo / a.n_owned;
-                    const uint32_t p0 = lo - pool_chunk * a.n_owned;
-                    const uint32_t tile = a.tiles[p0 >> 10], sb = (p0 & 1023u) >> 6;
-                    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+                    pool_chunk = lo / ka.n_owned;
+                    const uint32_t p0 = lo - pool_chunk * ka.n_owned;
+                    const uint32_t tile = ka.tiles[p0 >> 10], sb = (p0 & 1023u) >> 6;
+                    const uint32_t ty = tile / ka.tiles_x, tx = tile - ty * ka.tiles_x;
                     pool_x0 = __builtin_amdgcn_readfirstlane(tx * 32u + (sb & 3u) * 8u);
                     pool_y0 = __builtin_amdgcn_readfirstlane(ty * 32u + (sb >> 2) * 8u);
                     pool_chunk = __builtin_amdgcn_readfirstlane(pool_chunk);
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                 if (got) {
                     const uint32_t chunk = pool_chunk, l = item & 63u;
                     const uint32_t x = pool_x0 + (l & 7u), y = pool_y0 + (l >> 3);
-                    if (x < a.width && y < a.height) {  // slots of clipped tiles lie outside the image
+                    if (x < ka.width && y < ka.height) {  // slots of clipped tiles lie outside the image
                         want = false;
                         have_item = true;
                         item_done = false;
@@ -313,25 +314,27 @@ __global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT
                         stf(S_ACC + 0, acc_r.x, 0.f);
                         stf(S_ACC + 1, acc_r.y, 0.f);
                         stf(S_ACC + 2, acc_r.z, 0.f);
-                        const uint32_t s0 = chunk * a.chunk_spp;
+                        const uint32_t s0 = chunk * ka.chunk_spp;
                         stu(S_S, s_r, s0);
-                        stu(S_END, s_end_r, min(s0 + a.chunk_spp, a.iterations));
-                        stu(S_PIX, pix_r, y * a.width + x);
+                        stu(S_END, s_end_r, min(s0 + ka.chunk_spp, ka.iterations));
+                        stu(S_PIX, pix_r, y * ka.width + x);
                         // src/renderer.rs:174-176
-                        stf(S_XN, xn_r, (float(2u * x + 1u) - float(a.width)) * a.inv_dim);
-                        stf(S_YN, yn_r, (float(2u * (a.height - y) - 1u) - float(a.height)) * a.inv_dim);
+                        stf(S_XN, xn_r, (float(2u * x + 1u) - float(ka.width)) * ka.inv_dim);
+                        stf(S_YN, yn_r, (float(2u * (ka.height - y) - 1u) - float(ka.height)) * ka.inv_dim);
                     }
                 }
             }
         }
         if (need_path && alive) {
             if (alive) {  // src/renderer.rs:179-181
+                const auto& ka = *kernarg_args<RenderArgs>();
                 SECT(1);
                 const uint32_t s = ldu(S_S, s_r);
-                rng.seed(a.seed_mixed, ldu(S_PIX, pix_r), a.sample_offset + s);
-                float dx = rng.range(-a.inv_dim, a.inv_dim);
-                float dy = rng.range(-a.inv_dim, a.inv_dim);
-                cast_ray(a.cam, ldf(S_XN, xn_r) + dx, ldf(S_YN, yn_r) + dy, rng, ro, rd);
+                rng.seed(ka.seed_mixed, ldu(S_PIX, pix_r), ka.sample_offset + s);
+                float dx = rng.range(-ka.inv_dim, ka.inv_dim);
+                float dy = rng.range(-ka.inv_dim, ka.inv_dim);
+                const CameraG cam = kernarg_load(&ka.cam);
+                cast_ray(cam, ldf(S_XN, xn_r) + dx, ldf(S_YN, yn_r) + dy, rng, ro, rd);
                 depth = 0;
                 if constexpr (BVH == 0) {
                     stv(S_P, P, mk(0, 0, 0));
