@@ -777,6 +777,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     extern __shared__ uint32_t dyn_lds[];
     const RenderArgs& a = q.r;
     const SceneView& sc = a.sc;
+    const SceneView& sc_arg = a.sc;   // what the device functions are handed (they read the view from the kernarg segment themselves)
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
     const uint32_t K = max(q.gather_size, q.gather_size_volume);  // LDS columns are sized for the larger gather
     // One wave-private LDS region (after the BVH stack) serves two phases that never overlap in time
@@ -815,6 +816,11 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     uint32_t pi = 64u, blk = 0, chunk = 0, x0 = 0, y0 = 0, n_s = 0;  // wave-uniform: pixel cursor within the block, item
     const V cam_right = mk(a.cam.right[0], a.cam.right[1], a.cam.right[2]), cam_up = mk(a.cam.up[0], a.cam.up[1], a.cam.up[2]);
     for (;;) {
+        // the kernel's arguments are read per trip, where they are used (kernarg_scene in device_core.h): held in scalar
+        // registers since kernel entry they do not fit, and the overflow lives in VGPR lanes
+        const auto& q = *kernarg_args<QueryArgs>();
+        const auto& a = q.r;
+        const auto& sc = a.sc;
         if (pi == 64u) {  // next work item (wave-uniform)
             unsigned long long got = ~0ull;
             if (lane_ == 0) got = atomicAdd(a.queue, 1ull);
@@ -875,10 +881,10 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             rng.seed(a.seed_mixed, pix, a.sample_offset + chunk * 64u + lane_);
             c_samp++;
             float dx = rng.range(-a.inv_dim, a.inv_dim), dy = rng.range(-a.inv_dim, a.inv_dim);
-            cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
+            cast_ray(kernarg_load(&a.cam), xn + dx, yn + dy, rng, ro, rd);
             wo = -normalize(rd);
             tmin = ray_tmin_p(ro);
-            closest_hit<(BVH ? 2 : 0), false>(sc, ro, rd, tmin, t, code, inst, stk, 256, c0, c1);
+            closest_hit<(BVH ? 2 : 0), false>(sc_arg, ro, rd, tmin, t, code, inst, stk, 256, c0, c1);
         }
         const bool hit = code != CODE_MISS;
         V color = mk(0, 0, 0);
@@ -1023,12 +1029,12 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             }
             color = vc * mcol0;
         }
-        if (active && !hit && !MEDIUM) color = env_color(sc, rd);  // src/photon.rs:597
+        if (active && !hit && !MEDIUM) color = env_color(sc_arg, rd);  // src/photon.rs:597
         if (active && surface_on && !(q.skip & 2u)) {  // surface estimate, src/photon.rs:327-375
             V n;
             uint32_t obj;
-            finalize_hit(sc, ro, rd, tmin, t, code, inst, n, obj);
-            const Mat mat = load_mat(sc, obj);
+            finalize_hit(sc_arg, ro, rd, tmin, t, code, inst, n, obj);
+            const Mat mat = load_mat(sc_arg, obj);
             const V x = fma3(t, rd, ro);
             // Consecutive samples of a lane fall within a pixel of each other: the previous gather radius
             // (squared, doubled) bounds this search from its first node; the rare miss is searched again.
@@ -1047,7 +1053,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             // The closest hit below |disp| (1 - 1e-3) is the closest hit of the unbounded query whenever that one
             // would block, so the decisions are the same as with the full scan.
             uint64_t vis_mask = ~0ull;
-            if (!BVH) vis_mask = scan_mask_for_ball(sc, true, x, __builtin_sqrtf(max_d2) * (1.f + 1e-4f) + 1e-6f);
+            if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, true, x, __builtin_sqrtf(max_d2) * (1.f + 1e-4f) + 1e-6f);
             for (uint32_t k = 0; k < found; k++) {
                 const PhotonRec ph = q.s_ph[gi[k * 64u]];
                 V disp = x - xyz(ph.pos_r);
@@ -1059,8 +1065,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 float ts = BVH ? kInf : len * (1.f - 1e-3f);
                 uint32_t cs = CODE_MISS, is = 0;
                 if (!(q.skip & 8u)) {  // diagnostic: 8 = no visibility scans
-                    if (BVH) closest_hit<2, false>(sc, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
-                    else scan_prims<true>(sc, po, pd, ray_tmin_p(po), ts, cs, vis_mask);
+                    if (BVH) closest_hit<2, false>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
+                    else scan_prims<true>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, vis_mask);
                 }
                 // A hit inside the query point's own tangent plane is the grazing ray meeting its own surface: fp64
                 // rejects it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
