@@ -56,7 +56,11 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 #define RPT_MIN_WAVES_MESH 4  // per-mesh-tree instantiations (BVH = 1)
 #endif
 #ifndef RPT_MIN_WAVES_SCAN
-#define RPT_MIN_WAVES_SCAN 5  // linear-scan instantiations (BVH = 0): 96 VGPRs; the kernel is latency-bound
+#define RPT_MIN_WAVES_SCAN 5  // linear-scan instantiations (BVH = 0) without a medium: 96 VGPRs
+#endif
+#ifndef RPT_MIN_WAVES_SCAN_MEDIUM
+#define RPT_MIN_WAVES_SCAN_MEDIUM 5  // ... in a medium.  6 (80 VGPRs) renders C3 in 25.3 instead of 26.0 ms but spills 84 B/lane, a scratch
+                                     // footprint just over the XCD's L2: 32 GB of HBM writes per launch instead of 1.1 -- not taken
 #endif
 // Diagnostic sections of the megakernel (COUNT build): per section, counters[8 + 2k] counts wave-level
 // executions and counters[9 + 2k] the lanes active in them (lane utilisation of divergent code).
@@ -165,7 +169,8 @@ RPT_DEV bool stage_bounce(const RenderArgs& a, float albedo_med, V rd, uint32_t 
 // GROUPS: some Light::Object is a KdTree group (per-lane leaf sampler).  A separate instantiation: the extra
 // sampler copy costs the plain kernels 6 % through register allocation alone, and a call costs 6x.
 template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false>
-__global__ __launch_bounds__(256, BVH == 0 ? RPT_MIN_WAVES_SCAN : BVH == 1 ? RPT_MIN_WAVES_MESH : RPT_MIN_WAVES) void render_kernel(const RenderArgs a) {
+__global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : BVH == 1 ? RPT_MIN_WAVES_MESH : RPT_MIN_WAVES)
+void render_kernel(const RenderArgs a) {
     extern __shared__ uint32_t dyn_lds[];
     const SceneView& sc = a.sc;
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
