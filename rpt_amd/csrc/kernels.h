@@ -1,6 +1,7 @@
 // kernels.h — host-callable launchers of the HIP kernels (implemented in kernels.hip).
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <stddef.h>
 #include <stdint.h>
 #include "gpu_layout.h"
 
@@ -28,6 +29,10 @@ struct RenderArgs {
     uint32_t defer_lanes;     // per-mesh-tree kernels: parked tree walks per wave that trigger a walk (1..64)
     uint32_t defer_stop;      // ... and the number of still-walking lanes below which the wave leaves the walk
 };
+
+// The device functions read the scene view at kernarg + 0 (kernarg_scene in device_core.h): every kernel that calls them
+// takes ONE argument struct that begins with the SceneView.
+static_assert(offsetof(RenderArgs, sc) == 0, "RenderArgs must begin with the SceneView");
 
 struct KernelInfo {
     int vgprs, sgprs, lds, max_blocks_per_cu;

@@ -49,6 +49,7 @@ struct ShootArgs {
     PhotonRec* vol;
 };
 
+static_assert(offsetof(ShootArgs, sc) == 0, "kernel arguments begin with the SceneView (kernarg_scene)");
 // shoot_photon + trace_photon, src/photon.rs:724-946.  WRITE = false: count only.
 template <bool MEDIUM, bool BVH, bool WRITE>
 __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
@@ -468,6 +469,7 @@ struct QueryArgs {
     uint32_t* gather;        // GG kernels (gather size > kGatherLds): [waves of the grid][2][K][64] gather lists in global memory
 };
 
+static_assert(offsetof(QueryArgs, r) == 0, "kernel arguments begin with the SceneView (kernarg_scene)");
 // Batched wave-cooperative walk (used when the rays of a wave do not form a packet).  Walking one
 // node at a time costs one dependent memory round trip per node (~3,400 cycles each with 220 MB of
 // nodes + photons far beyond L2: measured 118 ms per-lane, 56 ms wave-uniform for the same pass that
