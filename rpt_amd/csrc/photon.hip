@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "device_core.h"
@@ -467,6 +468,7 @@ struct QueryArgs {
     uint32_t* cand;          // [waves of the grid][cand_cap] candidate photons of each wave's current pixel block
     uint32_t cand_cap;       // 0: no candidate lists (every sample walks the tree)
     uint32_t* gather;        // GG kernels (gather size > kGatherLds): [waves of the grid][2][K][64] gather lists in global memory
+    uint32_t parts;          // work items per (8x8 pixel block, sample chunk): the block's rows in 1, 2, 4 or 8 strips
 };
 
 static_assert(offsetof(QueryArgs, r) == 0, "kernel arguments begin with the SceneView (kernarg_scene)");
@@ -486,6 +488,10 @@ static constexpr uint32_t kBeamCap = 1024;
 static constexpr uint32_t kGatherLds = 56;
 static constexpr uint32_t kGatherMax = 1024;
 static constexpr uint32_t kCandCap = 4096;  // candidate photons one wave keeps per 8x8 pixel block (global memory)
+// Samples of one pixel that a work item of the camera pass handles (four trips of 64 lanes).  The beam x point estimate
+// keeps their rays in LDS ([kSuper] x 16 B per wave) and runs with one PHOTON per lane over them.
+static constexpr uint32_t kSuper = 256;
+static constexpr uint32_t kPendCap = 128;   // culled candidate indices waiting for a full batch of 64 (LDS, per wave)
 template <class G, class F>
 RPT_DEV void beam_walk_batch(const BvhNode* nodes, const PhotonRec* photons, uint32_t n, bool active, V o, V d,
                              uint32_t* wstack, F4* stage, uint32_t* overflow, G&& prep, F&& visit) {
@@ -799,52 +805,63 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     uint32_t c0 = 0, c1 = 0;
     float prev_r2 = 0.f;  // squared radius of this lane's previous surface gather
     unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
-    // Work decomposition of the camera pass: a wave takes one 8x8 pixel block and one chunk of up to 64 samples
-    // at a time and walks through the block's pixels; in each trip its 64 LANES ARE THE SAMPLES OF ONE PIXEL.
-    // The rays of a trip then differ only by their sub-pixel jitter, so the packet frustum of the beam query is
-    // one pixel wide (459 photons accepted of ~480 tested per ray, instead of 1359 tested with one pixel per
-    // lane), the k-nearest walks of the lanes follow the same path through the tree, and pixel, NDC
-    // coordinates and camera basis are wave-uniform.  The 64 sample values of a pixel are summed across the
-    // wave in a fixed butterfly order and stored as that (pixel, chunk)'s partial sum.
+    // Work decomposition of the camera pass: a wave takes a strip of rows of one 8x8 pixel block and one chunk of up
+    // to kSuper samples at a time and walks through the strip's pixels; a pixel's samples are handled 64 at a time:
+    // in each trip the 64 LANES ARE SAMPLES OF ONE PIXEL.  The rays of a trip then differ only by their sub-pixel
+    // jitter, so the k-nearest walks of the lanes follow the same path through the tree, and pixel, NDC coordinates
+    // and camera basis are wave-uniform.  The sample values of a pixel are summed per lane over the trips, then
+    // across the wave in a fixed butterfly order, and stored as that (pixel, chunk)'s partial sum.
     //
-    // Beam x point estimate with a pinhole camera: the photon spheres that reach into the BLOCK's frustum are
-    // found once per work item (one tree walk) and kept in a per-wave list in global memory; each pixel trip
-    // re-culls that list against its own frustum while staging.
+    // Beam x point estimate with a pinhole camera: the photon spheres that reach into the STRIP's frustum are found
+    // once per work item (one tree walk) and kept in a per-wave list in global memory.  For a pixel, the rays of
+    // all its samples are generated first and parked in LDS (direction + squared hit distance, 16 B each); the list
+    // is culled against the pixel's own frustum, and then the roles turn around: ONE PHOTON PER LANE, each lane
+    // holding what depends on its photon and the eye in registers and looping over the pixel's rays (one broadcast
+    // LDS read per test).  The estimate is a sum over (ray, photon) pairs either way; with the samples in the lanes
+    // every test read a 48-byte staged record from LDS (the LDS pipe was as busy as the VALU) and the list was culled
+    // and staged once per 64 samples instead of once per pixel.
     uint32_t* const cand = q.cand_cap ? q.cand + size_t(blockIdx.x * 4u + wave_) * q.cand_cap : nullptr;
     const bool cand_mode = MEDIUM && KIND == RPT_PHOTON_POINT_BEAM && q.cand_cap != 0u && a.cam.aperture <= 0.f && !(q.skip & 1u);
     uint32_t cand_n = 0;       // wave-uniform
-    bool cand_valid = false;   // wave-uniform: the list describes the block this wave is working on
+    bool cand_valid = false;   // wave-uniform: the list describes the strip this wave is working on
     const uint32_t n_blocks64 = a.n_owned >> 6;  // 8x8 blocks owned by this rank
-    uint32_t pi = 64u, blk = 0, chunk = 0, x0 = 0, y0 = 0, n_s = 0;  // wave-uniform: pixel cursor within the block, item
+    uint32_t pi = 0u, pi_end = 0u, blk = 0, chunk = 0, x0 = 0, y0 = 0, n_s = 0;  // wave-uniform: pixel cursor within the block, item
     const V cam_right = mk(a.cam.right[0], a.cam.right[1], a.cam.right[2]), cam_up = mk(a.cam.up[0], a.cam.up[1], a.cam.up[2]);
+    float4* const rays = reinterpret_cast<float4*>(region);   // [kSuper] (direction, squared hit distance) of the pixel's samples
+    uint32_t* const pend_list = region + kSuper * 4u;         // [kPendCap] culled candidates waiting for a full batch
     for (;;) {
         // the kernel's arguments are read per trip, where they are used (kernarg_scene in device_core.h): held in scalar
         // registers since kernel entry they do not fit, and the overflow lives in VGPR lanes
         const auto& q = *kernarg_args<QueryArgs>();
         const auto& a = q.r;
         const auto& sc = a.sc;
-        if (pi == 64u) {  // next work item (wave-uniform)
+        if (pi == pi_end) {  // next work item (wave-uniform)
             unsigned long long got = ~0ull;
             if (lane_ == 0) got = atomicAdd(a.queue, 1ull);
             const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(got));
             const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(got >> 32));
             if (hi != 0 || lo >= a.n_items) break;
-            chunk = lo / n_blocks64;
-            blk = lo - chunk * n_blocks64;
+            const uint32_t per_chunk = n_blocks64 * q.parts;
+            chunk = lo / per_chunk;
+            const uint32_t rem = lo - chunk * per_chunk;
+            blk = rem / q.parts;
+            const uint32_t part = rem - blk * q.parts, per_part = 64u / q.parts;   // whole rows of the block
             const uint32_t tile = a.tiles[blk >> 4], sb = blk & 15u;
             const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
             x0 = __builtin_amdgcn_readfirstlane(tx * 32u + (sb & 3u) * 8u);
             y0 = __builtin_amdgcn_readfirstlane(ty * 32u + (sb >> 2) * 8u);
-            n_s = min(64u, a.iterations - chunk * 64u);
-            pi = 0u;
+            n_s = min(kSuper, a.iterations - chunk * kSuper);
+            pi = __builtin_amdgcn_readfirstlane(part * per_part);
+            pi_end = pi + per_part;
             cand_valid = false;
             if (cand_mode) {
-                // the four corner directions of the block (footprints included): every sample ray lies between them
+                // the four corner directions of the strip (footprints included): every sample ray lies between them
                 const float e = a.inv_dim * 1.0001f;
+                const uint32_t r0 = pi >> 3, r1 = (pi_end - 1u) >> 3;
                 const float xl = (float(2u * x0 + 1u) - float(a.width)) * a.inv_dim - e;
                 const float xh = (float(2u * (x0 + 7u) + 1u) - float(a.width)) * a.inv_dim + e;
-                const float yh = (float(2u * (a.height - y0) - 1u) - float(a.height)) * a.inv_dim + e;
-                const float yl = (float(2u * (a.height - (y0 + 7u)) - 1u) - float(a.height)) * a.inv_dim - e;
+                const float yh = (float(2u * (a.height - (y0 + r0)) - 1u) - float(a.height)) * a.inv_dim + e;
+                const float yl = (float(2u * (a.height - (y0 + r1)) - 1u) - float(a.height)) * a.inv_dim - e;
                 const V eye = mk(a.cam.eye[0], a.cam.eye[1], a.cam.eye[2]);
                 const V dd = mk(a.cam.ddir[0], a.cam.ddir[1], a.cam.ddir[2]);
                 const V corners[4] = {dd + xl * cam_right + yl * cam_up, dd + xh * cam_right + yl * cam_up,
@@ -865,7 +882,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 }
             }
         }
-        // ---- one pixel of the block per trip; lane = sample
+        // ---- one pixel of the strip per trip of this loop
         const uint32_t px = x0 + (pi & 7u), py = y0 + (pi >> 3);
         const uint32_t slab_idx = chunk * a.n_owned + blk * 64u + pi;
         pi++;
@@ -873,21 +890,124 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         const uint32_t pix = py * a.width + px;
         const float xn = (float(2u * px + 1u) - float(a.width)) * a.inv_dim;           // src/renderer.rs:174-176
         const float yn = (float(2u * (a.height - py) - 1u) - float(a.height)) * a.inv_dim;
-        const bool active = lane_ < n_s;
-        V ro = mk(0, 0, 0), rd = mk(0, 0, 1), wo = mk(0, 0, -1);
-        float tmin = 0.f, t = kInf;
-        uint32_t code = CODE_MISS, inst = 0;
-        Rng rng;
-        rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-        if (active) {
-            rng.seed(a.seed_mixed, pix, a.sample_offset + chunk * 64u + lane_);
-            c_samp++;
-            float dx = rng.range(-a.inv_dim, a.inv_dim), dy = rng.range(-a.inv_dim, a.inv_dim);
-            cast_ray(kernarg_load(&a.cam), xn + dx, yn + dy, rng, ro, rd);
-            wo = -normalize(rd);
-            tmin = ray_tmin_p(ro);
-            closest_hit<(BVH ? 2 : 0), false>(sc_arg, ro, rd, tmin, t, code, inst, stk, 256, c0, c1);
+        const uint32_t n_sub = (n_s + 63u) >> 6;   // trips of 64 samples
+        // camera ray of sample (chunk, sub, lane) and its closest hit
+        auto gen_ray = [&](uint32_t sub, Rng& rng, V& ro, V& rd, float& tmin, float& t, uint32_t& code, uint32_t& inst) {
+            const bool active = sub * 64u + lane_ < n_s;
+            ro = mk(0, 0, 0); rd = mk(0, 0, 1); tmin = 0.f; t = kInf; code = CODE_MISS; inst = 0;
+            rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+            if (active) {
+                rng.seed(a.seed_mixed, pix, a.sample_offset + chunk * kSuper + sub * 64u + lane_);
+                float dx = rng.range(-a.inv_dim, a.inv_dim), dy = rng.range(-a.inv_dim, a.inv_dim);
+                cast_ray(kernarg_load(&a.cam), xn + dx, yn + dy, rng, ro, rd);
+                tmin = ray_tmin_p(ro);
+                closest_hit<(BVH ? 2 : 0), false>(sc_arg, ro, rd, tmin, t, code, inst, stk, 256, c0, c1);
+            }
+            return active;
+        };
+        // ---- beam x point estimate, one photon per lane (src/photon.rs:439-502)
+        V beam_sum = mk(0, 0, 0);   // this lane's photons over all the pixel's rays
+        const bool beam_lanes = MEDIUM && KIND == RPT_PHOTON_POINT_BEAM && cand_valid;
+        if (beam_lanes) {
+            float far2 = 0.f;
+            for (uint32_t sub = 0; sub < n_sub; sub++) {
+                Rng rng;
+                V ro, rd;
+                float tmin, t;
+                uint32_t code, inst;
+                const bool active = gen_ray(sub, rng, ro, rd, tmin, t, code, inst);
+                const float t2 = !active ? -1.f : (code != CODE_MISS ? t * t : kInf);   // no photon centre lies within a negative distance
+                rays[sub * 64u + lane_] = make_float4(rd.x, rd.y, rd.z, t2);
+                far2 = fmaxf(far2, t2);
+            }
+            far2 = wave_max(far2);   // farthest hit of the pixel's samples (inf on a miss)
+            // the pixel's own frustum (footprint included) re-culls the strip's candidates
+            const float e = a.inv_dim * 1.0001f;
+            const V dd = mk(a.cam.ddir[0], a.cam.ddir[1], a.cam.ddir[2]);
+            const V eye0 = mk(a.cam.eye[0], a.cam.eye[1], a.cam.eye[2]);  // pinhole: every ray starts here
+            const V corners[4] = {dd + (xn - e) * cam_right + (yn - e) * cam_up, dd + (xn + e) * cam_right + (yn - e) * cam_up,
+                                  dd + (xn - e) * cam_right + (yn + e) * cam_up, dd + (xn + e) * cam_right + (yn + e) * cam_up};
+            Frustum fs;
+            const bool have_fs = frustum_from_dirs(true, eye0, corners, 4, fs);
+            const float phase = sc.medium_phase;
+            // A batch of nb <= 64 culled candidates: lane j takes pend_list[j].  What depends on the photon and the common
+            // origin is computed once per photon -- c = centre - eye, |c|^2, |c|, the power pre-multiplied by 3/pi * phase /
+            // r^2 * exp(-sigma_t |c|) -- and per ray exp(-sigma_t s) = exp(-sigma_t |c|) * exp(sigma_t (|c| - s)) with
+            // sigma_t (|c| - s) <= sigma_t r^2 / |c| ~ 1e-5, so the second factor is 1 + x to fp32 precision
+            // (src/photon.rs:474-493: k2(d^2/r^2)/r^2 with k2(x) = 3/pi (1-x)^2).
+            auto flush = [&](uint32_t nb, auto counting) {
+                if (lane_ < nb) {
+                    const PhotonRec raw = q.v_ph[pend_list[lane_]];
+                    const V c = xyz(raw.pos_r) - eye0;
+                    const float r2 = raw.pos_r.w * raw.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = __builtin_sqrtf(c2);
+                    const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
+                    const V pw = kk * xyz(raw.pow);
+                    const float one_plus = fmaf(sigma_t, len, 1.f);
+                    V acc = mk(0, 0, 0);
+                    uint32_t n_ok = 0;
+                    if (!(q.skip & 4u)) {  // diagnostic: 4 = tree walk, culling and photon preparation only
+#pragma unroll 4
+                        for (uint32_t s = 0; s < n_s; s++) {
+                            const float4 ray = rays[s];
+                            const V rd = mk(ray.x, ray.y, ray.z);
+                            const float disk = dot(c, rd);
+                            const V dv = fma3(disk, rd, -c);
+                            const float dist2 = dot(dv, dv);
+                            const bool ok = disk > 0.f && dist2 < r2 && c2 <= ray.w;
+                            const float tmp = fmaf(-dist2, ir2, 1.f);
+                            const float w = tmp * tmp * fmaf(-sigma_t, disk, one_plus);
+                            acc = fma3(ok ? w : 0.f, pw, acc);
+                            if (decltype(counting)::value) n_ok += ok ? 1u : 0u;
+                        }
+                    }
+                    beam_sum = beam_sum + acc;
+                    if (decltype(counting)::value) { c_leaf += n_s; c_acc += n_ok; }
+                }
+            };
+            auto flush_batch = [&](uint32_t nb) {
+                if (a.counters) flush(nb, std::true_type{});
+                else flush(nb, std::false_type{});
+            };
+            uint32_t pend = 0;   // wave-uniform: entries of pend_list
+            for (uint32_t base = 0; base < cand_n; base += 64u) {  // wave-uniform loop
+                bool take = false;
+                uint32_t idx = 0u;
+                if (base + lane_ < cand_n) {
+                    idx = cand[base + lane_];
+                    const F4 pr = q.v_ph[idx].pos_r;
+                    take = !have_fs || !sphere_outside(fs, pr);
+                    const V cc = xyz(pr) - eye0;
+                    take = take && dot(cc, cc) <= far2;  // the per-ray test rejects centres beyond the ray's hit
+                }
+                const uint64_t tm = __ballot(take);
+                if (take) pend_list[pend + __builtin_amdgcn_mbcnt_hi(uint32_t(tm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(tm), 0u))] = idx;
+                pend += uint32_t(__popcll(tm));
+                __builtin_amdgcn_wave_barrier();
+                if (pend >= 64u) {
+                    flush_batch(64u);
+                    __builtin_amdgcn_wave_barrier();
+                    const bool mv = lane_ + 64u < pend;   // the rest moves to the front
+                    uint32_t v = 0u;
+                    if (mv) v = pend_list[64u + lane_];
+                    __builtin_amdgcn_wave_barrier();
+                    if (mv) pend_list[lane_] = v;
+                    pend -= 64u;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (pend) flush_batch(pend);
+            __builtin_amdgcn_wave_barrier();   // the gather lists of the surface estimate reuse this LDS
         }
+        // ---- the pixel's samples, 64 per trip; lane = sample
+        V pixel_sum = mk(0, 0, 0);
+        for (uint32_t sub = 0; sub < n_sub; sub++) {
+        V ro, rd;
+        float tmin, t;
+        uint32_t code, inst;
+        Rng rng;
+        const bool active = gen_ray(sub, rng, ro, rd, tmin, t, code, inst);
+        const V wo = -normalize(rd);
+        if (active) c_samp++;
         const bool hit = code != CODE_MISS;
         V color = mk(0, 0, 0);
         bool surface_on = hit;
@@ -914,7 +1034,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     surface_scale = __expf(-sigma_t * t) * rcp(tr_d);   // transmittance(t) / (1 - cdf), 1 - cdf = T(d)
                 }
             }
-        } else if (MEDIUM && !(q.skip & 1u)) {  // beam x point volume estimate, src/photon.rs:439-502
+        } else if (MEDIUM && !(q.skip & 1u) && !beam_lanes) {  // beam estimates with the samples in the lanes
             V vc = mk(0, 0, 0);
             const float phase = sc.medium_phase;
             // The staging lane pre-computes what depends on the photon only: pos_r.w = r^2, pow = power *
@@ -940,10 +1060,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 }
             };
             auto prep_none = [](const PhotonRec& ph) { return ph; };
-            // Packet form (every ray of the wave starts at o0): what depends on the photon and the common origin
-            // is computed once by the staging lane -- c = centre - o0, |c|^2, |c|, and the power pre-multiplied by
-            // 3/pi * phase / r^2 * exp(-sigma_t |c|); per ray exp(-sigma_t s) = exp(-sigma_t |c|) * exp(sigma_t (|c| - s))
-            // with sigma_t (|c| - s) <= sigma_t r^2 / |c| ~ 1e-5, so the second factor is 1 + x to fp32 precision.
+            // Packet form (every ray of the wave starts at o0; the same per-photon terms as in the photon-per-lane form
+            // above, computed by the staging lane; used when the strip has no candidate list)
             const float t2 = hit ? t * t : kInf;
             auto prep_packet = [&](PhotonRec ph, const V& o0) {
                 const V c = xyz(ph.pos_r) - o0;
@@ -1006,25 +1124,6 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 if (!beam_walk_packet<false>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow,
                                              [](const PhotonRec& ph, const V&) { return ph; }, visit_beam))
                     beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_none, visit_beam);
-            } else if (cand_valid) {
-                // this sample's own (tighter) frustum re-culls the block's candidates while they are staged
-                Frustum fs;
-                const bool have_fs = frustum_from_dirs(active, ro, &rd, 1, fs);
-                const V eye0 = mk(a.cam.eye[0], a.cam.eye[1], a.cam.eye[2]);  // pinhole: every ray starts here
-                const float far2 = wave_max(active ? t2 : 0.f);               // farthest hit of the pixel's samples (inf on a miss)
-                for (uint32_t base = 0; base < cand_n; base += 64u) {  // wave-uniform loop
-                    const bool mine = base + lane_ < cand_n;
-                    PhotonRec staged{};
-                    bool take = false;
-                    if (mine) {
-                        const PhotonRec raw = q.v_ph[cand[base + lane_]];
-                        take = !have_fs || !sphere_outside(fs, raw.pos_r);
-                        const V cc = xyz(raw.pos_r) - eye0;
-                        take = take && dot(cc, cc) <= far2;  // the per-ray test rejects centres beyond the ray's hit
-                        if (take) staged = prep_packet(raw, eye0);  // (a staging lane need not hold a live sample: not its own ro)
-                    }
-                    stage_and_test(take, staged, stage, active, visit_packet);
-                }
             } else {
                 if (!beam_walk_packet<true>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_packet, visit_packet))
                     beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_point, visit);
@@ -1090,8 +1189,11 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             else if (MEDIUM) sc_col = __expf(-sigma_t * t) * sc_col;                  // :610-611
             color = color + sc_col;
         }
-        // the pixel's partial sum over this chunk: its samples are summed in a fixed butterfly order (inactive lanes add 0)
-        V sum = active ? color : mk(0, 0, 0);
+        if (active) pixel_sum = pixel_sum + color;
+        }   // trips of the pixel
+        // the pixel's partial sum over this chunk: per lane its samples in trip order plus its photons' beam terms, then
+        // the lanes in a fixed butterfly order
+        V sum = beam_lanes ? fma3(beam_sum, mcol0, pixel_sum) : pixel_sum;
         for (int off = 32; off; off >>= 1) {
             sum.x += __shfl_xor(sum.x, off);
             sum.y += __shfl_xor(sum.y, off);
@@ -1503,13 +1605,19 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     const bool gg = gather_max > kGatherLds;  // lists in global memory
     const uint64_t gather_lds = gg ? 0 : gather_max;
     QueryArgs q{};
-    // Work items of the camera pass are wave-level: (8x8 pixel block, chunk of up to 64 samples); the chunking is
-    // fixed here (whatever the "chunk_spp" option says) and prepare_render sizes the slab [n_chunks][n_owned] for it.
-    int rc = rpti::prepare_render(s, st, cam, prm, num_samples, seed, sample_offset, q.r, 0, 64);
+    // Work items of the camera pass are wave-level: (a strip of rows of an 8x8 pixel block, chunk of up to kSuper
+    // samples); the chunking is fixed here (whatever the "chunk_spp" option says) and prepare_render sizes the slab
+    // [n_chunks][n_owned] for it.  How many strips a block is cut into changes no pixel's arithmetic.
+    int rc = rpti::prepare_render(s, st, cam, prm, num_samples, seed, sample_offset, q.r, 0, kSuper);
     if (rc) return rc;
     rc = rpti::serialize_with_other_streams(s, st);  // candidate lists and the overflow flag exist once per scene
     if (rc) return rc;
-    q.r.n_items = (q.r.n_owned / 64u) * q.r.n_chunks;
+    const int64_t parts = rpti::option_photon_parts(s);
+    if (parts != 1 && parts != 2 && parts != 4 && parts != 8) return rpti::fail(RPT_ERR_INVALID, "photon_parts must be 1, 2, 4 or 8");
+    q.parts = uint32_t(parts);
+    const uint64_t n_items = uint64_t(q.r.n_owned / 64u) * q.parts * q.r.n_chunks;
+    if (n_items >= (1ull << 32) - (1ull << 24)) return rpti::fail(RPT_ERR_INVALID, "too many work items");
+    q.r.n_items = uint32_t(n_items);
     q.s_nodes = pm->surf.nodes; q.s_ph = pm->surf.sorted; q.n_s = pm->surf.n;
     q.v_nodes = pm->vol.nodes; q.v_ph = pm->vol.sorted; q.n_v = pm->vol.n;
     q.kind = uint32_t(pm->kind);
@@ -1517,7 +1625,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     q.gather_size = uint32_t(gather_size);
     q.gather_size_volume = pm->kind == RPT_PHOTON_MAP ? uint32_t(gather_size_volume) : 0u;  // only the point-point estimate gathers in the volume
     const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_nodes != 0;
-    q.region_dwords = uint32_t(std::max<size_t>(size_t(gather_lds) * 64u * 2u, size_t(kBeamCap) + 64u * 16u));
+    q.region_dwords = uint32_t(std::max<size_t>({size_t(gather_lds) * 64u * 2u, size_t(kBeamCap) + 64u * 16u, size_t(kSuper) * 4u + kPendCap}));
     const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + 4u * size_t(q.region_dwords) * 4u;
     if (!pm->d_overflow) RPTI_HIP_TRY(hipMalloc((void**)&pm->d_overflow, 64));
     RPTI_HIP_TRY(hipMemsetAsync(pm->d_overflow, 0, 4, st));
