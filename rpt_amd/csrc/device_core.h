@@ -515,13 +515,22 @@ RPT_DEV uint64_t scan_mask_for_ball(const SceneView& scene_, bool live, V c, flo
     if (n > 64u) return ~0ull;
     const float r2 = r * r;
     uint64_t mask = 0ull;
-    for (uint32_t i = 0; i < n; i++) {
-        const AabbScan b = uload(&sc.pbox[i]);
+    auto reaches = [&](const AabbScan& b) {
         const float dx = fmaxf(fmaxf(b.lo.x - c.x, c.x - b.hi.x), 0.f);
         const float dy = fmaxf(fmaxf(b.lo.y - c.y, c.y - b.hi.y), 0.f);
         const float dz = fmaxf(fmaxf(b.lo.z - c.z, c.z - b.hi.z), 0.f);
-        if (__any(live && fmaf(dx, dx, fmaf(dy, dy, dz * dz)) <= r2)) mask |= 1ull << i;
+        return __any(live && fmaf(dx, dx, fmaf(dy, dy, dz * dz)) <= r2);
+    };
+    uint32_t i = 0;
+    for (; i + 4u <= n; i += 4u) {   // four records' scalar loads in flight at a time
+        const AabbScan b0 = uload(&sc.pbox[i]), b1 = uload(&sc.pbox[i + 1u]), b2 = uload(&sc.pbox[i + 2u]), b3 = uload(&sc.pbox[i + 3u]);
+        if (reaches(b0)) mask |= 1ull << i;
+        if (reaches(b1)) mask |= 2ull << i;
+        if (reaches(b2)) mask |= 4ull << i;
+        if (reaches(b3)) mask |= 8ull << i;
     }
+    for (; i < n; i++)
+        if (reaches(uload(&sc.pbox[i]))) mask |= 1ull << i;
     return mask;
 }
 // Would a walk of the per-mesh trees visit anything?  The two child boxes of every mesh root against the

@@ -469,6 +469,7 @@ struct QueryArgs {
     uint32_t cand_cap;       // 0: no candidate lists (every sample walks the tree)
     uint32_t* gather;        // GG kernels (gather size > kGatherLds): [waves of the grid][2][K][64] gather lists in global memory
     uint32_t parts;          // work items per (8x8 pixel block, sample chunk): the block's rows in 1, 2, 4 or 8 strips
+    uint32_t coop_cap;       // candidates the wave-level surface gather may hold in LDS (multiple of 4, <= kCoopCap); 0: one search per lane
 };
 
 static_assert(offsetof(QueryArgs, r) == 0, "kernel arguments begin with the SceneView (kernarg_scene)");
@@ -775,6 +776,145 @@ RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint
     return found;
 }
 
+// ---- the surface gather of a pixel's samples, by the wave together.
+// The samples of a pixel hit within a footprint of each other, far less than a gather radius apart: their k-nearest sets
+// overlap almost entirely.  Instead of 64 searches (or one lock-step search with 64 selections going on inside it) the wave
+// 1. collects every photon within reach of the cluster of query points -- a ball around one of them that contains each
+//    member's own search ball -- walking the tree with a DIFFERENT pending node per lane (ball_collect: 64 nodes per
+//    instruction stream, no dependent load per node and lane);
+// 2. orders the candidates by their distance to the cluster's centre (sort_candidates: rank by counting);
+// 3. lets every lane pick its K nearest from the LDS list: in that order a lane's list is nearly final once it is full,
+//    and the scan stops when no lane can be reached any more.
+// Conservative collection + exact per-lane distances => each lane gets exactly its K nearest photons.
+static constexpr uint32_t kBallStack = 128;   // pending tree entries of ball_collect (LDS, per wave)
+static constexpr uint32_t kCoopCap = 256;     // candidates at most (four per lane in sort_candidates)
+static constexpr uint32_t kCoopOverflow = 0xFFFFFFFFu;
+// The deepest inner node below which every photon within sqrt(R2) of c lies: down from the root while only one child's
+// box is in reach (c, R2 wave-uniform; the nodes come through scalar loads).  A pixel's query ball is tiny against the
+// map: most of a walk from the root is this chain of one-child steps, a dependent load each -- so the wave keeps the end
+// of the chain of a LARGER ball around its current query (the anchor) and starts from there until a query leaves it.
+RPT_DEV uint32_t ball_anchor(const BvhNode* nodes, uint32_t n, V c, float R2) {
+    uint32_t cur = 0u;
+    if (n < 2u) return cur;
+    for (;;) {
+        const BvhNode nd = uload(nodes + cur);
+        const bool h0 = box_dist2(nd.lo0, nd.hi0, c) <= R2, h1 = box_dist2(nd.lo1, nd.hi1, c) <= R2;
+        const uint32_t both = __builtin_amdgcn_readfirstlane((h0 ? 1u : 0u) | (h1 ? 2u : 0u));
+        if (both != 1u && both != 2u) break;
+        const uint32_t next = both == 1u ? nd.e0 : nd.e1;
+        if (next & BVH_LEAF) break;
+        cur = __builtin_amdgcn_readfirstlane(next);
+    }
+    return cur;
+}
+// Every photon below the inner node `start` within sqrt(R2) of c, as (position, index) records in cand[0 .. return value);
+// the set is a function of (c, R2) alone when `start` is an anchor of a ball that contains this one.  kCoopOverflow if the
+// stack or the list does not hold them.  `lscratch`: 64 dwords of wave-private LDS.
+RPT_DEV uint32_t ball_collect(const BvhNode* nodes, const PhotonRec* p, uint32_t n, uint32_t start, V c, float R2, uint32_t* pstack,
+                              uint32_t* lscratch, F4* cand, uint32_t cap, uint32_t& steps) {
+    const uint32_t lane = threadIdx.x & 63u;
+    auto prefix = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)); };
+    uint32_t count = 1u, M = 0u;  // wave-uniform
+    if (lane == 0u) pstack[0] = (n == 1u) ? BVH_LEAF : start;
+    __builtin_amdgcn_wave_barrier();
+    while (count != 0u) {
+        steps++;
+        const uint32_t b = min(count, 64u);
+        const bool mine = lane < b;
+        uint32_t e = 0u;
+        if (mine) e = pstack[count - b + lane];
+        count -= b;
+        const bool leaf = mine && (e & BVH_LEAF) != 0u;
+        bool s0 = false, s1 = false;
+        uint32_t c0 = 0u, c1 = 0u;
+        if (mine && !leaf) {
+            const BvhNode nd = nodes[e];
+            c0 = nd.e0;
+            c1 = nd.e1;
+            s0 = box_dist2(nd.lo0, nd.hi0, c) <= R2;
+            s1 = box_dist2(nd.lo1, nd.hi1, c) <= R2;
+        }
+        const uint64_t m0 = __ballot(s0), m1 = __ballot(s1);
+        const uint32_t n0 = uint32_t(__popcll(m0)), n1 = uint32_t(__popcll(m1));
+        if (count + n0 + n1 > kBallStack) return kCoopOverflow;
+        __builtin_amdgcn_wave_barrier();   // the popped entries are read before their slots are written again
+        if (s0) pstack[count + prefix(m0)] = c0;
+        if (s1) pstack[count + n0 + prefix(m1)] = c1;
+        count += n0 + n1;
+        const uint64_t lm = __ballot(leaf);
+        if (lm != 0ull) {   // the photons of the popped leaves: eight leaves at a time, one photon per lane, all loads in flight
+            const uint32_t nl = uint32_t(__popcll(lm));
+            if (leaf) lscratch[prefix(lm)] = e;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t g = 0; g < nl; g += 8u) {
+                const uint32_t li = g + (lane >> 3), k = lane & 7u;
+                uint32_t le = 0u;
+                if (li < nl) le = lscratch[li];
+                const uint32_t first = le & PH_LEAF_INDEX, cnt = li < nl ? ((le >> 26) & 31u) + 1u : 0u;
+                for (uint32_t k0 = 0; __ballot(k0 + k < cnt) != 0ull; k0 += 8u) {   // (one pass: k-nearest trees have leaves of <= 8)
+                    bool take = false;
+                    F4 pr{};
+                    if (k0 + k < cnt) {
+                        pr = p[first + k0 + k].pos_r;
+                        const V d = xyz(pr) - c;
+                        take = dot(d, d) <= R2;
+                    }
+                    const uint64_t tm = __ballot(take);
+                    const uint32_t nt = uint32_t(__popcll(tm));
+                    if (M + nt > cap) return kCoopOverflow;
+                    if (take) cand[M + prefix(tm)] = F4{pr.x, pr.y, pr.z, __uint_as_float(first + k0 + k)};
+                    M += nt;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return M;
+}
+// Orders cand[0 .. M) by squared distance to c (ties keep their list order) and leaves those distances in keys[0 .. M).
+// Rank by counting: every lane holds up to four records and counts, for each, the keys below it (broadcast LDS reads).
+RPT_DEV void sort_candidates(F4* cand, float* keys, uint32_t M, V c) {
+    const uint32_t lane = threadIdx.x & 63u;
+    F4 rec[4];
+    float key[4];
+    uint32_t rank[4];
+#pragma unroll
+    for (uint32_t r = 0; r < 4u; r++) {
+        const uint32_t i = r * 64u + lane;
+        rec[r] = F4{0.f, 0.f, 0.f, 0.f};
+        key[r] = kInf;
+        rank[r] = 0u;
+        if (i < M) {
+            rec[r] = cand[i];
+            const V d = xyz(rec[r]) - c;
+            key[r] = dot(d, d);
+            keys[i] = key[r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+    for (uint32_t j = 0; j < M; j++) {
+        const float kj = keys[j];
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; r++) {
+            if (r * 64u < M) {   // wave-uniform
+                const uint32_t i = r * 64u + lane;
+                rank[r] += (kj < key[r] || (kj == key[r] && j < i)) ? 1u : 0u;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (uint32_t r = 0; r < 4u; r++) {
+        const uint32_t i = r * 64u + lane;
+        if (i < M) {
+            cand[rank[r]] = rec[r];
+            keys[rank[r]] = key[r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
 // KIND: the PhotonRenderKind of the map (RPT_PHOTON_*).  One instantiation per kind: the three estimators share the
@@ -805,6 +945,10 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     uint32_t c0 = 0, c1 = 0;
     float prev_r2 = 0.f;  // squared radius of this lane's previous surface gather
     unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
+    uint32_t g_cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic (counters build), wave-level: see the end of the kernel
+    V anc_c = mk(0, 0, 0);   // wave-uniform: the surface gather's anchor (ball_anchor) -- centre, radius, node
+    float anc_R = 0.f;
+    uint32_t anc_node = 0u;
     // Work decomposition of the camera pass: a wave takes a strip of rows of one 8x8 pixel block and one chunk of up
     // to kSuper samples at a time and walks through the strip's pixels; a pixel's samples are handled 64 at a time:
     // in each trip the 64 LANES ARE SAMPLES OF ONE PIXEL.  The rays of a trip then differ only by their sub-pixel
@@ -908,18 +1052,43 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         // ---- beam x point estimate, one photon per lane (src/photon.rs:439-502)
         V beam_sum = mk(0, 0, 0);   // this lane's photons over all the pixel's rays
         const bool beam_lanes = MEDIUM && KIND == RPT_PHOTON_POINT_BEAM && cand_valid;
-        if (beam_lanes) {
-            float far2 = 0.f;
+        // the surface gather can collect its candidates once for all the pixel's samples (below) when the estimator decides
+        // "surface or not" by the hit alone
+        const bool pix_gather = !GG && q.coop_cap != 0u && q.gather_size != 0u && KIND != RPT_PHOTON_MAP && !(q.skip & 2u);
+        float far2 = 0.f;
+        bool have_xc = false;      // wave-uniform
+        V pxc = mk(0, 0, 0);       // wave-uniform: the first surface point among the pixel's samples
+        float prho2 = 0.f;         // how far (squared) this lane's surface points lie from it
+        if (beam_lanes || pix_gather) {
             for (uint32_t sub = 0; sub < n_sub; sub++) {
                 Rng rng;
                 V ro, rd;
                 float tmin, t;
                 uint32_t code, inst;
                 const bool active = gen_ray(sub, rng, ro, rd, tmin, t, code, inst);
-                const float t2 = !active ? -1.f : (code != CODE_MISS ? t * t : kInf);   // no photon centre lies within a negative distance
-                rays[sub * 64u + lane_] = make_float4(rd.x, rd.y, rd.z, t2);
-                far2 = fmaxf(far2, t2);
+                if (beam_lanes) {
+                    const float t2 = !active ? -1.f : (code != CODE_MISS ? t * t : kInf);   // no photon centre lies within a negative distance
+                    rays[sub * 64u + lane_] = make_float4(rd.x, rd.y, rd.z, t2);
+                    far2 = fmaxf(far2, t2);
+                }
+                if (pix_gather) {
+                    const bool sf = active && code != CODE_MISS;
+                    const uint64_t sm = __ballot(sf);
+                    if (sm != 0ull) {
+                        const V xs = fma3(t, rd, ro);
+                        if (!have_xc) {
+                            const uint32_t lead = uint32_t(__ffsll((unsigned long long)sm)) - 1u;
+                            auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lead)); };
+                            pxc = mk(bc(xs.x), bc(xs.y), bc(xs.z));
+                            have_xc = true;
+                        }
+                        const V dxs = xs - pxc;
+                        if (sf) prho2 = fmaxf(prho2, dot(dxs, dxs));
+                    }
+                }
             }
+        }
+        if (beam_lanes) {
             far2 = wave_max(far2);   // farthest hit of the pixel's samples (inf on a miss)
             // the pixel's own frustum (footprint included) re-culls the strip's candidates
             const float e = a.inv_dim * 1.0001f;
@@ -997,6 +1166,37 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             }
             if (pend) flush_batch(pend);
             __builtin_amdgcn_wave_barrier();   // the gather lists of the surface estimate reuse this LDS
+        }
+        // ---- the surface gather's candidates, once for all the pixel's samples when their hit points form one cluster: every
+        // photon within pix_R of pxc, ordered by distance to pxc.  A lane may then search any ball that lies inside that one.
+        uint32_t pix_M = 0u;       // wave-uniform
+        bool pix_valid = false;    // wave-uniform
+        float pix_R = 0.f;         // wave-uniform
+        if (pix_gather && have_xc) {
+            const uint32_t K = q.gather_size;
+            uint32_t* const pstack = region + K * 64u;
+            float* const keys = reinterpret_cast<float*>(pstack + kBallStack);
+            F4* const cl = reinterpret_cast<F4*>(keys + q.coop_cap);
+            const float G = wave_max(prev_r2 > 0.f ? 2.f * prev_r2 : 0.f);
+            const float rho_max2 = wave_max(prho2);
+            if (G > 0.f && rho_max2 <= G) {
+                pix_R = (__builtin_sqrtf(G) + __builtin_sqrtf(rho_max2)) * (1.f + 1e-5f);
+                const V da = pxc - anc_c;
+                if (!(anc_R > 0.f) || __builtin_sqrtf(dot(da, da)) + pix_R > anc_R) {
+                    anc_c = pxc;
+                    anc_R = 2.f * pix_R;
+                    anc_node = ball_anchor(q.s_nodes, q.n_s, pxc, anc_R * anc_R);
+                    if (a.counters) g_cnt[9]++;
+                }
+                uint32_t steps = 0;
+                pix_M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc_node, pxc, pix_R * pix_R, pstack, reinterpret_cast<uint32_t*>(keys), cl,
+                                     q.coop_cap, steps);
+                if (a.counters) { g_cnt[2] += steps; if (pix_M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += pix_M; }
+                if (pix_M != kCoopOverflow) {
+                    sort_candidates(cl, keys, pix_M, pxc);
+                    pix_valid = true;
+                }
+            }
         }
         // ---- the pixel's samples, 64 per trip; lane = sample
         V pixel_sum = mk(0, 0, 0);
@@ -1131,59 +1331,232 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             color = vc * mcol0;
         }
         if (active && !hit && !MEDIUM) color = env_color(sc_arg, rd);  // src/photon.rs:597
-        if (active && surface_on && !(q.skip & 2u)) {  // surface estimate, src/photon.rs:327-375
-            V n;
+        // ---- surface estimate, src/photon.rs:327-375
+        const bool surf = active && surface_on && !(q.skip & 2u);
+        V n = mk(0, 1, 0), x = ro;
+        Mat mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
+        if (surf) {
             uint32_t obj;
             finalize_hit(sc_arg, ro, rd, tmin, t, code, inst, n, obj);
-            const Mat mat = load_mat(sc_arg, obj);
-            const V x = fma3(t, rd, ro);
-            // Consecutive samples of a lane fall within a pixel of each other: the previous gather radius
-            // (squared, doubled) bounds this search from its first node; the rare miss is searched again.
-            float max_d2;
+            mat = load_mat(sc_arg, obj);
+            x = fma3(t, rd, ro);
+        }
+        V sc_col = mat_emit(mat) * mat_color(mat);
+        float max_d2 = 0.f;
+        // One gathered photon's term (src/photon.rs:357-371).  Visibility ("something lies between the photon and the
+        // query point"): only a hit closer than the query point can block, and every point of the segment photon -> x
+        // lies within the gather radius of x: scanned records whose box misses that ball (of any sample of this pixel:
+        // the mask is wave-uniform) cannot decide the test and are skipped.  The closest hit below |disp| (1 - 1e-3)
+        // is the closest hit of the unbounded query whenever that one would block, so the decisions are the same as
+        // with the full scan.
+        auto add_photon = [&](V po, V pdir, V ppow, uint64_t vis_mask) {
+            V disp = x - po;
+            float len2 = dot(disp, disp);
+            float ilen = rsq(len2);
+            V pd = ilen * disp;
+            float len = len2 * ilen;
+            float ts = BVH ? kInf : len * (1.f - 1e-3f);
+            uint32_t cs = CODE_MISS, is = 0;
+            if (!(q.skip & 8u)) {  // diagnostic: 8 = no visibility scans
+                if (BVH) closest_hit<2, false>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
+                else scan_prims<true>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, vis_mask);
+            }
+            // A hit inside the query point's own tangent plane is the grazing ray meeting its own surface: fp64
+            // rejects it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
+            V hp = fma3(ts, pd, po) - x;
+            bool own_plane = fabsf(dot(hp, n)) <= 1e-4f * len;
+            bool blocked = cs != CODE_MISS && !own_plane && ts < len * (1.f - 1e-3f);
+            if (!blocked || !(len2 > 0.f)) {  // (a query point that coincides with the photon has no ray to trace)
+                float c = fminf(fmaxf(dot(pdir, n), 0.f), 1.f);
+                sc_col = fma3(c, bsdf(mat, n, wo, pdir) * ppow, sc_col);
+            }
+        };
+        bool todo = surf;
+        // Consecutive samples of a lane fall within a pixel of each other: the previous gather radius (squared, doubled)
+        // bounds this search; a lane that finds fewer than K photons inside it searches again with a larger one.
+        if (!GG && q.coop_cap != 0u && q.gather_size != 0u) {
+            const uint32_t K = q.gather_size, want_k = min(K, q.n_s);
+            uint32_t* const pstack = region + K * 64u;
+            float* const keys = reinterpret_cast<float*>(pstack + kBallStack);
+            F4* const cl = reinterpret_cast<F4*>(keys + q.coop_cap);
+            // Every member lane picks its K nearest out of the M ordered candidates (centre: where `rho` is measured from)
+            // inside its search radius `guess`, then sums the terms of the photons within its K-th distance, in candidate
+            // order.  Lanes that found K are done.
+            auto serve = [&](bool member, float guess, float rho, uint32_t M) {
+                // -- each member's K nearest distances (list in LDS; entries beyond `guess` do not count)
+                uint32_t found = 0, wslot = 0;
+                float worst = 0.f;
+                const float reach0 = __builtin_sqrtf(guess) + rho;
+                float thr = member ? reach0 * reach0 * (1.f + 1e-5f) : -1.f;
+                float k_next = M ? keys[0] : 0.f;
+                F4 c_next = M ? cl[0] : F4{0.f, 0.f, 0.f, 0.f};
+                for (uint32_t j = 0; j < M; j++) {
+                    const float kj = k_next;
+                    const F4 cj = c_next;
+                    {   // the next candidate's LDS reads are in flight while this one is handled
+                        const uint32_t jn = min(j + 1u, M - 1u);
+                        k_next = keys[jn];
+                        c_next = cl[jn];
+                    }
+                    if (__ballot(kj <= thr) == 0ull) break;   // no member's ball reaches this far from the centre
+                    if (a.counters) g_cnt[5]++;
+                    const V d = xyz(cj) - x;
+                    const float d2 = dot(d, d);
+                    bool changed = false;
+                    if (member) {
+                        if (found < K) {
+                            if (d2 <= guess) {
+                                gd[found * 64u] = d2;
+                                found++;
+                                changed = found == K;
+                            }
+                        } else if (d2 < worst) {
+                            gd[wslot * 64u] = d2;
+                            changed = true;
+                        }
+                        if (changed) {   // (re)locate the current worst: four independent LDS reads per step
+                            worst = -1.f;
+                            uint32_t k = 0;
+                            for (; k + 4u <= K; k += 4u) {
+                                const float v0 = gd[k * 64u], v1 = gd[(k + 1u) * 64u], v2 = gd[(k + 2u) * 64u], v3 = gd[(k + 3u) * 64u];
+                                const float m01 = fmaxf(v0, v1), m23 = fmaxf(v2, v3), m = fmaxf(m01, m23);
+                                if (m > worst) {
+                                    worst = m;
+                                    wslot = k + (m == m01 ? (m == v0 ? 0u : 1u) : (m == v2 ? 2u : 3u));
+                                }
+                            }
+                            for (; k < K; k++) {
+                                const float v = gd[k * 64u];
+                                if (v > worst) { worst = v; wslot = k; }
+                            }
+                            const float reach = __builtin_sqrtf(worst) + rho;
+                            thr = reach * reach * (1.f + 1e-5f);
+                        }
+                    }
+                    if (a.counters && __ballot(changed) != 0ull) g_cnt[6]++;
+                }
+                const bool ok = member && found >= want_k;
+                float r2k = found == K ? worst : 0.f;
+                if (ok && found < K) for (uint32_t k = 0; k < found; k++) r2k = fmaxf(r2k, gd[k * 64u]);   // (a map of fewer than K photons)
+                if (!ok) r2k = 0.f;
+                // -- the terms of the photons within each lane's radius, in candidate order
+                uint64_t vis_mask = ~0ull;
+                if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, ok, x, __builtin_sqrtf(r2k) * (1.f + 1e-4f) + 1e-6f);
+                const float reach2 = __builtin_sqrtf(r2k) + rho;
+                const float thr2 = ok ? reach2 * reach2 * (1.f + 1e-5f) : -1.f;
+                bool more = __ballot(ok) != 0ull && !(q.skip & 16u);   // diagnostic: 16 = no second pass
+                const float thr2_max = wave_max(thr2);
+                for (uint32_t base = 0; base < M && more; base += 64u) {
+                    // lane l fetches what the term needs of candidate base + l; the records are then handed round by readlane
+                    F4 fdir{}, fpow{};
+                    if (base + lane_ < M && keys[base + lane_] <= thr2_max) {
+                        const uint32_t idx = __float_as_uint(cl[base + lane_].w);
+                        fdir = q.s_ph[idx].dir;
+                        fpow = q.s_ph[idx].pow;
+                    }
+                    const uint32_t nb = min(64u, M - base);
+                    float k_nx = keys[base];
+                    F4 c_nx = cl[base];
+                    for (uint32_t jj = 0; jj < nb; jj++) {
+                        const uint32_t j = base + jj;
+                        const float kj = k_nx;
+                        const V po = xyz(c_nx);
+                        {
+                            const uint32_t jn = min(j + 1u, M - 1u);
+                            k_nx = keys[jn];
+                            c_nx = cl[jn];
+                        }
+                        if (__ballot(kj <= thr2) == 0ull) { more = false; break; }
+                        if (a.counters) g_cnt[7]++;
+                        const V dd = po - x;
+                        const bool in = ok && dot(dd, dd) <= r2k;
+                        if (__ballot(in) == 0ull) continue;
+                        auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), jj)); };
+                        const V pdir = mk(rl(fdir.x), rl(fdir.y), rl(fdir.z)), ppow = mk(rl(fpow.x), rl(fpow.y), rl(fpow.z));
+                        if (a.counters) g_cnt[8]++;
+                        if (in) add_photon(po, pdir, ppow, vis_mask);
+                    }
+                }
+                if (ok) {
+                    max_d2 = r2k;
+                    todo = false;
+                }
+                return ok;
+            };
+            // Consecutive samples of a lane fall within a pixel of each other: the previous gather radius (squared, doubled)
+            // bounds this search; a lane that finds fewer than K photons inside it searches again with a larger one.
+            float guess = prev_r2 > 0.f ? 2.f * prev_r2 : 0.f;
+            {   // a lane without a radius of its own borrows the largest one in the wave
+                const float g = wave_max(todo ? guess : 0.f);
+                if (!(guess > 0.f)) guess = g;
+            }
+            if (a.counters && __ballot(todo) != 0ull) g_cnt[0]++;
+            // round 0 serves the lanes from the pixel's candidate list (a lane's ball has to lie inside the collected one); the
+            // later rounds collect for clusters of the query points that are left: none, unless the pixel straddles an edge,
+            // a radius was too small or there is no pixel list
+            for (uint32_t round = pix_valid ? 0u : 1u; round < 7u; round++) {
+                const uint64_t cm = __ballot(todo && guess > 0.f);
+                if (cm == 0ull) break;
+                bool member;
+                float g_use, rho;
+                uint32_t M;
+                if (round == 0u) {
+                    const V dx = x - pxc;
+                    rho = __builtin_sqrtf(dot(dx, dx));
+                    const float room = pix_R * (1.f - 2e-5f) - rho;
+                    g_use = fminf(guess, room > 0.f ? room * room : 0.f);
+                    member = todo && g_use > 0.f;
+                    M = pix_M;
+                } else {
+                    if (a.counters) g_cnt[1]++;
+                    pix_valid = false;   // (these rounds reuse the list's LDS)
+                    const uint32_t lead = uint32_t(__ffsll((unsigned long long)cm)) - 1u;
+                    auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lead)); };
+                    const V xc = mk(bc(x.x), bc(x.y), bc(x.z));
+                    const float gc = bc(guess);
+                    const V dx = x - xc;
+                    const float rho2 = dot(dx, dx);
+                    member = todo && guess > 0.f && rho2 <= gc;   // within the leader's own search radius
+                    rho = __builtin_sqrtf(rho2);
+                    g_use = guess;
+                    const float R = wave_max(member ? __builtin_sqrtf(guess) + rho : 0.f) * (1.f + 1e-5f);
+                    // the anchor: the end of the one-child chain of a ball twice as wide, kept while the queries stay inside that ball
+                    const V da = xc - anc_c;
+                    if (!(anc_R > 0.f) || __builtin_sqrtf(dot(da, da)) + R > anc_R) {
+                        anc_c = xc;
+                        anc_R = 2.f * R;
+                        anc_node = ball_anchor(q.s_nodes, q.n_s, xc, anc_R * anc_R);
+                        if (a.counters) g_cnt[9]++;
+                    }
+                    uint32_t steps = 0;
+                    M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc_node, xc, R * R, pstack, reinterpret_cast<uint32_t*>(keys), cl, q.coop_cap, steps);
+                    if (a.counters) { g_cnt[2] += steps; if (M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += M; }
+                    if (M == kCoopOverflow) break;   // the lanes still to do search one by one below
+                    if (q.skip & 64u) { if (member) { max_d2 = 0.5f * guess; todo = false; } continue; }   // diagnostic: collection only
+                    sort_candidates(cl, keys, M, xc);
+                    if (q.skip & 32u) { if (member) { max_d2 = 0.5f * guess; todo = false; } continue; }   // diagnostic: collection + ordering only
+                }
+                const bool ok = serve(member, g_use, rho, M);
+                if (member && !ok) guess = fmaxf(guess, 4.f * g_use);   // too few photons inside: twice the radius next round
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (a.counters) { const uint64_t fm = __ballot(todo); if (fm) { g_cnt[10]++; g_cnt[11] += uint32_t(__popcll(fm)); } }
+        if (todo) {   // one search per lane (lists in global memory, no radius to start from, an overfull candidate list)
             const uint32_t want_k = min(q.gather_size, q.n_s);
             uint32_t found = 0;
             // (the samples of a pixel hit within a footprint of each other: they search the tree together)
             if (prev_r2 > 0.f) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2, 2.f * prev_r2);
             if (found < want_k || !(prev_r2 > 0.f)) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2);
-            prev_r2 = max_d2;
-            V sc_col = mat_emit(mat) * mat_color(mat);
-            // Visibility of the gathered photons (src/photon.rs:357-361: "something lies between the photon and the
-            // query point").  Only a hit closer than the query point can block, and every point of the segment
-            // photon -> x lies within the gather radius of x: scanned records whose box misses that ball (of any
-            // sample of this pixel: the mask is wave-uniform) cannot decide any of the `found` tests and are skipped.
-            // The closest hit below |disp| (1 - 1e-3) is the closest hit of the unbounded query whenever that one
-            // would block, so the decisions are the same as with the full scan.
             uint64_t vis_mask = ~0ull;
             if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, true, x, __builtin_sqrtf(max_d2) * (1.f + 1e-4f) + 1e-6f);
             for (uint32_t k = 0; k < found; k++) {
                 const PhotonRec ph = q.s_ph[gi[k * 64u]];
-                V disp = x - xyz(ph.pos_r);
-                float len2 = dot(disp, disp);
-                float ilen = rsq(len2);
-                V pd = ilen * disp;
-                V po = xyz(ph.pos_r);
-                float len = len2 * ilen;
-                float ts = BVH ? kInf : len * (1.f - 1e-3f);
-                uint32_t cs = CODE_MISS, is = 0;
-                if (!(q.skip & 8u)) {  // diagnostic: 8 = no visibility scans
-                    if (BVH) closest_hit<2, false>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
-                    else scan_prims<true>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, vis_mask);
-                }
-                // A hit inside the query point's own tangent plane is the grazing ray meeting its own surface: fp64
-                // rejects it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
-                V hp = fma3(ts, pd, po) - x;
-                bool own_plane = fabsf(dot(hp, n)) <= 1e-4f * len;
-                bool blocked = cs != CODE_MISS && !own_plane && ts < len * (1.f - 1e-3f);
-                if (!blocked && len2 > 0.f) {
-                    V pdir = xyz(ph.dir);
-                    float c = fminf(fmaxf(dot(pdir, n), 0.f), 1.f);
-                    sc_col = fma3(c, bsdf(mat, n, wo, pdir) * xyz(ph.pow), sc_col);
-                } else if (!(len2 > 0.f)) {  // query point coincides with the photon: no ray to trace
-                    V pdir = xyz(ph.dir);
-                    float c = fminf(fmaxf(dot(pdir, n), 0.f), 1.f);
-                    sc_col = fma3(c, bsdf(mat, n, wo, pdir) * xyz(ph.pow), sc_col);
-                }
+                add_photon(xyz(ph.pos_r), xyz(ph.dir), xyz(ph.pow), vis_mask);
             }
+        }
+        if (surf) {
+            prev_r2 = max_d2;
             sc_col = (kInvPi * rcp(max_d2)) * sc_col;
             if (MEDIUM && KIND == RPT_PHOTON_MAP) sc_col = surface_scale * sc_col;  // :433-435
             else if (MEDIUM) sc_col = __expf(-sigma_t * t) * sc_col;                  // :610-611
@@ -1205,6 +1578,11 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         atomicAdd(&a.counters[0], c_samp);
         atomicAdd(&a.counters[5], c_leaf);
         atomicAdd(&a.counters[6], c_acc);
+        // the wave-level surface gather: [8] trips with a gather, [9] cluster rounds, [10] steps of the ball walks, [11] candidates,
+        // [12] overfull walks, [13] / [14] selection steps / list updates, [15] / [16] candidates looked at / photon terms of the
+        // second pass, [17] new anchors, [18] / [19] trips / lanes that searched one by one
+        if (lane_ == 0u)
+            for (int k = 0; k < 12; k++) atomicAdd(&a.counters[8 + k], (unsigned long long)g_cnt[k]);
     }
 }
 
@@ -1625,7 +2003,11 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     q.gather_size = uint32_t(gather_size);
     q.gather_size_volume = pm->kind == RPT_PHOTON_MAP ? uint32_t(gather_size_volume) : 0u;  // only the point-point estimate gathers in the volume
     const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_nodes != 0;
-    q.region_dwords = uint32_t(std::max<size_t>({size_t(gather_lds) * 64u * 2u, size_t(kBeamCap) + 64u * 16u, size_t(kSuper) * 4u + kPendCap}));
+    // the wave-level surface gather: [K][64] distances, the ball walk's stack, candidate keys + (position, index) records
+    const size_t coop_base = size_t(gather_size) * 64u + kBallStack;
+    q.region_dwords = uint32_t(std::max<size_t>({size_t(gather_lds) * 64u * 2u, size_t(kBeamCap) + 64u * 16u, size_t(kSuper) * 4u + kPendCap,
+                                                 gg ? 0u : coop_base + 5u * 160u}));
+    q.coop_cap = (gg || !rpti::option_photon_coop_gather(s)) ? 0u : uint32_t(std::min<size_t>(kCoopCap, ((q.region_dwords - coop_base) / 5u) & ~size_t(3)));
     const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + 4u * size_t(q.region_dwords) * 4u;
     if (!pm->d_overflow) RPTI_HIP_TRY(hipMalloc((void**)&pm->d_overflow, 64));
     RPTI_HIP_TRY(hipMemsetAsync(pm->d_overflow, 0, 4, st));

@@ -59,6 +59,7 @@ struct rpt_options {
     int64_t room_shell = 1;         // fold rectangles that are the faces of one box into a single slab test
     int64_t photon_skip = 0;
     int64_t photon_block_lists = 1;
+    int64_t photon_coop_gather = 1; // surface gather of a pixel's samples by the wave together (0: one search per lane)
     int64_t photon_parts = 4;       // work items per (8x8 pixel block, sample chunk) of the photon camera pass: the block's rows in strips
     int64_t instancing = 1;         // meshes shared by several shapes are stored once and instanced
     int64_t bvh_leaf_max = 4;       // triangles per leaf of a mesh tree (read by rpt_scene_commit)
@@ -80,6 +81,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "photon_skip") o.photon_skip = value;
     else if (s == "photon_block_lists") o.photon_block_lists = value;
     else if (s == "photon_parts") o.photon_parts = value;
+    else if (s == "photon_coop_gather") o.photon_coop_gather = value;
     else if (s == "instancing") o.instancing = value;
     else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); o.defer_lanes = value; }
     else if (s == "bvh_leaf_max") { if (value < 1 || value > 16) return fail(RPT_ERR_INVALID, "bvh_leaf_max must be 1..16"); o.bvh_leaf_max = value; }
@@ -1647,6 +1649,7 @@ extern "C++" void*& rpti::photon_slot(rpt_scene* s) { return s->photon; }
 extern "C++" int64_t rpti::option_photon_skip(rpt_scene* s) { return s->opt.photon_skip; }
 extern "C++" int64_t rpti::option_photon_block_lists(rpt_scene* s) { return s->opt.photon_block_lists; }
 extern "C++" int64_t rpti::option_photon_parts(rpt_scene* s) { return s->opt.photon_parts; }
+extern "C++" int64_t rpti::option_photon_coop_gather(rpt_scene* s) { return s->opt.photon_coop_gather; }
 extern "C++" double* rpti::scratch_out(rpt_scene* s, size_t bytes) {
     if (bytes > s->out_cap) {
         if (s->d_out) (void)hipFree(s->d_out);

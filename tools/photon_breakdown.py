@@ -14,7 +14,8 @@ r = Renderer(scene, cam).width(cfg["width"]).height(cfg["height"]).seed(0)
 r.gather_size(cfg["gather_size"]).gather_size_volume(cfg["gather_size_volume"]).watts(cfg["renderer_watts"] / cfg["photons"] * n)
 print(r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM))
 for skip, what in ((0, "full"), (1, "no volume (beam) estimate"), (2, "no surface estimate"), (3, "primary rays only"),
-                   (6, "beam walk without the per-ray tests"), (9, "surface estimate without visibility scans")):
+                   (6, "beam walk without the per-ray tests"), (9, "surface estimate without visibility scans"),
+                   (17, "surface: no second pass"), (33, "surface: collection + ordering only"), (65, "surface: collection only")):
     rpt_amd.set_option("photon_skip", skip)
     ms = []
     for _ in range(2):
