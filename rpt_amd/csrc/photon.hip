@@ -1054,7 +1054,9 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         const bool beam_lanes = MEDIUM && KIND == RPT_PHOTON_POINT_BEAM && cand_valid;
         // the surface gather can collect its candidates once for all the pixel's samples (below) when the estimator decides
         // "surface or not" by the hit alone
-        const bool pix_gather = !GG && q.coop_cap != 0u && q.gather_size != 0u && KIND != RPT_PHOTON_MAP && !(q.skip & 2u);
+        // -- and when no beam walk of the trips below needs the list's LDS (it runs with the photons in the lanes, or not at all)
+        const bool pix_gather = !GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u && KIND != RPT_PHOTON_MAP && !(q.skip & 2u) &&
+                                (!MEDIUM || beam_lanes || (q.skip & 1u) != 0u);
         float far2 = 0.f;
         bool have_xc = false;      // wave-uniform
         V pxc = mk(0, 0, 0);       // wave-uniform: the first surface point among the pixel's samples
@@ -1374,7 +1376,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         bool todo = surf;
         // Consecutive samples of a lane fall within a pixel of each other: the previous gather radius (squared, doubled)
         // bounds this search; a lane that finds fewer than K photons inside it searches again with a larger one.
-        if (!GG && q.coop_cap != 0u && q.gather_size != 0u) {
+        if (!GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u) {
             const uint32_t K = q.gather_size, want_k = min(K, q.n_s);
             uint32_t* const pstack = region + K * 64u;
             float* const keys = reinterpret_cast<float*>(pstack + kBallStack);
@@ -1533,7 +1535,12 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     if (a.counters) { g_cnt[2] += steps; if (M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += M; }
                     if (M == kCoopOverflow) break;   // the lanes still to do search one by one below
                     if (q.skip & 64u) { if (member) { max_d2 = 0.5f * guess; todo = false; } continue; }   // diagnostic: collection only
-                    sort_candidates(cl, keys, M, xc);
+                    // ordered, like the pixel's list, by distance to the pixel's first surface point when there is one: the order
+                    // of a lane's terms is then the same whichever round serves it
+                    const V kc = (pix_gather && have_xc) ? pxc : xc;
+                    sort_candidates(cl, keys, M, kc);
+                    const V dk = x - kc;
+                    rho = __builtin_sqrtf(dot(dk, dk));
                     if (q.skip & 32u) { if (member) { max_d2 = 0.5f * guess; todo = false; } continue; }   // diagnostic: collection + ordering only
                 }
                 const bool ok = serve(member, g_use, rho, M);
@@ -1542,6 +1549,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             }
         }
         if (a.counters) { const uint64_t fm = __ballot(todo); if (fm) { g_cnt[10]++; g_cnt[11] += uint32_t(__popcll(fm)); } }
+        if (__ballot(todo) != 0ull) pix_valid = false;   // (the index lists of these searches lie where the pixel's candidate list is)
         if (todo) {   // one search per lane (lists in global memory, no radius to start from, an overfull candidate list)
             const uint32_t want_k = min(q.gather_size, q.n_s);
             uint32_t found = 0;

@@ -301,3 +301,57 @@ def test_block_candidate_lists_equal_the_per_sample_walk(w, h, spp):
     assert np.all(np.isfinite(imgs[0])) and imgs[1].mean() > 0
     assert rel_rms(imgs[0], imgs[1]) < 1e-5
     assert np.max(np.abs(imgs[0] - imgs[1]) / (np.abs(imgs[1]) + 1e-3 * imgs[1].mean())) < 1e-3
+
+
+@pytest.mark.parametrize("w,h,spp", [(64, 64, 70), (40, 24, 300)])
+def test_strips_per_block_of_the_camera_pass(w, h, spp):
+    """A work item of the camera pass is a strip of rows of an 8x8 pixel block x up to 256 samples ("photon_parts"
+    strips per block).  How the blocks are cut decides which wave renders a pixel and in which order the strip's
+    candidate photons are listed -- i.e. the fp32 order of a pixel's beam sum, never which photons are in it: images
+    for different cuts agree to rounding, a repeated render with the same cut is bit-identical.  300 samples = two
+    chunks, the second one ragged."""
+    import rpt_amd
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    n = 30000
+    r = Renderer(scene, cam).width(w).height(h).watts(14.65 * n).seed(6).gather_size(20).gather_size_volume(3)
+    r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    imgs = []
+    try:
+        for parts in (4, 4, 1, 2, 8):
+            rpt_amd.set_option("photon_parts", parts)
+            r._sample_offset = 0
+            imgs.append(r.photon_sample_array(spp))
+        rpt_amd.set_option("photon_parts", 3)
+        with pytest.raises(RptError):
+            r.photon_sample_array(1)
+    finally:
+        rpt_amd.set_option("photon_parts", 4)
+    assert np.all(np.isfinite(imgs[0])) and imgs[0].mean() > 0
+    assert np.array_equal(imgs[0], imgs[1])
+    for other in imgs[2:]:
+        assert rel_rms(imgs[0], other) < 1e-6
+        assert np.max(np.abs(imgs[0] - other) / (np.abs(other) + 1e-3 * other.mean())) < 1e-4
+
+
+@pytest.mark.parametrize("n,gather", [(30000, 20), (12, 20), (2000, 56)])
+def test_wave_level_surface_gather_equals_one_search_per_lane(n, gather):
+    """Surface estimate: the wave collects the candidates of a pixel's query cluster once and every lane picks its K
+    nearest from that list ("photon_coop_gather", default) against one tree search per lane.  The same K photons
+    per sample either way (exact distances, conservative collection), summed in another order; a map of fewer
+    photons than K and the largest K whose lists fit LDS are the edge cases."""
+    import rpt_amd
+    scene, cam, cfg = scenes.CONFIGS["C2"]()   # no medium: the image is the surface estimate alone
+    size, spp = 48, 70
+    r = Renderer(scene, cam).width(size).height(size).watts(100.0 * n).seed(8).gather_size(gather).gather_size_volume(3)
+    r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    imgs = []
+    try:
+        for on in (1, 0):
+            rpt_amd.set_option("photon_coop_gather", on)
+            r._sample_offset = 0
+            imgs.append(r.photon_sample_array(spp))
+    finally:
+        rpt_amd.set_option("photon_coop_gather", 1)
+    assert np.all(np.isfinite(imgs[0])) and imgs[1].mean() > 0
+    assert rel_rms(imgs[0], imgs[1]) < 1e-5
+    assert np.max(np.abs(imgs[0] - imgs[1]) / (np.abs(imgs[1]) + 1e-3 * imgs[1].mean())) < 1e-3
