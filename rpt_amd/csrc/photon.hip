@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     uint32_t pi = 0u, pi_end = 0u, blk = 0, chunk = 0, x0 = 0, y0 = 0, n_s = 0;  // wave-uniform: pixel cursor within the block, item
     const V cam_right = mk(a.cam.right[0], a.cam.right[1], a.cam.right[2]), cam_up = mk(a.cam.up[0], a.cam.up[1], a.cam.up[2]);
     float4* const rays = reinterpret_cast<float4*>(region);   // [kSuper] (direction, squared hit distance) of the pixel's samples
-    uint32_t* const pend_list = region + kSuper * 4u;         // [kPendCap] culled candidates waiting for a full batch
+    uint32_t* const pend_list = region + kSuper * 4u;         // [2][kPendCap] culled candidates (plain, guarded) waiting for a full batch
     for (;;) {
         // the kernel's arguments are read per trip, where they are used (kernarg_scene in device_core.h): held in scalar
         // registers since kernel entry they do not fit, and the overflow lives in VGPR lanes
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         // -- and when no beam walk of the trips below needs the list's LDS (it runs with the photons in the lanes, or not at all)
         const bool pix_gather = !GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u && KIND != RPT_PHOTON_MAP && !(q.skip & 2u) &&
                                 (!MEDIUM || beam_lanes || (q.skip & 1u) != 0u);
-        float far2 = 0.f;
+        float far2 = 0.f, near2 = kInf;
         bool have_xc = false;      // wave-uniform
         V pxc = mk(0, 0, 0);       // wave-uniform: the first surface point among the pixel's samples
         float prho2 = 0.f;         // how far (squared) this lane's surface points lie from it
@@ -1072,6 +1072,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     const float t2 = !active ? -1.f : (code != CODE_MISS ? t * t : kInf);   // no photon centre lies within a negative distance
                     rays[sub * 64u + lane_] = make_float4(rd.x, rd.y, rd.z, t2);
                     far2 = fmaxf(far2, t2);
+                    if (active) near2 = fminf(near2, t2);
                 }
                 if (pix_gather) {
                     const bool sf = active && code != CODE_MISS;
@@ -1092,6 +1093,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         }
         if (beam_lanes) {
             far2 = wave_max(far2);   // farthest hit of the pixel's samples (inf on a miss)
+            near2 = wave_min(near2);  // nearest one
             // the pixel's own frustum (footprint included) re-culls the strip's candidates
             const float e = a.inv_dim * 1.0001f;
             const V dd = mk(a.cam.ddir[0], a.cam.ddir[1], a.cam.ddir[2]);
@@ -1106,9 +1108,12 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             // r^2 * exp(-sigma_t |c|) -- and per ray exp(-sigma_t s) = exp(-sigma_t |c|) * exp(sigma_t (|c| - s)) with
             // sigma_t (|c| - s) <= sigma_t r^2 / |c| ~ 1e-5, so the second factor is 1 + x to fp32 precision
             // (src/photon.rs:474-493: k2(d^2/r^2)/r^2 with k2(x) = 3/pi (1-x)^2).
-            auto flush = [&](uint32_t nb, auto counting) {
+            // Two kinds of photons: PLAIN ones lie in front of every ray of the pixel and nearer to the eye than every hit, so
+            // their test is the radius test alone (as a clamp of the kernel's argument: no comparison at all); GUARDED ones --
+            // behind the eye's plane or inside the shell between the nearest and the farthest hit -- take the full test.
+            auto flush = [&](const uint32_t* list, uint32_t nb, auto counting, auto plain) {
                 if (lane_ < nb) {
-                    const PhotonRec raw = q.v_ph[pend_list[lane_]];
+                    const PhotonRec raw = q.v_ph[list[lane_]];
                     const V c = xyz(raw.pos_r) - eye0;
                     const float r2 = raw.pos_r.w * raw.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = __builtin_sqrtf(c2);
                     const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
@@ -1124,49 +1129,72 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                             const float disk = dot(c, rd);
                             const V dv = fma3(disk, rd, -c);
                             const float dist2 = dot(dv, dv);
-                            const bool ok = disk > 0.f && dist2 < r2 && c2 <= ray.w;
-                            const float tmp = fmaf(-dist2, ir2, 1.f);
-                            const float w = tmp * tmp * fmaf(-sigma_t, disk, one_plus);
-                            acc = fma3(ok ? w : 0.f, pw, acc);
-                            if (decltype(counting)::value) n_ok += ok ? 1u : 0u;
+                            if (decltype(plain)::value) {
+                                const float tmp = fmaxf(fmaf(-dist2, ir2, 1.f), 0.f);   // 0 from the radius on
+                                acc = fma3(tmp * tmp * fmaf(-sigma_t, disk, one_plus), pw, acc);
+                                if (decltype(counting)::value) n_ok += tmp > 0.f ? 1u : 0u;
+                            } else {
+                                const bool ok = disk > 0.f && dist2 < r2 && c2 <= ray.w;
+                                const float tmp = fmaf(-dist2, ir2, 1.f);
+                                const float w = tmp * tmp * fmaf(-sigma_t, disk, one_plus);
+                                acc = fma3(ok ? w : 0.f, pw, acc);
+                                if (decltype(counting)::value) n_ok += ok ? 1u : 0u;
+                            }
                         }
                     }
                     beam_sum = beam_sum + acc;
                     if (decltype(counting)::value) { c_leaf += n_s; c_acc += n_ok; }
                 }
             };
-            auto flush_batch = [&](uint32_t nb) {
-                if (a.counters) flush(nb, std::true_type{});
-                else flush(nb, std::false_type{});
+            auto flush_batch = [&](const uint32_t* list, uint32_t nb, auto plain) {
+                if (a.counters) flush(list, nb, std::true_type{}, plain);
+                else flush(list, nb, std::false_type{}, plain);
             };
-            uint32_t pend = 0;   // wave-uniform: entries of pend_list
+            auto prefix = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)); };
+            // a list has received `cnt` more entries: a full batch of 64 goes through the rays, the rest moves to the front
+            auto drain = [&](uint32_t* list, uint32_t& pend, auto plain) {
+                __builtin_amdgcn_wave_barrier();
+                if (pend >= 64u) {
+                    flush_batch(list, 64u, plain);
+                    __builtin_amdgcn_wave_barrier();
+                    const bool mv = lane_ + 64u < pend;
+                    uint32_t v = 0u;
+                    if (mv) v = list[64u + lane_];
+                    __builtin_amdgcn_wave_barrier();
+                    if (mv) list[lane_] = v;
+                    pend -= 64u;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            };
+            uint32_t* const guard_list = pend_list + kPendCap;
+            uint32_t pend = 0, pend_g = 0;   // wave-uniform: entries of pend_list / guard_list
             for (uint32_t base = 0; base < cand_n; base += 64u) {  // wave-uniform loop
-                bool take = false;
+                bool take = false, plain = false;
                 uint32_t idx = 0u;
                 if (base + lane_ < cand_n) {
                     idx = cand[base + lane_];
                     const F4 pr = q.v_ph[idx].pos_r;
                     take = !have_fs || !sphere_outside(fs, pr);
                     const V cc = xyz(pr) - eye0;
-                    take = take && dot(cc, cc) <= far2;  // the per-ray test rejects centres beyond the ray's hit
+                    const float cc2 = dot(cc, cc), along = dot(cc, fs.axis);
+                    take = take && cc2 <= far2;  // the per-ray test rejects centres beyond the ray's hit
+                    // in front of every ray of the pixel (within 89.4 degrees of its axis; the pixel's cone is ~1e-3 wide)
+                    plain = have_fs && cc2 <= near2 && along > 0.f && along * along > 1e-4f * cc2;
                 }
-                const uint64_t tm = __ballot(take);
-                if (take) pend_list[pend + __builtin_amdgcn_mbcnt_hi(uint32_t(tm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(tm), 0u))] = idx;
-                pend += uint32_t(__popcll(tm));
-                __builtin_amdgcn_wave_barrier();
-                if (pend >= 64u) {
-                    flush_batch(64u);
-                    __builtin_amdgcn_wave_barrier();
-                    const bool mv = lane_ + 64u < pend;   // the rest moves to the front
-                    uint32_t v = 0u;
-                    if (mv) v = pend_list[64u + lane_];
-                    __builtin_amdgcn_wave_barrier();
-                    if (mv) pend_list[lane_] = v;
-                    pend -= 64u;
-                    __builtin_amdgcn_wave_barrier();
-                }
+                const uint64_t tp = __ballot(take && plain), tg = __ballot(take && !plain);
+                if (take && plain) pend_list[pend + prefix(tp)] = idx;
+                if (take && !plain) guard_list[pend_g + prefix(tg)] = idx;
+                pend += uint32_t(__popcll(tp));
+                pend_g += uint32_t(__popcll(tg));
+                drain(pend_list, pend, std::true_type{});
+                drain(guard_list, pend_g, std::false_type{});
             }
-            if (pend) flush_batch(pend);
+            // what is left of both lists goes through the full test together (a batch costs the same whatever it holds)
+            if (lane_ < pend) guard_list[pend_g + lane_] = pend_list[lane_];
+            pend_g += pend;
+            __builtin_amdgcn_wave_barrier();
+            if (pend_g) flush_batch(guard_list, min(pend_g, 64u), std::false_type{});
+            if (pend_g > 64u) flush_batch(guard_list + 64, pend_g - 64u, std::false_type{});
             __builtin_amdgcn_wave_barrier();   // the gather lists of the surface estimate reuse this LDS
         }
         // ---- the surface gather's candidates, once for all the pixel's samples when their hit points form one cluster: every
@@ -2013,7 +2041,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     const bool medium = q.r.sc.has_medium != 0, bvh = q.r.sc.n_nodes != 0;
     // the wave-level surface gather: [K][64] distances, the ball walk's stack, candidate keys + (position, index) records
     const size_t coop_base = size_t(gather_size) * 64u + kBallStack;
-    q.region_dwords = uint32_t(std::max<size_t>({size_t(gather_lds) * 64u * 2u, size_t(kBeamCap) + 64u * 16u, size_t(kSuper) * 4u + kPendCap,
+    q.region_dwords = uint32_t(std::max<size_t>({size_t(gather_lds) * 64u * 2u, size_t(kBeamCap) + 64u * 16u, size_t(kSuper) * 4u + 2u * kPendCap,
                                                  gg ? 0u : coop_base + 5u * 160u}));
     q.coop_cap = (gg || !rpti::option_photon_coop_gather(s)) ? 0u : uint32_t(std::min<size_t>(kCoopCap, ((q.region_dwords - coop_base) / 5u) & ~size_t(3)));
     const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + 4u * size_t(q.region_dwords) * 4u;
