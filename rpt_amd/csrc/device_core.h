@@ -509,17 +509,22 @@ RPT_DEV void scan_prims(const SceneView& scene, V o, V d, float tmin, float& tbe
 // Which scanned records can a query touch that stays inside the ball (c, r) of each live lane?  Wave-uniform mask
 // for scan_prims<true> (the union over the lanes: one lane's ball reaching a box keeps that record for all of them).
 // Scenes with more than 64 bounded scan records do not occur (from 64 on, the scene-level tree takes over).
-RPT_DEV uint64_t scan_mask_for_ball(const SceneView& scene_, bool live, V c, float r) {
+// `touched` (optional): does any record's box reach THIS lane's ball?
+RPT_DEV uint64_t scan_mask_for_ball(const SceneView& scene_, bool live, V c, float r, bool* touched = nullptr) {
     const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     const uint32_t n = sc.n_sph + sc.n_cub + sc.n_aabb + sc.n_rect_x + sc.n_rect_y + sc.n_rect_z + sc.n_tri;
+    if (touched) *touched = n != 0u;
     if (n > 64u) return ~0ull;
+    bool mine = false;
     const float r2 = r * r;
     uint64_t mask = 0ull;
     auto reaches = [&](const AabbScan& b) {
         const float dx = fmaxf(fmaxf(b.lo.x - c.x, c.x - b.hi.x), 0.f);
         const float dy = fmaxf(fmaxf(b.lo.y - c.y, c.y - b.hi.y), 0.f);
         const float dz = fmaxf(fmaxf(b.lo.z - c.z, c.z - b.hi.z), 0.f);
-        return __any(live && fmaf(dx, dx, fmaf(dy, dy, dz * dz)) <= r2);
+        const bool t = live && fmaf(dx, dx, fmaf(dy, dy, dz * dz)) <= r2;
+        mine = mine || t;
+        return __any(t);
     };
     uint32_t i = 0;
     for (; i + 4u <= n; i += 4u) {   // four records' scalar loads in flight at a time
@@ -531,6 +536,7 @@ RPT_DEV uint64_t scan_mask_for_ball(const SceneView& scene_, bool live, V c, flo
     }
     for (; i < n; i++)
         if (reaches(uload(&sc.pbox[i]))) mask |= 1ull << i;
+    if (touched) *touched = mine;
     return mask;
 }
 // Would a walk of the per-mesh trees visit anything?  The two child boxes of every mesh root against the

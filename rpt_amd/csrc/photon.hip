@@ -1379,7 +1379,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         // the mask is wave-uniform) cannot decide the test and are skipped.  The closest hit below |disp| (1 - 1e-3)
         // is the closest hit of the unbounded query whenever that one would block, so the decisions are the same as
         // with the full scan.
-        auto add_photon = [&](V po, V pdir, V ppow, uint64_t vis_mask) {
+        // no_scan (wave-uniform): no lane needs the scan; lane_free: this lane's test cannot be blocked whatever a scan finds
+        auto add_photon = [&](V po, V pdir, V ppow, uint64_t vis_mask, bool no_scan = false, bool lane_free = false) {
             V disp = x - po;
             float len2 = dot(disp, disp);
             float ilen = rsq(len2);
@@ -1387,7 +1388,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             float len = len2 * ilen;
             float ts = BVH ? kInf : len * (1.f - 1e-3f);
             uint32_t cs = CODE_MISS, is = 0;
-            if (!(q.skip & 8u)) {  // diagnostic: 8 = no visibility scans
+            if (!(q.skip & 8u) && !no_scan) {  // diagnostic: 8 = no visibility scans
                 if (BVH) closest_hit<2, false>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
                 else scan_prims<true>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, vis_mask);
             }
@@ -1395,11 +1396,23 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             // rejects it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
             V hp = fma3(ts, pd, po) - x;
             bool own_plane = fabsf(dot(hp, n)) <= 1e-4f * len;
-            bool blocked = cs != CODE_MISS && !own_plane && ts < len * (1.f - 1e-3f);
+            bool blocked = !lane_free && cs != CODE_MISS && !own_plane && ts < len * (1.f - 1e-3f);
             if (!blocked || !(len2 > 0.f)) {  // (a query point that coincides with the photon has no ray to trace)
                 float c = fminf(fmaxf(dot(pdir, n), 0.f), 1.f);
                 sc_col = fma3(c, bsdf(mat, n, wo, pdir) * ppow, sc_col);
             }
+        };
+        // the room shell's box, a few ulps wider (see `lane_clear` below)
+        const bool shell_on = !BVH && sc.has_shell != 0u;
+        F4 sh_lo{}, sh_hi{};
+        if (shell_on) {
+            const ShellScan sh = uload(sc.shell);
+            const float e = 2e-6f * fmaxf(max3(fabsf(sh.lo.x), fabsf(sh.lo.y), fabsf(sh.lo.z)), max3(fabsf(sh.hi.x), fabsf(sh.hi.y), fabsf(sh.hi.z)));
+            sh_lo = F4{sh.lo.x - e, sh.lo.y - e, sh.lo.z - e, 0.f};
+            sh_hi = F4{sh.hi.x + e, sh.hi.y + e, sh.hi.z + e, 0.f};
+        }
+        auto in_shell = [&](V p) {
+            return !shell_on || (p.x >= sh_lo.x && p.x <= sh_hi.x && p.y >= sh_lo.y && p.y <= sh_hi.y && p.z >= sh_lo.z && p.z <= sh_hi.z);
         };
         bool todo = surf;
         // Consecutive samples of a lane fall within a pixel of each other: the previous gather radius (squared, doubled)
@@ -1471,7 +1484,16 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 if (!ok) r2k = 0.f;
                 // -- the terms of the photons within each lane's radius, in candidate order
                 uint64_t vis_mask = ~0ull;
-                if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, ok, x, __builtin_sqrtf(r2k) * (1.f + 1e-4f) + 1e-6f);
+                bool touched = true;   // some scanned record comes near this lane's ball
+                if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, ok, x, __builtin_sqrtf(r2k) * (1.f + 1e-4f) + 1e-6f, &touched);
+                // A lane's test cannot be blocked when no scanned record comes near its ball, the scene has no plane, and both
+                // ends of the segment lie inside the room shell: its faces bound a convex box, a segment between two points of
+                // the closed box meets a face at its ends only, and those the search interval leaves out.  (The scan itself is
+                // less exact there: next to an edge of the room it reports false crossings, see tools/photon_breakdown.py 128.)
+                // Then the gathered photon is visible by construction; the scan runs only if some lane of the term needs it.
+                // A point counts as inside within a few ulps.  The decision is the lane's own: no other lane's geometry enters.
+                bool lane_clear = !BVH && !touched && sc.n_pln == 0u && !(q.skip & 128u);   // (diagnostic: 128 = always scan)
+                lane_clear = lane_clear && in_shell(x);
                 const float reach2 = __builtin_sqrtf(r2k) + rho;
                 const float thr2 = ok ? reach2 * reach2 * (1.f + 1e-5f) : -1.f;
                 bool more = __ballot(ok) != 0ull && !(q.skip & 16u);   // diagnostic: 16 = no second pass
@@ -1504,7 +1526,10 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                         auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), jj)); };
                         const V pdir = mk(rl(fdir.x), rl(fdir.y), rl(fdir.z)), ppow = mk(rl(fpow.x), rl(fpow.y), rl(fpow.z));
                         if (a.counters) g_cnt[8]++;
-                        if (in) add_photon(po, pdir, ppow, vis_mask);
+                        const bool lane_free = lane_clear && in_shell(po);   // (po is wave-uniform)
+                        const bool no_scan = __ballot(in && !lane_free) == 0ull;
+                        if (a.counters && no_scan) g_cnt[1]++;
+                        if (in) add_photon(po, pdir, ppow, vis_mask, no_scan, lane_free);
                     }
                 }
                 if (ok) {
@@ -1538,7 +1563,6 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     member = todo && g_use > 0.f;
                     M = pix_M;
                 } else {
-                    if (a.counters) g_cnt[1]++;
                     pix_valid = false;   // (these rounds reuse the list's LDS)
                     const uint32_t lead = uint32_t(__ffsll((unsigned long long)cm)) - 1u;
                     auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lead)); };
@@ -1585,10 +1609,13 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             if (prev_r2 > 0.f) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2, 2.f * prev_r2);
             if (found < want_k || !(prev_r2 > 0.f)) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2);
             uint64_t vis_mask = ~0ull;
-            if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, true, x, __builtin_sqrtf(max_d2) * (1.f + 1e-4f) + 1e-6f);
+            bool touched = true;
+            if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, true, x, __builtin_sqrtf(max_d2) * (1.f + 1e-4f) + 1e-6f, &touched);
+            const bool lane_clear = !BVH && !touched && sc.n_pln == 0u && !(q.skip & 128u) && in_shell(x);   // as in the wave-level gather
             for (uint32_t k = 0; k < found; k++) {
                 const PhotonRec ph = q.s_ph[gi[k * 64u]];
-                add_photon(xyz(ph.pos_r), xyz(ph.dir), xyz(ph.pow), vis_mask);
+                const bool lane_free = lane_clear && in_shell(xyz(ph.pos_r));
+                add_photon(xyz(ph.pos_r), xyz(ph.dir), xyz(ph.pow), vis_mask, __ballot(!lane_free) == 0ull, lane_free);
             }
         }
         if (surf) {
@@ -1614,7 +1641,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         atomicAdd(&a.counters[0], c_samp);
         atomicAdd(&a.counters[5], c_leaf);
         atomicAdd(&a.counters[6], c_acc);
-        // the wave-level surface gather: [8] trips with a gather, [9] cluster rounds, [10] steps of the ball walks, [11] candidates,
+        // the wave-level surface gather: [8] trips with a gather, [9] photon terms without a visibility scan, [10] steps of the ball walks, [11] candidates,
         // [12] overfull walks, [13] / [14] selection steps / list updates, [15] / [16] candidates looked at / photon terms of the
         // second pass, [17] new anchors, [18] / [19] trips / lanes that searched one by one
         if (lane_ == 0u)

@@ -17,7 +17,7 @@ r.photon_sample_array(spp)
 c = r.counters()
 out = (C.c_uint64 * 56)()
 _lib.check(_lib.load().rpt_debug_section_counters(r.scene._handle, out))
-names = ["trips with a gather", "cluster rounds", "ball-walk steps", "candidates", "overfull walks", "selection steps",
+names = ["trips with a gather", "terms without a scan", "ball-walk steps", "candidates", "overfull walks", "selection steps",
          "list updates", "second-pass candidates", "second-pass photon terms", "new anchors",
          "trips searching one by one", "lanes searching one by one"]
 trips = max(int(out[0]), 1)
