@@ -177,9 +177,13 @@ int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_ch
  * object scan, default 64), "instancing" 0/1 (read by rpt_scene_commit: store a mesh that several
  * shapes share once and instance it, default 1), "room_shell" 0/1 (read by rpt_scene_commit: answer the
  * rectangles that are the faces of one axis-aligned box with a single slab test, default 1),
- * "photon_block_lists" 0/1 (camera pass of the beam x point kind: collect the photon spheres of each 8x8
- * pixel block once per work batch, default 1; 0 walks the tree per sample), "photon_skip" (diagnostic bit
- * mask that switches parts of the photon camera pass off), "defer_lanes" / "defer_stop" (scenes whose meshes
+ * "photon_block_lists" 0/1 (camera pass of the beam x point kind: collect the photon spheres of each strip of an
+ * 8x8 pixel block once per work item and test them with one photon per lane, default 1; 0 walks the tree per
+ * sample), "photon_parts" (work items per 8x8 pixel block and sample chunk of the photon camera pass: the block's
+ * rows in 1, 2, 4 or 8 strips, default 4; changes the fp32 order of a pixel's beam sum, nothing else),
+ * "photon_coop_gather" 0/1 (surface estimate of the photon camera pass: the wave collects the candidates of a
+ * pixel's samples together and every lane picks its K nearest from that list, default 1; 0 searches per lane),
+ * "photon_skip" (diagnostic bit mask that switches parts of the photon camera pass off), "defer_lanes" / "defer_stop" (scenes whose meshes
  * have their own trees: a wave starts its parked tree walks when this many lanes wait, default 32, and leaves
  * them when fewer than this many are still walking, default 16; the image does not depend on either),
  * "bvh_leaf_max" (read by rpt_scene_commit: triangles per leaf of a mesh tree, default 4 -- C5: 49.8 / 43.1 / 41.1 /
