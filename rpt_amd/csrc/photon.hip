@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <type_traits>
 #include <vector>
 
@@ -1685,6 +1686,49 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
 using namespace rptg;
 
 namespace {
+// Device buffers of the photon maps of one scene, kept from one map to the next.  Renderer::photon_render builds a new map
+// per call (src/photon.rs:655-704): ~40 buffers of up to 100 MB each, and hipMalloc / hipFree of that size cost
+// milliseconds apiece (a C4 step spent 20 of its 140 ms in them).  A block is handed out again when it is free and fits
+// (at most twice the size asked for); blocks that stayed unused for three maps are given back.
+struct DevPool {
+    struct Block { void* p; size_t cap; bool used; uint32_t idle; };
+    std::vector<Block> blocks;
+    ~DevPool() { for (auto& b : blocks) (void)hipFree(b.p); }
+    hipError_t alloc(void** out, size_t bytes) {
+        bytes = std::max<size_t>(bytes, 64);
+        int best = -1;
+        for (size_t i = 0; i < blocks.size(); i++)
+            if (!blocks[i].used && blocks[i].cap >= bytes && blocks[i].cap <= 2 * bytes + (size_t(1) << 20) &&
+                (best < 0 || blocks[i].cap < blocks[size_t(best)].cap))
+                best = int(i);
+        if (best >= 0) {
+            blocks[size_t(best)].used = true;
+            blocks[size_t(best)].idle = 0;
+            *out = blocks[size_t(best)].p;
+            return hipSuccess;
+        }
+        const size_t cap = bytes + bytes / 8;   // photon counts move by a fraction of a percent from map to map
+        hipError_t e = hipMalloc(out, cap);
+        if (e == hipSuccess) blocks.push_back(Block{*out, cap, true, 0});
+        return e;
+    }
+    void free(void* p) {
+        if (!p) return;
+        for (auto& b : blocks)
+            if (b.p == p) { b.used = false; return; }
+        (void)hipFree(p);
+    }
+    void next_map() {   // called between maps, with the device idle
+        for (size_t i = 0; i < blocks.size();) {
+            if (!blocks[i].used && ++blocks[i].idle > 3) {
+                (void)hipFree(blocks[i].p);
+                blocks.erase(blocks.begin() + long(i));
+            } else {
+                i++;
+            }
+        }
+    }
+};
 struct DevLbvh {
     BvhNode* nodes = nullptr;
     PhotonRec* sorted = nullptr;
@@ -1705,18 +1749,19 @@ struct PhotonMapDev {
     size_t cand_words = 0;
     uint32_t* d_gather = nullptr;  // per-wave k-nearest lists of gathers too large for LDS
     size_t gather_words = 0;
+    std::shared_ptr<DevPool> pool = std::make_shared<DevPool>();   // handed on to the scene's next map (fresh_map)
     void release_raw() {
-        (void)hipFree(raw_s); (void)hipFree(raw_v);
+        pool->free(raw_s); pool->free(raw_v);
         raw_s = raw_v = nullptr;
         n_raw_s = n_raw_v = 0;
     }
     void release() {
         (void)hipSetDevice(device);
-        (void)hipFree(surf.nodes); (void)hipFree(surf.sorted);
-        (void)hipFree(vol.nodes); (void)hipFree(vol.sorted);
-        (void)hipFree(d_overflow);
-        (void)hipFree(d_cand);
-        (void)hipFree(d_gather);
+        pool->free(surf.nodes); pool->free(surf.sorted);
+        pool->free(vol.nodes); pool->free(vol.sorted);
+        pool->free(d_overflow);
+        pool->free(d_cand);
+        pool->free(d_gather);
         release_raw();
         d_overflow = nullptr;
         d_cand = nullptr;
@@ -1727,14 +1772,16 @@ struct PhotonMapDev {
         built = false;
     }
 };
-struct Tmp {
+struct Tmp {   // scratch buffers of one build step, back in the pool when it is over (the step ends with a synchronise)
+    DevPool& pool;
     std::vector<void*> ptrs;
+    explicit Tmp(DevPool& p) : pool(p) {}
     ~Tmp() {
-        for (void* p : ptrs) (void)hipFree(p);
+        for (void* p : ptrs) pool.free(p);
     }
     template <class T>
     hipError_t alloc(T** p, size_t n) {
-        hipError_t e = hipMalloc((void**)p, std::max<size_t>(n * sizeof(T), 64));
+        hipError_t e = pool.alloc((void**)p, n * sizeof(T));
         if (e == hipSuccess) ptrs.push_back(*p);
         return e;
     }
@@ -1743,13 +1790,13 @@ struct Tmp {
 // Build the LBVH of `n` photons in `raw` (consumed: the sorted copy is kept).  radius_k > 0: also
 // compute the k-NN radii and refit the boxes with them (sphere map for the beam query).
 // mode 0: point map; 1: point map + k-NN radii, then sphere boxes; 2: beam map (boxes of whole beams)
-int build_lbvh(PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t st) {
+int build_lbvh(DevPool& pool, PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t st) {
     const bool with_radius = mode == 1;
     const int first_mode = mode == 2 ? 2 : 0;
     out = DevLbvh{};
     out.n = n;
     if (n == 0) return RPT_OK;
-    Tmp tmp;
+    Tmp tmp(pool);
     float* lohi;
     uint64_t *keys, *keys2;
     uint32_t *vals, *vals2, *left, *right, *par_i, *par_l, *flags, *rlo, *rhi;
@@ -1778,10 +1825,10 @@ int build_lbvh(PhotonRec* raw, uint32_t n, int mode, DevLbvh& out, hipStream_t s
     void* temp;
     RPTI_HIP_TRY(tmp.alloc((char**)&temp, temp_bytes));
     RPTI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, int(n), 0, 63, st));
-    RPTI_HIP_TRY(hipMalloc((void**)&out.sorted, size_t(n) * sizeof(PhotonRec)));
+    RPTI_HIP_TRY(pool.alloc((void**)&out.sorted, size_t(n) * sizeof(PhotonRec)));
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, raw, vals2, n, out.sorted);
     if (n >= 2) {
-        RPTI_HIP_TRY(hipMalloc((void**)&out.nodes, size_t(n - 1) * sizeof(BvhNode)));
+        RPTI_HIP_TRY(pool.alloc((void**)&out.nodes, size_t(n - 1) * sizeof(BvhNode)));
         hipLaunchKernelGGL(karras_kernel, dim3(blocks), dim3(256), 0, st, keys2, int(n), left, right, par_i, par_l, rlo, rhi);
         RPTI_HIP_TRY(hipMemsetAsync(flags, 0, size_t(n) * 4, st));
         hipLaunchKernelGGL(refit_small_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), rlo, rhi, box, first_mode);
@@ -1865,7 +1912,7 @@ static int shoot_range(rpt_scene* s, PhotonMapDev* pm, uint64_t photon_count, ui
     hipEvent_t e0, e1;
     RPTI_HIP_TRY(hipEventCreate(&e0));
     RPTI_HIP_TRY(hipEventCreate(&e1));
-    Tmp tmp;
+    Tmp tmp(*pm->pool);
     ShootArgs a{};
     a.sc = sd.view;
     a.n_photons = n;
@@ -1907,8 +1954,8 @@ static int shoot_range(rpt_scene* s, PhotonMapDev* pm, uint64_t photon_count, ui
     RPTI_HIP_TRY(hipStreamSynchronize(st));
     const uint64_t ts = tot[0], tv = tot[1];
     if (ts >= (1ull << 26) || tv >= (1ull << 26)) return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons (2^26 records per map)");
-    RPTI_HIP_TRY(hipMalloc((void**)&pm->raw_s, std::max<size_t>(ts * sizeof(PhotonRec), 64)));
-    RPTI_HIP_TRY(hipMalloc((void**)&pm->raw_v, std::max<size_t>(tv * sizeof(PhotonRec), 64)));
+    RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->raw_s, ts * sizeof(PhotonRec)));
+    RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->raw_v, tv * sizeof(PhotonRec)));
     pm->n_raw_s = ts;
     pm->n_raw_v = tv;
     a.off_s = d_os;
@@ -1934,9 +1981,9 @@ static int build_maps(PhotonMapDev* pm, const PhotonRec* d_s, uint64_t n_s, cons
     RPTI_HIP_TRY(hipEventCreate(&e2));
     RPTI_HIP_TRY(hipEventRecord(e1, st));
     const int kind = pm->kind;
-    int rc = build_lbvh(const_cast<PhotonRec*>(d_s), uint32_t(n_s), 0, pm->surf, st);
+    int rc = build_lbvh(*pm->pool, const_cast<PhotonRec*>(d_s), uint32_t(n_s), 0, pm->surf, st);
     if (rc == RPT_OK)
-        rc = build_lbvh(const_cast<PhotonRec*>(d_v), uint32_t(n_v),
+        rc = build_lbvh(*pm->pool, const_cast<PhotonRec*>(d_v), uint32_t(n_v),
                         kind == RPT_PHOTON_POINT_BEAM ? 1 : (kind == RPT_PHOTON_BEAM_BEAM ? 2 : 0), pm->vol, st);
     if (rc != RPT_OK) return rc;
     RPTI_HIP_TRY(hipEventRecord(e2, st));
@@ -1964,11 +2011,19 @@ static int photon_args_ok(rpt_scene* s, uint64_t photon_count, int32_t kind) {
 }
 static PhotonMapDev* fresh_map(rpt_scene* s, uint64_t photon_count, int32_t kind) {
     void*& slot = rpti::photon_slot(s);
+    std::shared_ptr<DevPool> pool;
     if (slot) {
+        // the old map's buffers go back to the pool and may be handed out at once: nothing may still be reading them
+        // (hipFree used to wait for the device here)
+        (void)hipSetDevice(rpti::scene_dev(s).device);
+        (void)hipDeviceSynchronize();
+        pool = static_cast<PhotonMapDev*>(slot)->pool;
         rpti::photon_release(slot);
         slot = nullptr;
+        pool->next_map();
     }
     auto* pm = new PhotonMapDev();
+    if (pool) pm->pool = pool;
     pm->device = rpti::scene_dev(s).device;
     pm->kind = kind;
     pm->photon_count = photon_count;
@@ -2028,7 +2083,7 @@ int rpt_photon_map_from_records(rpt_scene* s, uint64_t photon_count, int32_t kin
     PhotonMapDev* pm = fresh_map(s, photon_count, kind);
     pm->build_ms[0] = keep.build_ms[0];
     rc = build_maps(pm, static_cast<const PhotonRec*>(d_surface), n_surface, static_cast<const PhotonRec*>(d_volume), n_volume);
-    (void)hipFree(keep.raw_s); (void)hipFree(keep.raw_v);
+    pm->pool->free(keep.raw_s); pm->pool->free(keep.raw_v);
     if (rc != RPT_OK) { drop_map(s); return rc; }
     return RPT_OK;
 }
@@ -2104,7 +2159,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
                                                  gg ? 0u : coop_base + 5u * 160u}));
     q.coop_cap = (gg || !rpti::option_photon_coop_gather(s)) ? 0u : uint32_t(std::min<size_t>(kCoopCap, ((q.region_dwords - coop_base) / 5u) & ~size_t(3)));
     const size_t lds = (bvh ? 32u * 256u * 4u : 0u) + 4u * size_t(q.region_dwords) * 4u;
-    if (!pm->d_overflow) RPTI_HIP_TRY(hipMalloc((void**)&pm->d_overflow, 64));
+    if (!pm->d_overflow) RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->d_overflow, 64));
     RPTI_HIP_TRY(hipMemsetAsync(pm->d_overflow, 0, 4, st));
     q.overflow = pm->d_overflow;
     auto launch = [&](const RenderArgs& ra, int nb, hipStream_t stream) -> hipError_t {
@@ -2117,10 +2172,10 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     if (gg) {  // one [2][K][64]-dword region per wave of the largest grid run_persistent may launch
         const size_t words = size_t(rpti::scene_dev(s).n_cus) * size_t(bpc) * 4u * size_t(gather_max) * 128u;
         if (words > pm->gather_words) {
-            (void)hipFree(pm->d_gather);
+            pm->pool->free(pm->d_gather);
             pm->d_gather = nullptr;
             pm->gather_words = 0;
-            RPTI_HIP_TRY(hipMalloc((void**)&pm->d_gather, words * 4u));
+            RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->d_gather, words * 4u));
             pm->gather_words = words;
         }
         q.gather = pm->d_gather;
@@ -2128,10 +2183,10 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     if (pm->kind == RPT_PHOTON_POINT_BEAM && medium && pm->vol.n && rpti::option_photon_block_lists(s)) {
         const size_t words = size_t(rpti::scene_dev(s).n_cus) * size_t(bpc) * 4u * kCandCap;
         if (words > pm->cand_words) {
-            (void)hipFree(pm->d_cand);
+            pm->pool->free(pm->d_cand);
             pm->d_cand = nullptr;
             pm->cand_words = 0;
-            RPTI_HIP_TRY(hipMalloc((void**)&pm->d_cand, words * 4u));
+            RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->d_cand, words * 4u));
             pm->cand_words = words;
         }
         q.cand = pm->d_cand;
