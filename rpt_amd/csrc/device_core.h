@@ -576,15 +576,24 @@ struct WalkState {
 RPT_DEV WalkState walk_begin(const SceneView&) { return WalkState{uload(&kernarg_scene()->meshes[0]).root, 0u, 0u}; }
 // `cap`: rows of the stack column (a mesh tree is at most bvh_max_depth = 20 levels deep: it pushes at most 19 entries).
 template <bool COUNT>
+// `leaf_quarters`: the lanes reach their next leaf after very different numbers of steps (a few on average, a dozen for the
+// slowest of 25), and a descent that waits for the last of them runs most of its steps for a handful of lanes.  So the
+// descent pauses as soon as 4 x (lanes waiting at a leaf) >= leaf_quarters x (lanes still descending): the waiting lanes
+// test their triangles, the others go on from where they are.  Every lane still performs its own steps in its own order.
 RPT_DEV void walk_meshes_resumable(const SceneView& scene_, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t* stk,
                                    uint32_t stride, WalkState& w, uint32_t min_active, AnyHit any, uint32_t& c_nodes,
-                                   uint32_t& c_tris, uint32_t cap = 32u) {
+                                   uint32_t& c_tris, uint32_t cap = 32u, uint32_t leaf_quarters = 0u) {
     const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     const BvhNode* nodes = sc.nodes;
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
     uint32_t cur = w.cur, sp = w.sp, mesh = w.mesh;
     while (uint32_t(__popcll(__ballot(cur != kWalkDone))) >= min_active) {
-        while (!(cur & BVH_LEAF)) {  // kWalkDone has the leaf bit set, so finished lanes fall through
+        for (;;) {  // the descent (kWalkDone has the leaf bit set: finished lanes take no part)
+            const bool inner = !(cur & BVH_LEAF);
+            const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
+            if (n_inner == 0u) break;
+            if (leaf_quarters != 0u && 4u * uint32_t(__popcll(__ballot(!inner && cur != kWalkDone))) >= leaf_quarters * n_inner) break;
+            if (!inner) continue;
             const BvhNode nd = nodes[cur];
             if (COUNT) c_nodes++;
             float n0, f0, n1, f1;
@@ -605,7 +614,7 @@ RPT_DEV void walk_meshes_resumable(const SceneView& scene_, V o, V d, float tmin
                 cur = kWalkDone;
             }
         }
-        if (cur != kWalkDone) {
+        if ((cur & BVH_LEAF) && cur != kWalkDone) {   // (lanes that are still descending go on with the next round)
             const uint32_t first = cur & BVH_INDEX_MASK;
             const uint32_t count = ((cur >> 26) & 31u) + 1u;
             TriScan nxt = sc.btri[first];

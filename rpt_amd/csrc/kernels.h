@@ -28,6 +28,7 @@ struct RenderArgs {
     uint32_t lds_stack;       // 1: BVH stack in dynamic LDS
     uint32_t defer_lanes;     // per-mesh-tree kernels: parked tree walks per wave that trigger a walk (1..64)
     uint32_t defer_stop;      // ... and the number of still-walking lanes below which the wave leaves the walk
+    uint32_t walk_leaf_quarters;  // ... and the descent of a walk pauses for the leaves when 4 x (lanes at a leaf) >= this x (lanes descending); 0: never
 };
 
 // The device functions read the scene view at kernarg + 0 (kernarg_scene in device_core.h): every kernel that calls them

@@ -457,7 +457,7 @@ void render_kernel(const RenderArgs a) {
                         any = AnyHit{lo <= hi ? v_dist * (1.f - 1e-3f) : -kInf, lo, hi};
                     }
                     walk_meshes_resumable<COUNT>(sc, qo, qd, ray_tmin(qo), q_t, q_code, stk, stride, walk,
-                                                 idle ? 1u : a.defer_stop, any, c_nodes, c_btris, kStackRows);
+                                                 idle ? 1u : a.defer_stop, any, c_nodes, c_btris, kStackRows, a.walk_leaf_quarters);
                     if (walk.cur == kWalkDone) {
                         phase = shadow ? PH_HAVES : PH_HAVEP;
                         SECT(16);

@@ -65,6 +65,7 @@ struct rpt_options {
     int64_t bvh_leaf_max = 4;       // triangles per leaf of a mesh tree (read by rpt_scene_commit)
     int64_t bvh_max_depth = 20;     // a mesh tree deeper than this is rebuilt balanced (read by rpt_scene_commit)
     int64_t defer_stop = 16;        // still-walking lanes below which a wave leaves the walk (the rest resume later)
+    int64_t walk_leaf_quarters = 6; // deferred walks: test the leaves when 4 x (lanes at a leaf) >= this x (lanes still descending); 0 = when all are there
     int64_t defer_lanes = 32;       // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
     int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built
 };
@@ -86,6 +87,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); o.defer_lanes = value; }
     else if (s == "bvh_leaf_max") { if (value < 1 || value > 16) return fail(RPT_ERR_INVALID, "bvh_leaf_max must be 1..16"); o.bvh_leaf_max = value; }
     else if (s == "bvh_max_depth") { if (value < 1 || value > 20) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..20"); o.bvh_max_depth = value; }
+    else if (s == "walk_leaf_quarters") { if (value < 0 || value > 256) return fail(RPT_ERR_INVALID, "walk_leaf_quarters must be 0..256"); o.walk_leaf_quarters = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); o.scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option: " + s);
@@ -1575,6 +1577,7 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     a.lds_stack = s->view.n_nodes ? 1u : 0u;
     a.defer_lanes = uint32_t(s->opt.defer_lanes);
     a.defer_stop = uint32_t(std::min(s->opt.defer_stop, s->opt.defer_lanes));
+    a.walk_leaf_quarters = uint32_t(s->opt.walk_leaf_quarters);
     return RPT_OK;
 }
 
