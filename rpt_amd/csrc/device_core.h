@@ -582,7 +582,7 @@ template <bool COUNT>
 // test their triangles, the others go on from where they are.  Every lane still performs its own steps in its own order.
 RPT_DEV void walk_meshes_resumable(const SceneView& scene_, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t* stk,
                                    uint32_t stride, WalkState& w, uint32_t min_active, AnyHit any, uint32_t& c_nodes,
-                                   uint32_t& c_tris, uint32_t cap = 32u, uint32_t leaf_quarters = 0u) {
+                                   uint32_t& c_tris, uint32_t cap = 32u, uint32_t leaf_quarters = 0u, uint32_t* c_wave = nullptr) {
     const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     const BvhNode* nodes = sc.nodes;
     const V inv = mk(rcp(d.x), rcp(d.y), rcp(d.z));
@@ -593,6 +593,7 @@ RPT_DEV void walk_meshes_resumable(const SceneView& scene_, V o, V d, float tmin
             const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
             if (n_inner == 0u) break;
             if (leaf_quarters != 0u && 4u * uint32_t(__popcll(__ballot(!inner && cur != kWalkDone))) >= leaf_quarters * n_inner) break;
+            if (COUNT && c_wave) c_wave[0]++;   // (wave-level: descent steps)
             if (!inner) continue;
             const BvhNode nd = nodes[cur];
             if (COUNT) c_nodes++;
@@ -613,6 +614,12 @@ RPT_DEV void walk_meshes_resumable(const SceneView& scene_, V o, V d, float tmin
             } else {
                 cur = kWalkDone;
             }
+        }
+        if (COUNT && c_wave) {   // (wave-level: triangle steps of this round = the largest leaf among the lanes at one)
+            uint32_t mx = 0;
+            for (uint32_t k = 1; k <= 4u; k++)
+                if (__ballot((cur & BVH_LEAF) && cur != kWalkDone && ((cur >> 26) & 31u) + 1u >= k) != 0ull) mx = k;
+            c_wave[1] += mx;
         }
         if ((cur & BVH_LEAF) && cur != kWalkDone) {   // (lanes that are still descending go on with the next round)
             const uint32_t first = cur & BVH_INDEX_MASK;

@@ -237,6 +237,7 @@ void render_kernel(const RenderArgs a) {
     uint32_t pool_chunk = 0, pool_x0 = 0, pool_y0 = 0;  // wave-uniform: the batch's chunk and 8x8 block origin
 
     uint32_t c_samples = 0, c_rays = 0, c_vertices = 0, c_trips = 0, c_nodes = 0, c_btris = 0;
+    uint32_t c_wave[2] = {0, 0}, w_tot[2] = {0, 0};   // steps of the deferred walks (descent, triangles): of the walk at hand as its lanes count them; wave-level totals
 
     // ---- per-mesh-tree flavour (BVH == 1): deferred walks.  In fog most rays never reach a mesh, a few walk
     // a hundred nodes, and a wave walks as long as its slowest lane: 43 wave-level node steps per query for 3.4
@@ -447,6 +448,7 @@ void render_kernel(const RenderArgs a) {
             const uint64_t wm = __ballot(waiting);
             const bool idle = __ballot(alive && !waiting) == 0;  // nothing else this wave could do
             if (wm != 0 && (uint32_t(__popcll(wm)) >= a.defer_lanes || idle)) {
+                if (COUNT) c_wave[0] = c_wave[1] = 0;
                 if (waiting) {
                     SECT(15);
                     const bool shadow = phase == PH_WAITS;
@@ -457,12 +459,19 @@ void render_kernel(const RenderArgs a) {
                         any = AnyHit{lo <= hi ? v_dist * (1.f - 1e-3f) : -kInf, lo, hi};
                     }
                     walk_meshes_resumable<COUNT>(sc, qo, qd, ray_tmin(qo), q_t, q_code, stk, stride, walk,
-                                                 idle ? 1u : a.defer_stop, any, c_nodes, c_btris, kStackRows, a.walk_leaf_quarters);
+                                                 idle ? 1u : a.defer_stop, any, c_nodes, c_btris, kStackRows, a.walk_leaf_quarters, c_wave);
                     if (walk.cur == kWalkDone) {
                         phase = shadow ? PH_HAVES : PH_HAVEP;
                         SECT(16);
                         if ((q_code >> 28) == K_BVHTRI) { SECT(17); }
                         if (shadow) { SECT(18); }
+                    }
+                }
+                if (COUNT) {   // every lane that walked counted the same steps
+                    for (int k = 0; k < 2; k++) {
+                        uint32_t v = c_wave[k];
+                        for (int off = 32; off; off >>= 1) v = max(v, uint32_t(__shfl_xor(int(v), off)));
+                        w_tot[k] += v;
                     }
                 }
             }
@@ -566,6 +575,7 @@ void render_kernel(const RenderArgs a) {
         atomicAdd(&a.counters[1], (unsigned long long)c_rays);
         atomicAdd(&a.counters[2], (unsigned long long)c_vertices);
         if ((threadIdx.x & 63u) == 0) atomicAdd(&a.counters[3], (unsigned long long)c_trips);
+        if ((threadIdx.x & 63u) == 0) { atomicAdd(&a.counters[46], (unsigned long long)w_tot[0]); atomicAdd(&a.counters[47], (unsigned long long)w_tot[1]); }
         atomicAdd(&a.counters[5], (unsigned long long)c_nodes);
         atomicAdd(&a.counters[6], (unsigned long long)c_btris);
     }

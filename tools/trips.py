@@ -26,3 +26,7 @@ for k, nm in enumerate(NAMES):
     w, l = int(out[2 * k]), int(out[2 * k + 1])
     if w:
         print(f"  {nm:48s} execs/trip {w / c['wave_trips']:.3f}   lanes {l / w:5.1f} / 64")
+if int(out[38]):
+    nd, tr = int(out[38]), int(out[39])   # wave-level steps of the deferred walks: descent, triangles
+    print(f"  deferred walks: {nd / c['wave_trips']:.2f} descent steps per trip with {c['bvh_nodes'] / nd:5.1f} / 64 lanes, "
+          f"{tr / c['wave_trips']:.2f} triangle steps per trip with {c['bvh_tris'] / max(tr, 1):5.1f} / 64 lanes")
