@@ -186,6 +186,8 @@ int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_ch
  * "photon_skip" (diagnostic bit mask that switches parts of the photon camera pass off), "defer_lanes" / "defer_stop" (scenes whose meshes
  * have their own trees: a wave starts its parked tree walks when this many lanes wait, default 32, and leaves
  * them when fewer than this many are still walking, default 16; the image does not depend on either),
+ * "walk_leaf_quarters" (same scenes: the descent of such a walk pauses for the triangle tests as soon as 4 x the lanes
+ * waiting at a leaf >= this x the lanes still descending, default 6, 0 = when every lane is at a leaf; no effect on the image),
  * "bvh_leaf_max" (read by rpt_scene_commit: triangles per leaf of a mesh tree, default 4 -- C5: 49.8 / 43.1 / 41.1 /
  * 41.1 / 41.7 ms for 1 / 2 / 4 / 6 / 8), "bvh_max_depth" (read by rpt_scene_commit: a mesh tree that the SAH builder makes deeper than this is rebuilt
  * with object-median splits, default and maximum 20 -- the traversal stack holds 21 entries per mesh tree, 32 for scene tree + mesh tree;
