@@ -333,19 +333,21 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
     cam = Camera.look_at(vec3(0.0, 1.5, 6.0), vec3(0.0, 0.0, 0.0), vec3(0, 1, 0), 0.8)
     w, h, spp = 96, 72, 24
 
-    def render(lanes, stop):
+    def render(lanes, stop, leaf_quarters=6):
         rpt_amd.set_option("defer_lanes", lanes)
         rpt_amd.set_option("defer_stop", stop)
+        rpt_amd.set_option("walk_leaf_quarters", leaf_quarters)   # when a walk's descent pauses for the triangle tests
         r = Renderer(sc, cam).width(w).height(h).max_bounces(3).seed(6)
         img = r.sample_array(spp)
         st = r.scene_stats()
         assert st["bvh_nodes"] > 0 and st["scene_bvh"] == 0      # the per-mesh-tree kernel
         return img
     try:
-        frames = [render(*v) for v in ((32, 16), (1, 1), (64, 64), (64, 1), (8, 5))]
+        frames = [render(*v) for v in ((32, 16), (1, 1), (64, 64), (64, 1), (8, 5), (32, 16, 0), (32, 16, 1), (40, 8, 64))]
     finally:
         rpt_amd.set_option("defer_lanes", 32)
         rpt_amd.set_option("defer_stop", 16)
+        rpt_amd.set_option("walk_leaf_quarters", 6)
     for f in frames[1:]:
         assert np.array_equal(frames[0], f)
     exp = _oracle(sc).render(cam, w, h, spp, 3, seed=6, robust=1)

@@ -355,3 +355,25 @@ def test_wave_level_surface_gather_equals_one_search_per_lane(n, gather):
     assert np.all(np.isfinite(imgs[0])) and imgs[1].mean() > 0
     assert rel_rms(imgs[0], imgs[1]) < 1e-5
     assert np.max(np.abs(imgs[0] - imgs[1]) / (np.abs(imgs[1]) + 1e-3 * imgs[1].mean())) < 1e-3
+
+
+def test_photon_maps_of_changing_size_reuse_their_device_buffers():
+    """Renderer::photon_render builds a new map per call; the device buffers of a scene's maps are kept in a pool
+    from one map to the next (photon.hip, DevPool) and handed out again when they fit.  Maps of other sizes in
+    between must not leave a trace: the third map equals the first, record for record and pixel for pixel."""
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    r = Renderer(scene, cam).width(32).height(32).gather_size(20).gather_size_volume(3).seed(9)
+
+    def build_and_render(n):
+        r.watts(14.65 * n)
+        st = r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+        r._sample_offset = 0
+        return st, r.photon_map_download(0), r.photon_map_download(1), r.photon_sample_array(5)
+    first = build_and_render(6000)
+    bigger = build_and_render(40000)
+    smaller = build_and_render(700)
+    again = build_and_render(6000)
+    assert bigger[0]["surface"] > 5 * first[0]["surface"] > 25 * smaller[0]["surface"] > 0
+    assert first[0]["surface"] == again[0]["surface"] and first[0]["volume"] == again[0]["volume"]
+    assert np.array_equal(first[1], again[1]) and np.array_equal(first[2], again[2])
+    assert np.array_equal(first[3], again[3]) and first[3].mean() > 0
