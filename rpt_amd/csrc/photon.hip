@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
                     const V pw = kk * xyz(raw.pow);
                     const float one_plus = fmaf(sigma_t, len, 1.f);
-                    V acc = mk(0, 0, 0);
+                    float wsum = 0.f;   // the photon's weights over the pixel's rays: its power multiplies their sum once
                     uint32_t n_ok = 0;
                     if (!(q.skip & 4u)) {  // diagnostic: 4 = tree walk, culling and photon preparation only
 #pragma unroll 4
@@ -1162,18 +1162,18 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                             const float dist2 = dot(dv, dv);
                             if (decltype(plain)::value) {
                                 const float tmp = fmaxf(fmaf(-dist2, ir2, 1.f), 0.f);   // 0 from the radius on
-                                acc = fma3(tmp * tmp * fmaf(-sigma_t, disk, one_plus), pw, acc);
+                                wsum = fmaf(tmp * tmp, fmaf(-sigma_t, disk, one_plus), wsum);
                                 if (decltype(counting)::value) n_ok += tmp > 0.f ? 1u : 0u;
                             } else {
                                 const bool ok = disk > 0.f && dist2 < r2 && c2 <= ray.w;
                                 const float tmp = fmaf(-dist2, ir2, 1.f);
                                 const float w = tmp * tmp * fmaf(-sigma_t, disk, one_plus);
-                                acc = fma3(ok ? w : 0.f, pw, acc);
+                                wsum += ok ? w : 0.f;
                                 if (decltype(counting)::value) n_ok += ok ? 1u : 0u;
                             }
                         }
                     }
-                    beam_sum = beam_sum + acc;
+                    beam_sum = fma3(wsum, pw, beam_sum);
                     if (decltype(counting)::value) { c_leaf += n_s; c_acc += n_ok; }
                 }
             };
