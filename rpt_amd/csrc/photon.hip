@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                                      q.coop_cap, steps);
                 if (a.counters) { g_cnt[2] += steps; if (pix_M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += pix_M; }
                 if (pix_M != kCoopOverflow) {
-                    sort_candidates(cl, keys, pix_M, pxc);
+                    if (!(q.skip & 64u)) sort_candidates(cl, keys, pix_M, pxc);   // (diagnostic: 64 = collection only)
                     pix_valid = true;
                 }
             }
@@ -1626,6 +1626,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     rho = __builtin_sqrtf(dot(dk, dk));
                     if (q.skip & 32u) { if (member) { max_d2 = 0.5f * guess; todo = false; } continue; }   // diagnostic: collection + ordering only
                 }
+                if (round == 0u && (q.skip & 96u)) { if (member) { max_d2 = 0.5f * guess; todo = false; } continue; }   // diagnostic: 32 / 64 = no selection
                 const bool ok = serve(member, g_use, rho, M);
                 if (member && !ok) guess = fmaxf(guess, 4.f * g_use);   // too few photons inside: twice the radius next round
                 __builtin_amdgcn_wave_barrier();
