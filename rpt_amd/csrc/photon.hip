@@ -946,6 +946,543 @@ RPT_DEV void sort_candidates(F4* cand, float* keys, uint32_t M, V c) {
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---- pieces of the camera pass (photon_query_kernel).  `q`: the kernel's arguments where they lie (kernarg_args).
+typedef const __attribute__((address_space(4))) QueryArgs& QueryK;
+
+// The volume estimates with the SAMPLES in the lanes (beam x beam; beam x point when the rays share no origin or the strip
+// has no candidate list): the sum of the weighted photon powers along this lane's ray, before the medium's colour.
+template <int KIND>
+RPT_DEV V volume_estimate_sample_lanes(QueryK q, bool active, V ro, V rd, bool hit, float t, float sigma_t, float phase,
+                                       uint32_t* wstack, F4* stage, unsigned long long& c_leaf, unsigned long long& c_acc) {
+    V vc = mk(0, 0, 0);
+    // The staging lane pre-computes what depends on the photon only: pos_r.w = r^2, pow = power *
+    // 3/pi * phase / r^2, pow.w = 1/r^2 (src/photon.rs:474-493: k2(d^2/r^2)/r^2 with k2(x) = 3/pi (1-x)^2).
+    auto prep_point = [&](PhotonRec ph) {
+        const float r2 = ph.pos_r.w * ph.pos_r.w, ir2 = rcp(r2), kk = (3.f * kInvPi) * phase * ir2;
+        ph.pos_r.w = r2;
+        ph.pow = F4{ph.pow.x * kk, ph.pow.y * kk, ph.pow.z * kk, ir2};
+        return ph;
+    };
+    auto visit = [&](const PhotonRec& ph) {
+        c_leaf++;
+        V otc = xyz(ph.pos_r) - ro;
+        float disk = dot(otc, rd);
+        V dv = fma3(disk, rd, ro) - xyz(ph.pos_r);
+        float dist2 = dot(dv, dv);
+        bool ok = disk > 0.f && dist2 < ph.pos_r.w && !(hit && dot(otc, otc) > t * t);
+        if (ok) {
+            c_acc++;
+            float tmp = 1.f - dist2 * ph.pow.w;
+            float w = tmp * tmp * __expf(-sigma_t * disk);
+            vc = fma3(w, xyz(ph.pow), vc);
+        }
+    };
+    auto prep_none = [](const PhotonRec& ph) { return ph; };
+    // Packet form (every ray of the wave starts at o0; the same per-photon terms as in the photon-per-lane form
+    // above, computed by the staging lane; used when the strip has no candidate list)
+    const float t2 = hit ? t * t : kInf;
+    auto prep_packet = [&](PhotonRec ph, const V& o0) {
+        const V c = xyz(ph.pos_r) - o0;
+        const float r2 = ph.pos_r.w * ph.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = __builtin_sqrtf(c2);
+        const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
+        ph.pos_r = F4{c.x, c.y, c.z, r2};
+        ph.dir = F4{c2, len, ir2, 0.f};
+        ph.pow = F4{ph.pow.x * kk, ph.pow.y * kk, ph.pow.z * kk, 0.f};
+        return ph;
+    };
+    auto visit_packet = [&](const PhotonRec& ph) {
+        if (q.skip & 4u) return;  // diagnostic: tree walk and staging only
+        c_leaf++;
+        const V c = xyz(ph.pos_r);
+        const float disk = dot(c, rd);
+        const V dv = fma3(disk, rd, -c);
+        const float dist2 = dot(dv, dv);
+        const bool ok = disk > 0.f && dist2 < ph.pos_r.w && ph.dir.x <= t2;
+        if (ok) {
+            c_acc++;
+            const float tmp = 1.f - dist2 * ph.dir.z;
+            const float w = tmp * tmp * fmaf(sigma_t, ph.dir.y - disk, 1.f);
+            vc = fma3(w, xyz(ph.pow), vc);
+        }
+    };
+    // beam x beam estimate, src/photon.rs:503-593 (equation 38 of Jarosz et al.)
+    const V inv_rd = mk(rcp(rd.x), rcp(rd.y), rcp(rd.z));
+    auto visit_beam = [&](const PhotonRec& ph) {
+        c_leaf++;
+        float lo[3], hi[3], tn, tf;
+        leaf_box(ph, 2, lo, hi);
+        slab2(lo, hi, ro, inv_rd, tn, tf);
+        if (!(fmaxf(tn, 0.f) <= tf)) return;  // bvh `traverse`: only beams whose own box the ray hits
+        const V bstart = xyz(ph.dir), bend = xyz(ph.pos_r);
+        const float radius = ph.pos_r.w;
+        const V bvec = bend - bstart;
+        const float beam_len = __builtin_sqrtf(dot(bvec, bvec));
+        const V bdir = rcp(beam_len) * bvec;
+        const V l = bstart - ro;
+        const V u = normalize(cross(l, bdir));
+        const V nn = normalize(cross(bdir, u));
+        const float tq = dot(nn, l) * rcp(dot(nn, rd));
+        const V qc = fma3(tq, rd, ro);
+        const float dd = dot(rd, bdir);
+        const float beam_t = dot(bdir, qc - bstart);
+        const V bc = fma3(beam_t, bdir, bstart);
+        const V dq = qc - bc;
+        const float dist = __builtin_sqrtf(dot(dq, dq));
+        const bool ok = !(hit && tq >= t) && beam_t >= 0.f && beam_t <= beam_len && dist < radius;
+        if (ok) {
+            c_acc++;
+            const float inv_sin = rsq(fmaxf(0.f, 1.f - dd * dd));
+            const float tmp = 1.f - dist * rcp(radius);
+            const float w = sigma_t * phase * inv_sin * __expf(-sigma_t * tq) * __expf(-sigma_t * beam_t) *
+                            (3.f * kInvPi) * tmp * tmp * rcp(2.f * radius);
+            vc = fma3(w, xyz(ph.pow), vc);
+        }
+    };
+    if (KIND == RPT_PHOTON_BEAM_BEAM) {
+        if (!beam_walk_packet<false>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow,
+                                     [](const PhotonRec& ph, const V&) { return ph; }, visit_beam))
+            beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_none, visit_beam);
+    } else {
+        if (!beam_walk_packet<true>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_packet, visit_packet))
+            beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_point, visit);
+    }
+    return vc;
+}
+
+// Beam x point estimate of one pixel with ONE PHOTON PER LANE (src/photon.rs:439-502): `cand` lists the photon spheres that
+// reach into the strip's frustum, `rays` holds the pixel's n_s rays (unit direction, squared hit distance; far2 / near2:
+// the largest / smallest of those distances).  Returns this lane's photons' sum over all the rays, before the medium's colour.
+RPT_DEV V beam_estimate_photon_lanes(QueryK q, const uint32_t* cand, uint32_t cand_n, float far2, float near2, float xn, float yn,
+                                     V cam_right, V cam_up, float sigma_t, uint32_t n_s, const float4* rays, uint32_t* pend_list,
+                                     unsigned long long& c_leaf, unsigned long long& c_acc) {
+    const auto& a = q.r;
+    const uint32_t lane_ = threadIdx.x & 63u;
+    V beam_sum = mk(0, 0, 0);
+    // the pixel's own frustum (footprint included) re-culls the strip's candidates
+    const float e = a.inv_dim * 1.0001f;
+    const V dd = mk(a.cam.ddir[0], a.cam.ddir[1], a.cam.ddir[2]);
+    const V eye0 = mk(a.cam.eye[0], a.cam.eye[1], a.cam.eye[2]);  // pinhole: every ray starts here
+    const V corners[4] = {dd + (xn - e) * cam_right + (yn - e) * cam_up, dd + (xn + e) * cam_right + (yn - e) * cam_up,
+                          dd + (xn - e) * cam_right + (yn + e) * cam_up, dd + (xn + e) * cam_right + (yn + e) * cam_up};
+    Frustum fs;
+    const bool have_fs = frustum_from_dirs(true, eye0, corners, 4, fs);
+    const float phase = a.sc.medium_phase;
+    // A batch of nb <= 64 culled candidates: lane j takes pend_list[j].  What depends on the photon and the common
+    // origin is computed once per photon -- c = centre - eye, |c|^2, |c|, the power pre-multiplied by 3/pi * phase /
+    // r^2 * exp(-sigma_t |c|) -- and per ray exp(-sigma_t s) = exp(-sigma_t |c|) * exp(sigma_t (|c| - s)) with
+    // sigma_t (|c| - s) <= sigma_t r^2 / |c| ~ 1e-5, so the second factor is 1 + x to fp32 precision
+    // (src/photon.rs:474-493: k2(d^2/r^2)/r^2 with k2(x) = 3/pi (1-x)^2).
+    // Two kinds of photons: PLAIN ones lie in front of every ray of the pixel and nearer to the eye than every hit, so
+    // their test is the radius test alone (as a clamp of the kernel's argument: no comparison at all); GUARDED ones --
+    // behind the eye's plane or inside the shell between the nearest and the farthest hit -- take the full test.
+    auto flush = [&](const uint32_t* list, uint32_t nb, auto counting, auto plain) {
+        if (lane_ < nb) {
+            const PhotonRec raw = q.v_ph[list[lane_]];
+            const V c = xyz(raw.pos_r) - eye0;
+            const float r2 = raw.pos_r.w * raw.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = __builtin_sqrtf(c2);
+            const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
+            const V pw = kk * xyz(raw.pow);
+            const float one_plus = fmaf(sigma_t, len, 1.f);
+            float wsum = 0.f;   // the photon's weights over the pixel's rays: its power multiplies their sum once
+            uint32_t n_ok = 0;
+            if (!(q.skip & 4u)) {  // diagnostic: 4 = tree walk, culling and photon preparation only
+#pragma unroll 4
+                for (uint32_t s = 0; s < n_s; s++) {
+                    const float4 ray = rays[s];
+                    const V rd = mk(ray.x, ray.y, ray.z);
+                    const float disk = dot(c, rd);
+                    const V dv = fma3(disk, rd, -c);
+                    const float dist2 = dot(dv, dv);
+                    if (decltype(plain)::value) {
+                        const float tmp = fmaxf(fmaf(-dist2, ir2, 1.f), 0.f);   // 0 from the radius on
+                        wsum = fmaf(tmp * tmp, fmaf(-sigma_t, disk, one_plus), wsum);
+                        if (decltype(counting)::value) n_ok += tmp > 0.f ? 1u : 0u;
+                    } else {
+                        const bool ok = disk > 0.f && dist2 < r2 && c2 <= ray.w;
+                        const float tmp = fmaf(-dist2, ir2, 1.f);
+                        const float w = tmp * tmp * fmaf(-sigma_t, disk, one_plus);
+                        wsum += ok ? w : 0.f;
+                        if (decltype(counting)::value) n_ok += ok ? 1u : 0u;
+                    }
+                }
+            }
+            beam_sum = fma3(wsum, pw, beam_sum);
+            if (decltype(counting)::value) { c_leaf += n_s; c_acc += n_ok; }
+        }
+    };
+    auto flush_batch = [&](const uint32_t* list, uint32_t nb, auto plain) {
+        if (a.counters) flush(list, nb, std::true_type{}, plain);
+        else flush(list, nb, std::false_type{}, plain);
+    };
+    auto prefix = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)); };
+    // a list has received `cnt` more entries: a full batch of 64 goes through the rays, the rest moves to the front
+    auto drain = [&](uint32_t* list, uint32_t& pend, auto plain) {
+        __builtin_amdgcn_wave_barrier();
+        if (pend >= 64u) {
+            flush_batch(list, 64u, plain);
+            __builtin_amdgcn_wave_barrier();
+            const bool mv = lane_ + 64u < pend;
+            uint32_t v = 0u;
+            if (mv) v = list[64u + lane_];
+            __builtin_amdgcn_wave_barrier();
+            if (mv) list[lane_] = v;
+            pend -= 64u;
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    uint32_t* const guard_list = pend_list + kPendCap;
+    uint32_t pend = 0, pend_g = 0;   // wave-uniform: entries of pend_list / guard_list
+    for (uint32_t base = 0; base < cand_n; base += 64u) {  // wave-uniform loop
+        bool take = false, plain = false;
+        uint32_t idx = 0u;
+        if (base + lane_ < cand_n) {
+            idx = cand[base + lane_];
+            const F4 pr = q.v_ph[idx].pos_r;
+            take = !have_fs || !sphere_outside(fs, pr);
+            const V cc = xyz(pr) - eye0;
+            const float cc2 = dot(cc, cc), along = dot(cc, fs.axis);
+            take = take && cc2 <= far2;  // the per-ray test rejects centres beyond the ray's hit
+            // in front of every ray of the pixel (within 89.4 degrees of its axis; the pixel's cone is ~1e-3 wide)
+            plain = have_fs && cc2 <= near2 && along > 0.f && along * along > 1e-4f * cc2;
+        }
+        const uint64_t tp = __ballot(take && plain), tg = __ballot(take && !plain);
+        if (take && plain) pend_list[pend + prefix(tp)] = idx;
+        if (take && !plain) guard_list[pend_g + prefix(tg)] = idx;
+        pend += uint32_t(__popcll(tp));
+        pend_g += uint32_t(__popcll(tg));
+        drain(pend_list, pend, std::true_type{});
+        drain(guard_list, pend_g, std::false_type{});
+    }
+    // what is left of both lists goes through the full test together (a batch costs the same whatever it holds)
+    if (lane_ < pend) guard_list[pend_g + lane_] = pend_list[lane_];
+    pend_g += pend;
+    __builtin_amdgcn_wave_barrier();
+    if (pend_g) flush_batch(guard_list, min(pend_g, 64u), std::false_type{});
+    if (pend_g > 64u) flush_batch(guard_list + 64, pend_g - 64u, std::false_type{});
+    return beam_sum;
+}
+
+// ---- surface estimate (src/photon.rs:327-375)
+// One lane's surface point and its estimate in the making.
+struct SurfaceSample {
+    V x, n, wo;
+    Mat mat;
+    V sc_col;       // emission + the terms of the gathered photons so far
+    float max_d2;   // squared distance of the K-th nearest photon, once known
+    bool todo;      // still to be served
+};
+// The room shell's box, a few ulps wider (see `lane_clear` in gather_serve).
+struct ShellBox {
+    bool on;
+    F4 lo, hi;
+    RPT_DEV bool holds(V p) const {
+        return !on || (p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z);
+    }
+};
+template <bool BVH>
+RPT_DEV ShellBox shell_box() {
+    const auto& sc = *kernarg_scene();
+    ShellBox b{!BVH && sc.has_shell != 0u, F4{}, F4{}};
+    if (b.on) {
+        const ShellScan sh = uload(sc.shell);
+        const float e = 2e-6f * fmaxf(max3(fabsf(sh.lo.x), fabsf(sh.lo.y), fabsf(sh.lo.z)), max3(fabsf(sh.hi.x), fabsf(sh.hi.y), fabsf(sh.hi.z)));
+        b.lo = F4{sh.lo.x - e, sh.lo.y - e, sh.lo.z - e, 0.f};
+        b.hi = F4{sh.hi.x + e, sh.hi.y + e, sh.hi.z + e, 0.f};
+    }
+    return b;
+}
+// The wave-private LDS of the gathers: per-lane [K][64] distance (and index) lists, then the wave-level gather's stack,
+// candidate keys and (position, index) records.
+struct GatherLds {
+    float* gd;
+    uint32_t* gi;
+    uint32_t* pstack;
+    float* keys;
+    F4* cl;
+};
+// What a scene's traversal needs besides the ray: the LDS stack column and two diagnostic counters.
+struct WalkScratch {
+    uint32_t* stk;
+    uint32_t c0, c1;
+};
+// One gathered photon's term (src/photon.rs:357-371).  Visibility ("something lies between the photon and the query
+// point"): only a hit closer than the query point can block, and every point of the segment photon -> x lies within the
+// gather radius of x: scanned records whose box misses that ball (of any sample of this pixel: the mask is wave-uniform)
+// cannot decide the test and are skipped.  The closest hit below |disp| (1 - 1e-3) is the closest hit of the unbounded
+// query whenever that one would block, so the decisions are the same as with the full scan.
+// no_scan (wave-uniform): no lane needs the scan; lane_free: this lane's test cannot be blocked whatever a scan finds.
+template <bool BVH>
+RPT_DEV void add_photon_term(QueryK q, const SceneView& sc_arg, SurfaceSample& s, WalkScratch& ws, V po, V pdir, V ppow,
+                             uint64_t vis_mask, bool no_scan, bool lane_free) {
+    V disp = s.x - po;
+    float len2 = dot(disp, disp);
+    float ilen = rsq(len2);
+    V pd = ilen * disp;
+    float len = len2 * ilen;
+    float ts = BVH ? kInf : len * (1.f - 1e-3f);
+    uint32_t cs = CODE_MISS, is = 0;
+    if (!(q.skip & 8u) && !no_scan) {  // diagnostic: 8 = no visibility scans
+        if (BVH) closest_hit<2, false>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, is, ws.stk, 256, ws.c0, ws.c1);
+        else scan_prims<true>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, vis_mask);
+    }
+    // A hit inside the query point's own tangent plane is the grazing ray meeting its own surface: fp64
+    // rejects it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
+    V hp = fma3(ts, pd, po) - s.x;
+    bool own_plane = fabsf(dot(hp, s.n)) <= 1e-4f * len;
+    bool blocked = !lane_free && cs != CODE_MISS && !own_plane && ts < len * (1.f - 1e-3f);
+    if (!blocked || !(len2 > 0.f)) {  // (a query point that coincides with the photon has no ray to trace)
+        float c = fminf(fmaxf(dot(pdir, s.n), 0.f), 1.f);
+        s.sc_col = fma3(c, bsdf(s.mat, s.n, s.wo, pdir) * ppow, s.sc_col);
+    }
+}
+// Every member lane picks its K nearest out of the M ordered candidates (centre: where `rho` is measured from) inside its
+// search radius `guess`, then sums the terms of the photons within its K-th distance, in candidate order.  Lanes that
+// found K are done (s.todo, s.max_d2).  g_cnt: diagnostic counters of the wave.
+template <bool BVH>
+RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
+                          WalkScratch& ws, bool member, float guess, float rho, uint32_t M, uint32_t* g_cnt) {
+    const auto& a = q.r;
+    const auto& sc = a.sc;
+    const uint32_t lane_ = threadIdx.x & 63u;
+    const uint32_t K = q.gather_size, want_k = min(K, q.n_s);
+    float* const gd = l.gd;
+    const float* const keys = l.keys;
+    const F4* const cl = l.cl;
+    const V x = s.x;
+    // -- each member's K nearest distances (list in LDS; entries beyond `guess` do not count)
+    uint32_t found = 0, wslot = 0;
+    float worst = 0.f;
+    const float reach0 = __builtin_sqrtf(guess) + rho;
+    float thr = member ? reach0 * reach0 * (1.f + 1e-5f) : -1.f;
+    float k_next = M ? keys[0] : 0.f;
+    F4 c_next = M ? cl[0] : F4{0.f, 0.f, 0.f, 0.f};
+    for (uint32_t j = 0; j < M; j++) {
+        const float kj = k_next;
+        const F4 cj = c_next;
+        {   // the next candidate's LDS reads are in flight while this one is handled
+            const uint32_t jn = min(j + 1u, M - 1u);
+            k_next = keys[jn];
+            c_next = cl[jn];
+        }
+        if (__ballot(kj <= thr) == 0ull) break;   // no member's ball reaches this far from the centre
+        if (a.counters) g_cnt[5]++;
+        const V d = xyz(cj) - x;
+        const float d2 = dot(d, d);
+        bool changed = false;
+        if (member) {
+            if (found < K) {
+                if (d2 <= guess) {
+                    gd[found * 64u] = d2;
+                    found++;
+                    changed = found == K;
+                }
+            } else if (d2 < worst) {
+                gd[wslot * 64u] = d2;
+                changed = true;
+            }
+            if (changed) {   // (re)locate the current worst: four independent LDS reads per step
+                worst = -1.f;
+                uint32_t k = 0;
+                for (; k + 4u <= K; k += 4u) {
+                    const float v0 = gd[k * 64u], v1 = gd[(k + 1u) * 64u], v2 = gd[(k + 2u) * 64u], v3 = gd[(k + 3u) * 64u];
+                    const float m01 = fmaxf(v0, v1), m23 = fmaxf(v2, v3), m = fmaxf(m01, m23);
+                    if (m > worst) {
+                        worst = m;
+                        wslot = k + (m == m01 ? (m == v0 ? 0u : 1u) : (m == v2 ? 2u : 3u));
+                    }
+                }
+                for (; k < K; k++) {
+                    const float v = gd[k * 64u];
+                    if (v > worst) { worst = v; wslot = k; }
+                }
+                const float reach = __builtin_sqrtf(worst) + rho;
+                thr = reach * reach * (1.f + 1e-5f);
+            }
+        }
+        if (a.counters && __ballot(changed) != 0ull) g_cnt[6]++;
+    }
+    const bool ok = member && found >= want_k;
+    float r2k = found == K ? worst : 0.f;
+    if (ok && found < K) for (uint32_t k = 0; k < found; k++) r2k = fmaxf(r2k, gd[k * 64u]);   // (a map of fewer than K photons)
+    if (!ok) r2k = 0.f;
+    // -- the terms of the photons within each lane's radius, in candidate order
+    uint64_t vis_mask = ~0ull;
+    bool touched = true;   // some scanned record comes near this lane's ball
+    if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, ok, x, __builtin_sqrtf(r2k) * (1.f + 1e-4f) + 1e-6f, &touched);
+    // A lane's test cannot be blocked when no scanned record comes near its ball, the scene has no plane, and both
+    // ends of the segment lie inside the room shell: its faces bound a convex box, a segment between two points of
+    // the closed box meets a face at its ends only, and those the search interval leaves out.  (The scan itself is
+    // less exact there: next to an edge of the room it reports false crossings, see tools/photon_vis_check.py.)
+    // Then the gathered photon is visible by construction; the scan runs only if some lane of the term needs it.
+    // A point counts as inside within a few ulps.  The decision is the lane's own: no other lane's geometry enters.
+    bool lane_clear = !BVH && !touched && sc.n_pln == 0u && !(q.skip & 128u);   // (diagnostic: 128 = always scan)
+    lane_clear = lane_clear && shell.holds(x);
+    const float reach2 = __builtin_sqrtf(r2k) + rho;
+    const float thr2 = ok ? reach2 * reach2 * (1.f + 1e-5f) : -1.f;
+    bool more = __ballot(ok) != 0ull && !(q.skip & 16u);   // diagnostic: 16 = no second pass
+    const float thr2_max = wave_max(thr2);
+    for (uint32_t base = 0; base < M && more; base += 64u) {
+        // lane l fetches what the term needs of candidate base + l; the records are then handed round by readlane
+        F4 fdir{}, fpow{};
+        if (base + lane_ < M && keys[base + lane_] <= thr2_max) {
+            const uint32_t idx = __float_as_uint(cl[base + lane_].w);
+            fdir = q.s_ph[idx].dir;
+            fpow = q.s_ph[idx].pow;
+        }
+        const uint32_t nb = min(64u, M - base);
+        float k_nx = keys[base];
+        F4 c_nx = cl[base];
+        for (uint32_t jj = 0; jj < nb; jj++) {
+            const uint32_t j = base + jj;
+            const float kj = k_nx;
+            const V po = xyz(c_nx);
+            {
+                const uint32_t jn = min(j + 1u, M - 1u);
+                k_nx = keys[jn];
+                c_nx = cl[jn];
+            }
+            if (__ballot(kj <= thr2) == 0ull) { more = false; break; }
+            if (a.counters) g_cnt[7]++;
+            const V dd = po - x;
+            const bool in = ok && dot(dd, dd) <= r2k;
+            if (__ballot(in) == 0ull) continue;
+            auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), jj)); };
+            const V pdir = mk(rl(fdir.x), rl(fdir.y), rl(fdir.z)), ppow = mk(rl(fpow.x), rl(fpow.y), rl(fpow.z));
+            if (a.counters) g_cnt[8]++;
+            const bool lane_free = lane_clear && shell.holds(po);   // (po is wave-uniform)
+            const bool no_scan = __ballot(in && !lane_free) == 0ull;
+            if (a.counters && no_scan) g_cnt[1]++;
+            if (in) add_photon_term<BVH>(q, sc_arg, s, ws, po, pdir, ppow, vis_mask, no_scan, lane_free);
+        }
+    }
+    if (ok) {
+        s.max_d2 = r2k;
+        s.todo = false;
+    }
+    return ok;
+}
+// The candidates of the pixel's hit points, when they form one cluster: every photon within R of c, ordered by distance to c
+// (valid); c = the pixel's first surface point whenever it has one (have_c), which also orders the lists of the later rounds.
+struct PixelList {
+    bool valid, have_c;
+    uint32_t M;
+    float R;
+    V c;
+};
+// The wave's anchor (ball_anchor): node, and the ball it was computed for.
+struct Anchor {
+    V c;
+    float R;
+    uint32_t node;
+};
+RPT_DEV void anchor_for(QueryK q, Anchor& anc, V c, float R, uint32_t* g_cnt) {
+    const V da = c - anc.c;
+    if (!(anc.R > 0.f) || __builtin_sqrtf(dot(da, da)) + R > anc.R) {   // kept while the queries stay inside a ball twice as wide
+        anc.c = c;
+        anc.R = 2.f * R;
+        anc.node = ball_anchor(q.s_nodes, q.n_s, c, anc.R * anc.R);
+        if (q.r.counters) g_cnt[9]++;
+    }
+}
+// Once per pixel: collect and order the candidates of all its samples (prho2: how far, squared, this lane's surface points
+// lie from pix.c; prev_r2: the lane's last gather radius, squared).
+RPT_DEV void pixel_candidates(QueryK q, const GatherLds& l, PixelList& pix, Anchor& anc, float prev_r2, float prho2, uint32_t* g_cnt) {
+    const float G = wave_max(prev_r2 > 0.f ? 2.f * prev_r2 : 0.f);
+    const float rho_max2 = wave_max(prho2);
+    if (!(G > 0.f && rho_max2 <= G)) return;
+    pix.R = (__builtin_sqrtf(G) + __builtin_sqrtf(rho_max2)) * (1.f + 1e-5f);
+    anchor_for(q, anc, pix.c, pix.R, g_cnt);
+    uint32_t steps = 0;
+    pix.M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc.node, pix.c, pix.R * pix.R, l.pstack, reinterpret_cast<uint32_t*>(l.keys), l.cl,
+                         q.coop_cap, steps);
+    if (q.r.counters) { g_cnt[2] += steps; if (pix.M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += pix.M; }
+    if (pix.M != kCoopOverflow) {
+        if (!(q.skip & 64u)) sort_candidates(l.cl, l.keys, pix.M, pix.c);   // (diagnostic: 64 = collection only)
+        pix.valid = true;
+    }
+}
+// The surface gather of one trip by the wave together.  Consecutive samples of a lane fall within a pixel of each other: the
+// previous gather radius (squared, doubled) bounds this search; a lane that finds fewer than K photons inside it searches
+// again with a larger one.  Round 0 serves the lanes from the pixel's candidate list (a lane's ball has to lie inside the
+// collected one); the later rounds collect for clusters of the query points that are left: none, unless the pixel straddles
+// an edge, a radius was too small or there is no pixel list.  Lanes it cannot serve keep s.todo.
+template <bool BVH>
+RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
+                                 WalkScratch& ws, PixelList& pix, Anchor& anc, float prev_r2, uint32_t* g_cnt) {
+    const auto& a = q.r;
+    const V x = s.x;
+    float guess = prev_r2 > 0.f ? 2.f * prev_r2 : 0.f;
+    {   // a lane without a radius of its own borrows the largest one in the wave
+        const float g = wave_max(s.todo ? guess : 0.f);
+        if (!(guess > 0.f)) guess = g;
+    }
+    if (a.counters && __ballot(s.todo) != 0ull) g_cnt[0]++;
+    for (uint32_t round = pix.valid ? 0u : 1u; round < 7u; round++) {
+        const uint64_t cm = __ballot(s.todo && guess > 0.f);
+        if (cm == 0ull) break;
+        bool member;
+        float g_use, rho;
+        uint32_t M;
+        if (round == 0u) {
+            const V dx = x - pix.c;
+            rho = __builtin_sqrtf(dot(dx, dx));
+            const float room = pix.R * (1.f - 2e-5f) - rho;
+            g_use = fminf(guess, room > 0.f ? room * room : 0.f);
+            member = s.todo && g_use > 0.f;
+            M = pix.M;
+        } else {
+            pix.valid = false;   // (these rounds reuse the list's LDS)
+            const uint32_t lead = uint32_t(__ffsll((unsigned long long)cm)) - 1u;
+            auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lead)); };
+            const V xc = mk(bc(x.x), bc(x.y), bc(x.z));
+            const float gc = bc(guess);
+            const V dx = x - xc;
+            const float rho2 = dot(dx, dx);
+            member = s.todo && guess > 0.f && rho2 <= gc;   // within the leader's own search radius
+            rho = __builtin_sqrtf(rho2);
+            g_use = guess;
+            const float R = wave_max(member ? __builtin_sqrtf(guess) + rho : 0.f) * (1.f + 1e-5f);
+            anchor_for(q, anc, xc, R, g_cnt);
+            uint32_t steps = 0;
+            M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc.node, xc, R * R, l.pstack, reinterpret_cast<uint32_t*>(l.keys), l.cl, q.coop_cap, steps);
+            if (a.counters) { g_cnt[2] += steps; if (M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += M; }
+            if (M == kCoopOverflow) break;   // the lanes still to do search one by one
+            if (q.skip & 64u) { if (member) { s.max_d2 = 0.5f * guess; s.todo = false; } continue; }   // diagnostic: collection only
+            // ordered, like the pixel's list, by distance to the pixel's first surface point when there is one: the order
+            // of a lane's terms is then the same whichever round serves it
+            const V kc = pix.have_c ? pix.c : xc;
+            sort_candidates(l.cl, l.keys, M, kc);
+            const V dk = x - kc;
+            rho = __builtin_sqrtf(dot(dk, dk));
+        }
+        if (q.skip & 96u) { if (member) { s.max_d2 = 0.5f * guess; s.todo = false; } continue; }   // diagnostic: 32 / 64 = no selection
+        const bool ok = gather_serve<BVH>(q, sc_arg, l, shell, s, ws, member, g_use, rho, M, g_cnt);
+        if (member && !ok) guess = fmaxf(guess, 4.f * g_use);   // too few photons inside: twice the radius next round
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// One search per lane (lists in global memory, no radius to start from, an overfull candidate list); the lanes of the call
+// search the tree together (knn_walk_wave).
+template <bool BVH>
+RPT_DEV void surface_gather_lane(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
+                                 WalkScratch& ws, float prev_r2) {
+    const auto& sc = q.r.sc;
+    const uint32_t want_k = min(q.gather_size, q.n_s);
+    uint32_t found = 0;
+    if (prev_r2 > 0.f) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, s.x, q.gather_size, l.gd, l.gi, s.max_d2, 2.f * prev_r2);
+    if (found < want_k || !(prev_r2 > 0.f)) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, s.x, q.gather_size, l.gd, l.gi, s.max_d2);
+    uint64_t vis_mask = ~0ull;
+    bool touched = true;
+    if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, true, s.x, __builtin_sqrtf(s.max_d2) * (1.f + 1e-4f) + 1e-6f, &touched);
+    const bool lane_clear = !BVH && !touched && sc.n_pln == 0u && !(q.skip & 128u) && shell.holds(s.x);   // as in gather_serve
+    for (uint32_t k = 0; k < found; k++) {
+        const PhotonRec ph = q.s_ph[l.gi[k * 64u]];
+        const bool lane_free = lane_clear && shell.holds(xyz(ph.pos_r));
+        add_photon_term<BVH>(q, sc_arg, s, ws, xyz(ph.pos_r), xyz(ph.dir), xyz(ph.pow), vis_mask, __ballot(!lane_free) == 0ull, lane_free);
+    }
+    s.todo = false;
+}
+
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
 // KIND: the PhotonRenderKind of the map (RPT_PHOTON_*).  One instantiation per kind: the three estimators share the
@@ -977,9 +1514,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     float prev_r2 = 0.f;  // squared radius of this lane's previous surface gather
     unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
     uint32_t g_cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic (counters build), wave-level: see the end of the kernel
-    V anc_c = mk(0, 0, 0);   // wave-uniform: the surface gather's anchor (ball_anchor) -- centre, radius, node
-    float anc_R = 0.f;
-    uint32_t anc_node = 0u;
+    Anchor anc{mk(0, 0, 0), 0.f, 0u};   // wave-uniform: the surface gather's anchor (ball_anchor)
     // Work decomposition of the camera pass: a wave takes a strip of rows of one 8x8 pixel block and one chunk of up
     // to kSuper samples at a time and walks through the strip's pixels; a pixel's samples are handled 64 at a time:
     // in each trip the 64 LANES ARE SAMPLES OF ONE PIXEL.  The rays of a trip then differ only by their sub-pixel
@@ -1125,140 +1660,17 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         if (beam_lanes) {
             far2 = wave_max(far2);   // farthest hit of the pixel's samples (inf on a miss)
             near2 = wave_min(near2);  // nearest one
-            // the pixel's own frustum (footprint included) re-culls the strip's candidates
-            const float e = a.inv_dim * 1.0001f;
-            const V dd = mk(a.cam.ddir[0], a.cam.ddir[1], a.cam.ddir[2]);
-            const V eye0 = mk(a.cam.eye[0], a.cam.eye[1], a.cam.eye[2]);  // pinhole: every ray starts here
-            const V corners[4] = {dd + (xn - e) * cam_right + (yn - e) * cam_up, dd + (xn + e) * cam_right + (yn - e) * cam_up,
-                                  dd + (xn - e) * cam_right + (yn + e) * cam_up, dd + (xn + e) * cam_right + (yn + e) * cam_up};
-            Frustum fs;
-            const bool have_fs = frustum_from_dirs(true, eye0, corners, 4, fs);
-            const float phase = sc.medium_phase;
-            // A batch of nb <= 64 culled candidates: lane j takes pend_list[j].  What depends on the photon and the common
-            // origin is computed once per photon -- c = centre - eye, |c|^2, |c|, the power pre-multiplied by 3/pi * phase /
-            // r^2 * exp(-sigma_t |c|) -- and per ray exp(-sigma_t s) = exp(-sigma_t |c|) * exp(sigma_t (|c| - s)) with
-            // sigma_t (|c| - s) <= sigma_t r^2 / |c| ~ 1e-5, so the second factor is 1 + x to fp32 precision
-            // (src/photon.rs:474-493: k2(d^2/r^2)/r^2 with k2(x) = 3/pi (1-x)^2).
-            // Two kinds of photons: PLAIN ones lie in front of every ray of the pixel and nearer to the eye than every hit, so
-            // their test is the radius test alone (as a clamp of the kernel's argument: no comparison at all); GUARDED ones --
-            // behind the eye's plane or inside the shell between the nearest and the farthest hit -- take the full test.
-            auto flush = [&](const uint32_t* list, uint32_t nb, auto counting, auto plain) {
-                if (lane_ < nb) {
-                    const PhotonRec raw = q.v_ph[list[lane_]];
-                    const V c = xyz(raw.pos_r) - eye0;
-                    const float r2 = raw.pos_r.w * raw.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = __builtin_sqrtf(c2);
-                    const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
-                    const V pw = kk * xyz(raw.pow);
-                    const float one_plus = fmaf(sigma_t, len, 1.f);
-                    float wsum = 0.f;   // the photon's weights over the pixel's rays: its power multiplies their sum once
-                    uint32_t n_ok = 0;
-                    if (!(q.skip & 4u)) {  // diagnostic: 4 = tree walk, culling and photon preparation only
-#pragma unroll 4
-                        for (uint32_t s = 0; s < n_s; s++) {
-                            const float4 ray = rays[s];
-                            const V rd = mk(ray.x, ray.y, ray.z);
-                            const float disk = dot(c, rd);
-                            const V dv = fma3(disk, rd, -c);
-                            const float dist2 = dot(dv, dv);
-                            if (decltype(plain)::value) {
-                                const float tmp = fmaxf(fmaf(-dist2, ir2, 1.f), 0.f);   // 0 from the radius on
-                                wsum = fmaf(tmp * tmp, fmaf(-sigma_t, disk, one_plus), wsum);
-                                if (decltype(counting)::value) n_ok += tmp > 0.f ? 1u : 0u;
-                            } else {
-                                const bool ok = disk > 0.f && dist2 < r2 && c2 <= ray.w;
-                                const float tmp = fmaf(-dist2, ir2, 1.f);
-                                const float w = tmp * tmp * fmaf(-sigma_t, disk, one_plus);
-                                wsum += ok ? w : 0.f;
-                                if (decltype(counting)::value) n_ok += ok ? 1u : 0u;
-                            }
-                        }
-                    }
-                    beam_sum = fma3(wsum, pw, beam_sum);
-                    if (decltype(counting)::value) { c_leaf += n_s; c_acc += n_ok; }
-                }
-            };
-            auto flush_batch = [&](const uint32_t* list, uint32_t nb, auto plain) {
-                if (a.counters) flush(list, nb, std::true_type{}, plain);
-                else flush(list, nb, std::false_type{}, plain);
-            };
-            auto prefix = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)); };
-            // a list has received `cnt` more entries: a full batch of 64 goes through the rays, the rest moves to the front
-            auto drain = [&](uint32_t* list, uint32_t& pend, auto plain) {
-                __builtin_amdgcn_wave_barrier();
-                if (pend >= 64u) {
-                    flush_batch(list, 64u, plain);
-                    __builtin_amdgcn_wave_barrier();
-                    const bool mv = lane_ + 64u < pend;
-                    uint32_t v = 0u;
-                    if (mv) v = list[64u + lane_];
-                    __builtin_amdgcn_wave_barrier();
-                    if (mv) list[lane_] = v;
-                    pend -= 64u;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            };
-            uint32_t* const guard_list = pend_list + kPendCap;
-            uint32_t pend = 0, pend_g = 0;   // wave-uniform: entries of pend_list / guard_list
-            for (uint32_t base = 0; base < cand_n; base += 64u) {  // wave-uniform loop
-                bool take = false, plain = false;
-                uint32_t idx = 0u;
-                if (base + lane_ < cand_n) {
-                    idx = cand[base + lane_];
-                    const F4 pr = q.v_ph[idx].pos_r;
-                    take = !have_fs || !sphere_outside(fs, pr);
-                    const V cc = xyz(pr) - eye0;
-                    const float cc2 = dot(cc, cc), along = dot(cc, fs.axis);
-                    take = take && cc2 <= far2;  // the per-ray test rejects centres beyond the ray's hit
-                    // in front of every ray of the pixel (within 89.4 degrees of its axis; the pixel's cone is ~1e-3 wide)
-                    plain = have_fs && cc2 <= near2 && along > 0.f && along * along > 1e-4f * cc2;
-                }
-                const uint64_t tp = __ballot(take && plain), tg = __ballot(take && !plain);
-                if (take && plain) pend_list[pend + prefix(tp)] = idx;
-                if (take && !plain) guard_list[pend_g + prefix(tg)] = idx;
-                pend += uint32_t(__popcll(tp));
-                pend_g += uint32_t(__popcll(tg));
-                drain(pend_list, pend, std::true_type{});
-                drain(guard_list, pend_g, std::false_type{});
-            }
-            // what is left of both lists goes through the full test together (a batch costs the same whatever it holds)
-            if (lane_ < pend) guard_list[pend_g + lane_] = pend_list[lane_];
-            pend_g += pend;
-            __builtin_amdgcn_wave_barrier();
-            if (pend_g) flush_batch(guard_list, min(pend_g, 64u), std::false_type{});
-            if (pend_g > 64u) flush_batch(guard_list + 64, pend_g - 64u, std::false_type{});
+            beam_sum = beam_estimate_photon_lanes(q, cand, cand_n, far2, near2, xn, yn, cam_right, cam_up, sigma_t, n_s, rays, pend_list, c_leaf, c_acc);
             __builtin_amdgcn_wave_barrier();   // the gather lists of the surface estimate reuse this LDS
         }
         // ---- the surface gather's candidates, once for all the pixel's samples when their hit points form one cluster: every
         // photon within pix_R of pxc, ordered by distance to pxc.  A lane may then search any ball that lies inside that one.
-        uint32_t pix_M = 0u;       // wave-uniform
-        bool pix_valid = false;    // wave-uniform
-        float pix_R = 0.f;         // wave-uniform
-        if (pix_gather && have_xc) {
-            const uint32_t K = q.gather_size;
-            uint32_t* const pstack = region + K * 64u;
-            float* const keys = reinterpret_cast<float*>(pstack + kBallStack);
-            F4* const cl = reinterpret_cast<F4*>(keys + q.coop_cap);
-            const float G = wave_max(prev_r2 > 0.f ? 2.f * prev_r2 : 0.f);
-            const float rho_max2 = wave_max(prho2);
-            if (G > 0.f && rho_max2 <= G) {
-                pix_R = (__builtin_sqrtf(G) + __builtin_sqrtf(rho_max2)) * (1.f + 1e-5f);
-                const V da = pxc - anc_c;
-                if (!(anc_R > 0.f) || __builtin_sqrtf(dot(da, da)) + pix_R > anc_R) {
-                    anc_c = pxc;
-                    anc_R = 2.f * pix_R;
-                    anc_node = ball_anchor(q.s_nodes, q.n_s, pxc, anc_R * anc_R);
-                    if (a.counters) g_cnt[9]++;
-                }
-                uint32_t steps = 0;
-                pix_M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc_node, pxc, pix_R * pix_R, pstack, reinterpret_cast<uint32_t*>(keys), cl,
-                                     q.coop_cap, steps);
-                if (a.counters) { g_cnt[2] += steps; if (pix_M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += pix_M; }
-                if (pix_M != kCoopOverflow) {
-                    if (!(q.skip & 64u)) sort_candidates(cl, keys, pix_M, pxc);   // (diagnostic: 64 = collection only)
-                    pix_valid = true;
-                }
-            }
-        }
+        GatherLds lds{gd, gi, region + q.gather_size * 64u, nullptr, nullptr};
+        lds.keys = reinterpret_cast<float*>(lds.pstack + kBallStack);
+        lds.cl = reinterpret_cast<F4*>(lds.keys + q.coop_cap);
+        PixelList plist{false, pix_gather && have_xc, 0u, 0.f, pxc};
+        if (plist.have_c) pixel_candidates(q, lds, plist, anc, prev_r2, prho2, g_cnt);
+        const ShellBox shell = shell_box<BVH>();
         // ---- the pixel's samples, 64 per trip; lane = sample
         V pixel_sum = mk(0, 0, 0);
         for (uint32_t sub = 0; sub < n_sub; sub++) {
@@ -1296,360 +1708,30 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 }
             }
         } else if (MEDIUM && !(q.skip & 1u) && !beam_lanes) {  // beam estimates with the samples in the lanes
-            V vc = mk(0, 0, 0);
-            const float phase = sc.medium_phase;
-            // The staging lane pre-computes what depends on the photon only: pos_r.w = r^2, pow = power *
-            // 3/pi * phase / r^2, pow.w = 1/r^2 (src/photon.rs:474-493: k2(d^2/r^2)/r^2 with k2(x) = 3/pi (1-x)^2).
-            auto prep_point = [&](PhotonRec ph) {
-                const float r2 = ph.pos_r.w * ph.pos_r.w, ir2 = rcp(r2), kk = (3.f * kInvPi) * phase * ir2;
-                ph.pos_r.w = r2;
-                ph.pow = F4{ph.pow.x * kk, ph.pow.y * kk, ph.pow.z * kk, ir2};
-                return ph;
-            };
-            auto visit = [&](const PhotonRec& ph) {
-                c_leaf++;
-                V otc = xyz(ph.pos_r) - ro;
-                float disk = dot(otc, rd);
-                V dv = fma3(disk, rd, ro) - xyz(ph.pos_r);
-                float dist2 = dot(dv, dv);
-                bool ok = disk > 0.f && dist2 < ph.pos_r.w && !(hit && dot(otc, otc) > t * t);
-                if (ok) {
-                    c_acc++;
-                    float tmp = 1.f - dist2 * ph.pow.w;
-                    float w = tmp * tmp * __expf(-sigma_t * disk);
-                    vc = fma3(w, xyz(ph.pow), vc);
-                }
-            };
-            auto prep_none = [](const PhotonRec& ph) { return ph; };
-            // Packet form (every ray of the wave starts at o0; the same per-photon terms as in the photon-per-lane form
-            // above, computed by the staging lane; used when the strip has no candidate list)
-            const float t2 = hit ? t * t : kInf;
-            auto prep_packet = [&](PhotonRec ph, const V& o0) {
-                const V c = xyz(ph.pos_r) - o0;
-                const float r2 = ph.pos_r.w * ph.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = __builtin_sqrtf(c2);
-                const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
-                ph.pos_r = F4{c.x, c.y, c.z, r2};
-                ph.dir = F4{c2, len, ir2, 0.f};
-                ph.pow = F4{ph.pow.x * kk, ph.pow.y * kk, ph.pow.z * kk, 0.f};
-                return ph;
-            };
-            auto visit_packet = [&](const PhotonRec& ph) {
-                if (q.skip & 4u) return;  // diagnostic: tree walk and staging only
-                c_leaf++;
-                const V c = xyz(ph.pos_r);
-                const float disk = dot(c, rd);
-                const V dv = fma3(disk, rd, -c);
-                const float dist2 = dot(dv, dv);
-                const bool ok = disk > 0.f && dist2 < ph.pos_r.w && ph.dir.x <= t2;
-                if (ok) {
-                    c_acc++;
-                    const float tmp = 1.f - dist2 * ph.dir.z;
-                    const float w = tmp * tmp * fmaf(sigma_t, ph.dir.y - disk, 1.f);
-                    vc = fma3(w, xyz(ph.pow), vc);
-                }
-            };
-            // beam x beam estimate, src/photon.rs:503-593 (equation 38 of Jarosz et al.)
-            const V inv_rd = mk(rcp(rd.x), rcp(rd.y), rcp(rd.z));
-            auto visit_beam = [&](const PhotonRec& ph) {
-                c_leaf++;
-                float lo[3], hi[3], tn, tf;
-                leaf_box(ph, 2, lo, hi);
-                slab2(lo, hi, ro, inv_rd, tn, tf);
-                if (!(fmaxf(tn, 0.f) <= tf)) return;  // bvh `traverse`: only beams whose own box the ray hits
-                const V bstart = xyz(ph.dir), bend = xyz(ph.pos_r);
-                const float radius = ph.pos_r.w;
-                const V bvec = bend - bstart;
-                const float beam_len = __builtin_sqrtf(dot(bvec, bvec));
-                const V bdir = rcp(beam_len) * bvec;
-                const V l = bstart - ro;
-                const V u = normalize(cross(l, bdir));
-                const V nn = normalize(cross(bdir, u));
-                const float tq = dot(nn, l) * rcp(dot(nn, rd));
-                const V qc = fma3(tq, rd, ro);
-                const float dd = dot(rd, bdir);
-                const float beam_t = dot(bdir, qc - bstart);
-                const V bc = fma3(beam_t, bdir, bstart);
-                const V dq = qc - bc;
-                const float dist = __builtin_sqrtf(dot(dq, dq));
-                const bool ok = !(hit && tq >= t) && beam_t >= 0.f && beam_t <= beam_len && dist < radius;
-                if (ok) {
-                    c_acc++;
-                    const float inv_sin = rsq(fmaxf(0.f, 1.f - dd * dd));
-                    const float tmp = 1.f - dist * rcp(radius);
-                    const float w = sigma_t * phase * inv_sin * __expf(-sigma_t * tq) * __expf(-sigma_t * beam_t) *
-                                    (3.f * kInvPi) * tmp * tmp * rcp(2.f * radius);
-                    vc = fma3(w, xyz(ph.pow), vc);
-                }
-            };
-            if (KIND == RPT_PHOTON_BEAM_BEAM) {
-                if (!beam_walk_packet<false>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow,
-                                             [](const PhotonRec& ph, const V&) { return ph; }, visit_beam))
-                    beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_none, visit_beam);
-            } else {
-                if (!beam_walk_packet<true>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_packet, visit_packet))
-                    beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_point, visit);
-            }
+            const V vc = volume_estimate_sample_lanes<KIND>(q, active, ro, rd, hit, t, sigma_t, sc.medium_phase, wstack, stage, c_leaf, c_acc);
             color = vc * mcol0;
         }
         if (active && !hit && !MEDIUM) color = env_color(sc_arg, rd);  // src/photon.rs:597
         // ---- surface estimate, src/photon.rs:327-375
         const bool surf = active && surface_on && !(q.skip & 2u);
-        V n = mk(0, 1, 0), x = ro;
-        Mat mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
+        SurfaceSample s{ro, mk(0, 1, 0), wo, Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f}, mk(0, 0, 0), 0.f, surf};
         if (surf) {
             uint32_t obj;
-            finalize_hit(sc_arg, ro, rd, tmin, t, code, inst, n, obj);
-            mat = load_mat(sc_arg, obj);
-            x = fma3(t, rd, ro);
+            finalize_hit(sc_arg, ro, rd, tmin, t, code, inst, s.n, obj);
+            s.mat = load_mat(sc_arg, obj);
+            s.x = fma3(t, rd, ro);
         }
-        V sc_col = mat_emit(mat) * mat_color(mat);
-        float max_d2 = 0.f;
-        // One gathered photon's term (src/photon.rs:357-371).  Visibility ("something lies between the photon and the
-        // query point"): only a hit closer than the query point can block, and every point of the segment photon -> x
-        // lies within the gather radius of x: scanned records whose box misses that ball (of any sample of this pixel:
-        // the mask is wave-uniform) cannot decide the test and are skipped.  The closest hit below |disp| (1 - 1e-3)
-        // is the closest hit of the unbounded query whenever that one would block, so the decisions are the same as
-        // with the full scan.
-        // no_scan (wave-uniform): no lane needs the scan; lane_free: this lane's test cannot be blocked whatever a scan finds
-        auto add_photon = [&](V po, V pdir, V ppow, uint64_t vis_mask, bool no_scan = false, bool lane_free = false) {
-            V disp = x - po;
-            float len2 = dot(disp, disp);
-            float ilen = rsq(len2);
-            V pd = ilen * disp;
-            float len = len2 * ilen;
-            float ts = BVH ? kInf : len * (1.f - 1e-3f);
-            uint32_t cs = CODE_MISS, is = 0;
-            if (!(q.skip & 8u) && !no_scan) {  // diagnostic: 8 = no visibility scans
-                if (BVH) closest_hit<2, false>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, is, stk, 256, c0, c1);
-                else scan_prims<true>(sc_arg, po, pd, ray_tmin_p(po), ts, cs, vis_mask);
-            }
-            // A hit inside the query point's own tangent plane is the grazing ray meeting its own surface: fp64
-            // rejects it as parallel (|cos| < 1e-8); fp32 would place it at a random t.  Not an occluder.
-            V hp = fma3(ts, pd, po) - x;
-            bool own_plane = fabsf(dot(hp, n)) <= 1e-4f * len;
-            bool blocked = !lane_free && cs != CODE_MISS && !own_plane && ts < len * (1.f - 1e-3f);
-            if (!blocked || !(len2 > 0.f)) {  // (a query point that coincides with the photon has no ray to trace)
-                float c = fminf(fmaxf(dot(pdir, n), 0.f), 1.f);
-                sc_col = fma3(c, bsdf(mat, n, wo, pdir) * ppow, sc_col);
-            }
-        };
-        // the room shell's box, a few ulps wider (see `lane_clear` below)
-        const bool shell_on = !BVH && sc.has_shell != 0u;
-        F4 sh_lo{}, sh_hi{};
-        if (shell_on) {
-            const ShellScan sh = uload(sc.shell);
-            const float e = 2e-6f * fmaxf(max3(fabsf(sh.lo.x), fabsf(sh.lo.y), fabsf(sh.lo.z)), max3(fabsf(sh.hi.x), fabsf(sh.hi.y), fabsf(sh.hi.z)));
-            sh_lo = F4{sh.lo.x - e, sh.lo.y - e, sh.lo.z - e, 0.f};
-            sh_hi = F4{sh.hi.x + e, sh.hi.y + e, sh.hi.z + e, 0.f};
-        }
-        auto in_shell = [&](V p) {
-            return !shell_on || (p.x >= sh_lo.x && p.x <= sh_hi.x && p.y >= sh_lo.y && p.y <= sh_hi.y && p.z >= sh_lo.z && p.z <= sh_hi.z);
-        };
-        bool todo = surf;
-        // Consecutive samples of a lane fall within a pixel of each other: the previous gather radius (squared, doubled)
-        // bounds this search; a lane that finds fewer than K photons inside it searches again with a larger one.
-        if (!GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u) {
-            const uint32_t K = q.gather_size, want_k = min(K, q.n_s);
-            uint32_t* const pstack = region + K * 64u;
-            float* const keys = reinterpret_cast<float*>(pstack + kBallStack);
-            F4* const cl = reinterpret_cast<F4*>(keys + q.coop_cap);
-            // Every member lane picks its K nearest out of the M ordered candidates (centre: where `rho` is measured from)
-            // inside its search radius `guess`, then sums the terms of the photons within its K-th distance, in candidate
-            // order.  Lanes that found K are done.
-            auto serve = [&](bool member, float guess, float rho, uint32_t M) {
-                // -- each member's K nearest distances (list in LDS; entries beyond `guess` do not count)
-                uint32_t found = 0, wslot = 0;
-                float worst = 0.f;
-                const float reach0 = __builtin_sqrtf(guess) + rho;
-                float thr = member ? reach0 * reach0 * (1.f + 1e-5f) : -1.f;
-                float k_next = M ? keys[0] : 0.f;
-                F4 c_next = M ? cl[0] : F4{0.f, 0.f, 0.f, 0.f};
-                for (uint32_t j = 0; j < M; j++) {
-                    const float kj = k_next;
-                    const F4 cj = c_next;
-                    {   // the next candidate's LDS reads are in flight while this one is handled
-                        const uint32_t jn = min(j + 1u, M - 1u);
-                        k_next = keys[jn];
-                        c_next = cl[jn];
-                    }
-                    if (__ballot(kj <= thr) == 0ull) break;   // no member's ball reaches this far from the centre
-                    if (a.counters) g_cnt[5]++;
-                    const V d = xyz(cj) - x;
-                    const float d2 = dot(d, d);
-                    bool changed = false;
-                    if (member) {
-                        if (found < K) {
-                            if (d2 <= guess) {
-                                gd[found * 64u] = d2;
-                                found++;
-                                changed = found == K;
-                            }
-                        } else if (d2 < worst) {
-                            gd[wslot * 64u] = d2;
-                            changed = true;
-                        }
-                        if (changed) {   // (re)locate the current worst: four independent LDS reads per step
-                            worst = -1.f;
-                            uint32_t k = 0;
-                            for (; k + 4u <= K; k += 4u) {
-                                const float v0 = gd[k * 64u], v1 = gd[(k + 1u) * 64u], v2 = gd[(k + 2u) * 64u], v3 = gd[(k + 3u) * 64u];
-                                const float m01 = fmaxf(v0, v1), m23 = fmaxf(v2, v3), m = fmaxf(m01, m23);
-                                if (m > worst) {
-                                    worst = m;
-                                    wslot = k + (m == m01 ? (m == v0 ? 0u : 1u) : (m == v2 ? 2u : 3u));
-                                }
-                            }
-                            for (; k < K; k++) {
-                                const float v = gd[k * 64u];
-                                if (v > worst) { worst = v; wslot = k; }
-                            }
-                            const float reach = __builtin_sqrtf(worst) + rho;
-                            thr = reach * reach * (1.f + 1e-5f);
-                        }
-                    }
-                    if (a.counters && __ballot(changed) != 0ull) g_cnt[6]++;
-                }
-                const bool ok = member && found >= want_k;
-                float r2k = found == K ? worst : 0.f;
-                if (ok && found < K) for (uint32_t k = 0; k < found; k++) r2k = fmaxf(r2k, gd[k * 64u]);   // (a map of fewer than K photons)
-                if (!ok) r2k = 0.f;
-                // -- the terms of the photons within each lane's radius, in candidate order
-                uint64_t vis_mask = ~0ull;
-                bool touched = true;   // some scanned record comes near this lane's ball
-                if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, ok, x, __builtin_sqrtf(r2k) * (1.f + 1e-4f) + 1e-6f, &touched);
-                // A lane's test cannot be blocked when no scanned record comes near its ball, the scene has no plane, and both
-                // ends of the segment lie inside the room shell: its faces bound a convex box, a segment between two points of
-                // the closed box meets a face at its ends only, and those the search interval leaves out.  (The scan itself is
-                // less exact there: next to an edge of the room it reports false crossings, see tools/photon_breakdown.py 128.)
-                // Then the gathered photon is visible by construction; the scan runs only if some lane of the term needs it.
-                // A point counts as inside within a few ulps.  The decision is the lane's own: no other lane's geometry enters.
-                bool lane_clear = !BVH && !touched && sc.n_pln == 0u && !(q.skip & 128u);   // (diagnostic: 128 = always scan)
-                lane_clear = lane_clear && in_shell(x);
-                const float reach2 = __builtin_sqrtf(r2k) + rho;
-                const float thr2 = ok ? reach2 * reach2 * (1.f + 1e-5f) : -1.f;
-                bool more = __ballot(ok) != 0ull && !(q.skip & 16u);   // diagnostic: 16 = no second pass
-                const float thr2_max = wave_max(thr2);
-                for (uint32_t base = 0; base < M && more; base += 64u) {
-                    // lane l fetches what the term needs of candidate base + l; the records are then handed round by readlane
-                    F4 fdir{}, fpow{};
-                    if (base + lane_ < M && keys[base + lane_] <= thr2_max) {
-                        const uint32_t idx = __float_as_uint(cl[base + lane_].w);
-                        fdir = q.s_ph[idx].dir;
-                        fpow = q.s_ph[idx].pow;
-                    }
-                    const uint32_t nb = min(64u, M - base);
-                    float k_nx = keys[base];
-                    F4 c_nx = cl[base];
-                    for (uint32_t jj = 0; jj < nb; jj++) {
-                        const uint32_t j = base + jj;
-                        const float kj = k_nx;
-                        const V po = xyz(c_nx);
-                        {
-                            const uint32_t jn = min(j + 1u, M - 1u);
-                            k_nx = keys[jn];
-                            c_nx = cl[jn];
-                        }
-                        if (__ballot(kj <= thr2) == 0ull) { more = false; break; }
-                        if (a.counters) g_cnt[7]++;
-                        const V dd = po - x;
-                        const bool in = ok && dot(dd, dd) <= r2k;
-                        if (__ballot(in) == 0ull) continue;
-                        auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), jj)); };
-                        const V pdir = mk(rl(fdir.x), rl(fdir.y), rl(fdir.z)), ppow = mk(rl(fpow.x), rl(fpow.y), rl(fpow.z));
-                        if (a.counters) g_cnt[8]++;
-                        const bool lane_free = lane_clear && in_shell(po);   // (po is wave-uniform)
-                        const bool no_scan = __ballot(in && !lane_free) == 0ull;
-                        if (a.counters && no_scan) g_cnt[1]++;
-                        if (in) add_photon(po, pdir, ppow, vis_mask, no_scan, lane_free);
-                    }
-                }
-                if (ok) {
-                    max_d2 = r2k;
-                    todo = false;
-                }
-                return ok;
-            };
-            // Consecutive samples of a lane fall within a pixel of each other: the previous gather radius (squared, doubled)
-            // bounds this search; a lane that finds fewer than K photons inside it searches again with a larger one.
-            float guess = prev_r2 > 0.f ? 2.f * prev_r2 : 0.f;
-            {   // a lane without a radius of its own borrows the largest one in the wave
-                const float g = wave_max(todo ? guess : 0.f);
-                if (!(guess > 0.f)) guess = g;
-            }
-            if (a.counters && __ballot(todo) != 0ull) g_cnt[0]++;
-            // round 0 serves the lanes from the pixel's candidate list (a lane's ball has to lie inside the collected one); the
-            // later rounds collect for clusters of the query points that are left: none, unless the pixel straddles an edge,
-            // a radius was too small or there is no pixel list
-            for (uint32_t round = pix_valid ? 0u : 1u; round < 7u; round++) {
-                const uint64_t cm = __ballot(todo && guess > 0.f);
-                if (cm == 0ull) break;
-                bool member;
-                float g_use, rho;
-                uint32_t M;
-                if (round == 0u) {
-                    const V dx = x - pxc;
-                    rho = __builtin_sqrtf(dot(dx, dx));
-                    const float room = pix_R * (1.f - 2e-5f) - rho;
-                    g_use = fminf(guess, room > 0.f ? room * room : 0.f);
-                    member = todo && g_use > 0.f;
-                    M = pix_M;
-                } else {
-                    pix_valid = false;   // (these rounds reuse the list's LDS)
-                    const uint32_t lead = uint32_t(__ffsll((unsigned long long)cm)) - 1u;
-                    auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lead)); };
-                    const V xc = mk(bc(x.x), bc(x.y), bc(x.z));
-                    const float gc = bc(guess);
-                    const V dx = x - xc;
-                    const float rho2 = dot(dx, dx);
-                    member = todo && guess > 0.f && rho2 <= gc;   // within the leader's own search radius
-                    rho = __builtin_sqrtf(rho2);
-                    g_use = guess;
-                    const float R = wave_max(member ? __builtin_sqrtf(guess) + rho : 0.f) * (1.f + 1e-5f);
-                    // the anchor: the end of the one-child chain of a ball twice as wide, kept while the queries stay inside that ball
-                    const V da = xc - anc_c;
-                    if (!(anc_R > 0.f) || __builtin_sqrtf(dot(da, da)) + R > anc_R) {
-                        anc_c = xc;
-                        anc_R = 2.f * R;
-                        anc_node = ball_anchor(q.s_nodes, q.n_s, xc, anc_R * anc_R);
-                        if (a.counters) g_cnt[9]++;
-                    }
-                    uint32_t steps = 0;
-                    M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc_node, xc, R * R, pstack, reinterpret_cast<uint32_t*>(keys), cl, q.coop_cap, steps);
-                    if (a.counters) { g_cnt[2] += steps; if (M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += M; }
-                    if (M == kCoopOverflow) break;   // the lanes still to do search one by one below
-                    if (q.skip & 64u) { if (member) { max_d2 = 0.5f * guess; todo = false; } continue; }   // diagnostic: collection only
-                    // ordered, like the pixel's list, by distance to the pixel's first surface point when there is one: the order
-                    // of a lane's terms is then the same whichever round serves it
-                    const V kc = (pix_gather && have_xc) ? pxc : xc;
-                    sort_candidates(cl, keys, M, kc);
-                    const V dk = x - kc;
-                    rho = __builtin_sqrtf(dot(dk, dk));
-                    if (q.skip & 32u) { if (member) { max_d2 = 0.5f * guess; todo = false; } continue; }   // diagnostic: collection + ordering only
-                }
-                if (round == 0u && (q.skip & 96u)) { if (member) { max_d2 = 0.5f * guess; todo = false; } continue; }   // diagnostic: 32 / 64 = no selection
-                const bool ok = serve(member, g_use, rho, M);
-                if (member && !ok) guess = fmaxf(guess, 4.f * g_use);   // too few photons inside: twice the radius next round
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (a.counters) { const uint64_t fm = __ballot(todo); if (fm) { g_cnt[10]++; g_cnt[11] += uint32_t(__popcll(fm)); } }
-        if (__ballot(todo) != 0ull) pix_valid = false;   // (the index lists of these searches lie where the pixel's candidate list is)
-        if (todo) {   // one search per lane (lists in global memory, no radius to start from, an overfull candidate list)
-            const uint32_t want_k = min(q.gather_size, q.n_s);
-            uint32_t found = 0;
-            // (the samples of a pixel hit within a footprint of each other: they search the tree together)
-            if (prev_r2 > 0.f) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2, 2.f * prev_r2);
-            if (found < want_k || !(prev_r2 > 0.f)) found = gather_knn<true>(q.s_nodes, q.s_ph, q.n_s, x, q.gather_size, gd, gi, max_d2);
-            uint64_t vis_mask = ~0ull;
-            bool touched = true;
-            if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, true, x, __builtin_sqrtf(max_d2) * (1.f + 1e-4f) + 1e-6f, &touched);
-            const bool lane_clear = !BVH && !touched && sc.n_pln == 0u && !(q.skip & 128u) && in_shell(x);   // as in the wave-level gather
-            for (uint32_t k = 0; k < found; k++) {
-                const PhotonRec ph = q.s_ph[gi[k * 64u]];
-                const bool lane_free = lane_clear && in_shell(xyz(ph.pos_r));
-                add_photon(xyz(ph.pos_r), xyz(ph.dir), xyz(ph.pow), vis_mask, __ballot(!lane_free) == 0ull, lane_free);
-            }
-        }
+        s.sc_col = mat_emit(s.mat) * mat_color(s.mat);
+        WalkScratch ws{stk, c0, c1};
+        if (!GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u)
+            surface_gather_wave<BVH>(q, sc_arg, lds, shell, s, ws, plist, anc, prev_r2, g_cnt);
+        if (a.counters) { const uint64_t fm = __ballot(s.todo); if (fm) { g_cnt[10]++; g_cnt[11] += uint32_t(__popcll(fm)); } }
+        if (__ballot(s.todo) != 0ull) plist.valid = false;   // (the index lists of these searches lie where the pixel's candidate list is)
+        if (s.todo) surface_gather_lane<BVH>(q, sc_arg, lds, shell, s, ws, prev_r2);
+        c0 = ws.c0;
+        c1 = ws.c1;
+        V sc_col = s.sc_col;
+        const float max_d2 = s.max_d2;
         if (surf) {
             prev_r2 = max_d2;
             sc_col = (kInvPi * rcp(max_d2)) * sc_col;
