@@ -1256,7 +1256,31 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
     float thr = member ? reach0 * reach0 * (1.f + 1e-5f) : -1.f;
     float k_next = M ? keys[0] : 0.f;
     F4 c_next = M ? cl[0] : F4{0.f, 0.f, 0.f, 0.f};
-    for (uint32_t j = 0; j < M; j++) {
+    uint32_t j = 0;
+    // The first K candidates fill the lists: as long as every member takes every one of them (the usual case) nothing has
+    // to be decided per lane, and the largest entry is known when the list is full.
+    for (; j < K && j < M; j++) {
+        const float kj = k_next;
+        const V d = xyz(c_next) - x;
+        const float d2 = dot(d, d);
+        if (__ballot(kj <= thr) == 0ull || __ballot(member && d2 > guess) != 0ull) break;   // (the general loop goes on from here)
+        {
+            const uint32_t jn = min(j + 1u, M - 1u);
+            k_next = keys[jn];
+            c_next = cl[jn];
+        }
+        if (a.counters) g_cnt[5]++;
+        if (member) {
+            gd[j * 64u] = d2;
+            if (d2 > worst) { worst = d2; wslot = j; }
+        }
+    }
+    if (member) found = j;
+    if (member && found == K) {
+        const float reach = __builtin_sqrtf(worst) + rho;
+        thr = reach * reach * (1.f + 1e-5f);
+    }
+    for (; j < M; j++) {
         const float kj = k_next;
         const F4 cj = c_next;
         {   // the next candidate's LDS reads are in flight while this one is handled
