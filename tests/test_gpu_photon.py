@@ -377,3 +377,36 @@ def test_photon_maps_of_changing_size_reuse_their_device_buffers():
     assert first[0]["surface"] == again[0]["surface"] and first[0]["volume"] == again[0]["volume"]
     assert np.array_equal(first[1], again[1]) and np.array_equal(first[2], again[2])
     assert np.array_equal(first[3], again[3]) and first[3].mean() > 0
+
+
+@pytest.mark.parametrize("fog", [False, True])
+def test_photon_mapping_over_a_mesh_with_its_own_tree(fog):
+    """Photon mapping in a scene whose mesh is large enough for a tree of its own (the BVH instantiations of the shooting
+    and camera-pass kernels: traversal stack in LDS next to the gather lists, visibility of a gathered photon through the
+    tree walk instead of the masked scan): shooting statistics and the camera pass against the oracle, whose meshes
+    are rpt's kd-trees."""
+    from rpt_amd import Camera, Medium, Mesh, plane
+    sc = Scene()
+    sc.add(Object(Mesh(scenes.bumpy_torus(40, 24)).scale(vec3(1.5, 1.5, 1.5)).rotate_x(0.5)).material(Material.diffuse(vec3(0.8, 0.6, 0.3))))
+    sc.add(Object(plane(vec3(0, 1, 0), -1.2)).material(Material.diffuse(vec3(0.7, 0.7, 0.7))))
+    quad = polygon([vec3(1.0, 3.0, -1.0), vec3(1.0, 3.0, 1.0), vec3(-1.0, 3.0, 1.0), vec3(-1.0, 3.0, -1.0)])
+    sc.add(Object(quad).material(Material.light(vec3(1, 1, 1), 40.0)))
+    sc.add(Light.Object(Object(polygon([vec3(1.0, 3.0, -1.0), vec3(1.0, 3.0, 1.0), vec3(-1.0, 3.0, 1.0), vec3(-1.0, 3.0, -1.0)]))
+                        .material(Material.light(vec3(1, 1, 1), 40.0))))
+    if fog:
+        sc.add(Medium.homogeneous_isotropic(0.02, 0.08))
+    cam = Camera.look_at(vec3(0.0, 1.5, 5.0), vec3(0.0, 0.0, 0.0), vec3(0, 1, 0), 0.8)
+    n, size, spp, watts = 8000, 40, 4, 300.0
+    r = Renderer(sc, cam).width(size).height(size).watts(watts).gather_size(12).gather_size_volume(3).seed(11)
+    st = r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    assert r.scene_stats()["bvh_nodes"] > 0                  # the mesh has a tree
+    got = r.photon_sample_array(spp)
+    pm = _oracle(sc).photon_map(n, 1, watts, 12, 3, seed=11, robust=1)
+    for which, key in ((0, "surface"), (1, "volume")):
+        n_oracle = len(pm.photons(which))
+        assert abs(st[key] - n_oracle) <= 0.02 * n_oracle + 5
+    assert (st["volume"] > 0) == fog
+    exp = pm.render(cam, size, size, spp, seed=11)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert rel_rms(got, exp) < 3e-2
+    assert abs(got.mean() - exp.mean()) / exp.mean() < 1e-2
