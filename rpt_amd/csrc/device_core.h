@@ -907,11 +907,15 @@ RPT_DEV void sample_light_leaf(const SceneView& scene_, uint32_t shape, uint32_t
         } else {
             tr = sc.ltris[first + idx];
         }
-        float u = rng.uniform(), vv = rng.uniform();
-        while (u + vv > 1.f) {
-            u = rng.uniform();
-            vv = rng.uniform();
+        // `while u + v > 1 { redraw }` (src/shape/mesh.rs:89-93) on the draws' integers: with u = (2k+1) 2^-24 the sum is exact
+        // in fp32 and u + v > 1 <=> ku + kv >= 2^23, so the rejected pairs are never converted (the wave runs the loop for its
+        // unluckiest lane: ~7 rounds for 2 on average)
+        uint32_t ku = rng.next() >> 9, kv = rng.next() >> 9;
+        while (ku + kv >= (1u << 23)) {
+            ku = rng.next() >> 9;
+            kv = rng.next() >> 9;
         }
+        const float u = float((ku << 1) | 1u) * 0x1p-24f, vv = float((kv << 1) | 1u) * 0x1p-24f;
         float w = 1.f - u - vv;
         vl = u * xyz(tr.v1) + vv * xyz(tr.v2) + w * xyz(tr.v3);  // already world space
         nl = normalize(u * xyz(tr.n1) + vv * xyz(tr.n2) + w * xyz(tr.n3));
