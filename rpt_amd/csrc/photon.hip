@@ -1520,9 +1520,14 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     const SceneView& sc_arg = a.sc;   // what the device functions are handed (they read the view from the kernarg segment themselves)
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
     const uint32_t K = max(q.gather_size, q.gather_size_volume);  // LDS columns are sized for the larger gather
-    // One wave-private LDS region (after the BVH stack) serves two phases that never overlap in time
-    // within a wave: the gather lists ([K][64] distances + [K][64] indices) of the k-nearest walks, and
-    // the beam walk's pending-entry stack + staging slots.
+    // One wave-private LDS region (after the BVH stack, q.region_dwords each) serves phases that never overlap in time
+    // within a wave (dword offsets):
+    //   surface gather      [0, K*64) per-lane distance lists, then either [K*64, 2*K*64) per-lane index lists (one search
+    //                       per lane) or the wave-level gather's ball-walk stack [kBallStack], candidate keys [coop_cap]
+    //                       and (position, index) records [4 * coop_cap] -- the pixel's candidate list lives there from
+    //                       pixel_candidates to the pixel's last trip;
+    //   beam, photon/lane   [0, 4*kSuper) the pixel's rays, then the two lists of culled candidates [2 * kPendCap];
+    //   beam, sample/lane   [0, kBeamCap) the walk's pending entries, then 64 staging slots of 16 dwords.
     const uint32_t lane_ = threadIdx.x & 63u, wave_ = threadIdx.x >> 6;
     uint32_t* region = dyn_lds + (BVH ? 32u * 256u : 0u) + wave_ * q.region_dwords;
     // GG: the lists of a gather larger than kGatherLds live in a per-wave global-memory region, same [k][lane] layout
