@@ -265,17 +265,20 @@ def main(argv=None):
     spp = args.spp or cfg["spp"]
     r = Renderer(scene, cam).width(width).height(height).max_bounces(cfg["max_bounces"]).seed(0)
     r.device(local_rank).shard(rank, world)
-    # Two frames on two HIP streams, used alternately -- what an iterative render does with consecutive batches:
-    # the first blocks of step k + 1 take over the CUs that the last paths of step k no longer fill (the library
-    # keeps a slab + work counter per stream), and for N > 1 the sum-reduce of step k (RCCL, its own stream)
-    # overlaps the rendering of step k + 1.  Everything has completed before the closing synchronize + barrier of
-    # the timed region.
-    frames = [torch.zeros(width * height * 3, dtype=torch.float64, device="cuda") for _ in range(2)]
+    # Two HIP streams used alternately -- what an iterative render does with consecutive batches: the first blocks
+    # of step k + 1 take over the CUs that the last paths of step k no longer fill (the library keeps a slab + work
+    # counter per stream) -- and, for N > 1, the sum-reduce of step k on RCCL's own stream.  The persistent grid of step
+    # k + 1 holds every CU slot until it drains, so the reduce of step k gets its workgroups only then, next to the first
+    # blocks of step k + 2: the frames form a ring of THREE, so that step k + 2 does not write the frame that reduce is
+    # still reading (with two, every step would wait for a reduce with the GPU otherwise idle).  Everything has completed
+    # before the closing synchronize + barrier of the timed region.
+    n_frames = 3
+    frames = [torch.zeros(width * height * 3, dtype=torch.float64, device="cuda") for _ in range(n_frames)]
     if args.streams == 0:
         args.streams = 2   # consecutive steps alternate between two streams: the start of one overlaps the tail of the other
     streams = [torch.cuda.Stream() for _ in range(2)]
     d_out = frames[0]
-    pending = [None, None]
+    pending = [None] * n_frames
     step_no = [0]
     stream = torch.cuda.current_stream().cuda_stream
     rpt_amd.set_option("timing", 1)
@@ -290,14 +293,15 @@ def main(argv=None):
     def step():
         r._sample_offset = 0
         slot = step_no[0] % 2 if (args.streams == 2 and not photon) else 0   # the photon map is built on the null stream
+        fi = step_no[0] % n_frames
         step_no[0] += 1
-        frame = frames[slot]
+        frame = frames[fi]
         on = torch.cuda.default_stream() if (photon or args.streams == 1) else streams[slot]
         with torch.cuda.stream(on):
             st = on.cuda_stream
-            if pending[slot] is not None:   # the reduce that last used this frame must be done before it is overwritten
-                pending[slot].wait()
-                pending[slot] = None
+            if pending[fi] is not None:   # the reduce that last used this frame must be done before it is overwritten
+                pending[fi].wait()
+                pending[fi] = None
             if photon:
                 if dist is not None:   # shooting sharded by photon index, records all-gathered over RCCL
                     photon_map_build_sharded(r, n_photons, Renderer.PHOTON_POINT_BEAM, rank, world)
@@ -307,10 +311,10 @@ def main(argv=None):
             else:
                 r.sample_device(spp, frame.data_ptr(), st)
             if dist is not None:
-                pending[slot] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+                pending[fi] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
 
     def drain():
-        for i in range(2):
+        for i in range(n_frames):
             if pending[i] is not None:
                 pending[i].wait()
                 pending[i] = None
@@ -355,7 +359,7 @@ def main(argv=None):
                 slot = (step_no[0] - 1) % 2 if (args.streams == 2 and not photon) else 0
                 on = torch.cuda.default_stream() if (photon or args.streams == 1) else streams[slot]
                 with torch.cuda.stream(on):
-                    host_frame.copy_(frames[slot], non_blocking=True)
+                    host_frame.copy_(frames[(step_no[0] - 1) % n_frames], non_blocking=True)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
