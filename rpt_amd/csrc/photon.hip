@@ -1240,7 +1240,7 @@ RPT_DEV void add_photon_term(QueryK q, const SceneView& sc_arg, SurfaceSample& s
 // found K are done (s.todo, s.max_d2).  g_cnt: diagnostic counters of the wave.
 template <bool BVH>
 RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
-                          WalkScratch& ws, bool member, float guess, float rho, uint32_t M, uint32_t* g_cnt) {
+                          WalkScratch& ws, bool member, float guess, float rho, uint32_t M, uint32_t* g_cnt, unsigned long long* t_sec) {
     const auto& a = q.r;
     const auto& sc = a.sc;
     const uint32_t lane_ = threadIdx.x & 63u;
@@ -1249,6 +1249,8 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
     const float* const keys = l.keys;
     const F4* const cl = l.cl;
     const V x = s.x;
+    unsigned long long tk = a.counters ? __builtin_amdgcn_s_memtime() : 0ull;   // (diagnostic: t_sec[7..9] = selection, mask, terms)
+    auto lap = [&](int k) { if (a.counters) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_sec[k] += t1 - tk; tk = t1; } };
     // -- each member's K nearest distances (list in LDS; entries beyond `guess` do not count)
     uint32_t found = 0, wslot = 0;
     float worst = 0.f;
@@ -1329,6 +1331,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
     float r2k = found == K ? worst : 0.f;
     if (ok && found < K) for (uint32_t k = 0; k < found; k++) r2k = fmaxf(r2k, gd[k * 64u]);   // (a map of fewer than K photons)
     if (!ok) r2k = 0.f;
+    lap(7);
     // -- the terms of the photons within each lane's radius, in candidate order
     uint64_t vis_mask = ~0ull;
     bool touched = true;   // some scanned record comes near this lane's ball
@@ -1345,6 +1348,13 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
     const float thr2 = ok ? reach2 * reach2 * (1.f + 1e-5f) : -1.f;
     bool more = __ballot(ok) != 0ull && !(q.skip & 16u);   // diagnostic: 16 = no second pass
     const float thr2_max = wave_max(thr2);
+    // Most terms need no visibility scan and sit on diffuse surfaces: what bsdf() returns for a Lambertian surface whenever
+    // n.wi >= 0 is a constant of the lane (src/material.rs:268-275; for n.wi < 0 the cosine factor is zero anyway), and the
+    // term is cos * (albedo / pi) * power with nothing of the ray to the photon in it.
+    const bool lambert = s.mat.kind == M_LAMBERTIAN;
+    const V f_diffuse = (lambert && !__builtin_signbit(dot(s.n, s.wo))) ? kInvPi * s.mat.albedo : mk(0.f, 0.f, 0.f);
+    const bool all_diffuse = __ballot(ok && !lambert) == 0ull;   // wave-uniform
+    lap(8);
     for (uint32_t base = 0; base < M && more; base += 64u) {
         // lane l fetches what the term needs of candidate base + l; the records are then handed round by readlane
         F4 fdir{}, fpow{};
@@ -1376,9 +1386,17 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
             const bool lane_free = lane_clear && shell.holds(po);   // (po is wave-uniform)
             const bool no_scan = __ballot(in && !lane_free) == 0ull;
             if (a.counters && no_scan) g_cnt[1]++;
-            if (in) add_photon_term<BVH>(q, sc_arg, s, ws, po, pdir, ppow, vis_mask, no_scan, lane_free);
+            if (no_scan && all_diffuse) {   // (wave-uniform) visible by construction, diffuse: the term itself
+                if (in) {
+                    const float c = fminf(fmaxf(dot(pdir, s.n), 0.f), 1.f);
+                    s.sc_col = fma3(c, f_diffuse * ppow, s.sc_col);
+                }
+            } else if (in) {
+                add_photon_term<BVH>(q, sc_arg, s, ws, po, pdir, ppow, vis_mask, no_scan, lane_free);
+            }
         }
     }
+    lap(9);
     if (ok) {
         s.max_d2 = r2k;
         s.todo = false;
@@ -1432,7 +1450,7 @@ RPT_DEV void pixel_candidates(QueryK q, const GatherLds& l, PixelList& pix, Anch
 // an edge, a radius was too small or there is no pixel list.  Lanes it cannot serve keep s.todo.
 template <bool BVH>
 RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
-                                 WalkScratch& ws, PixelList& pix, Anchor& anc, float prev_r2, uint32_t* g_cnt) {
+                                 WalkScratch& ws, PixelList& pix, Anchor& anc, float prev_r2, uint32_t* g_cnt, unsigned long long* t_sec) {
     const auto& a = q.r;
     const V x = s.x;
     float guess = prev_r2 > 0.f ? 2.f * prev_r2 : 0.f;
@@ -1480,7 +1498,7 @@ RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const Gather
             rho = __builtin_sqrtf(dot(dk, dk));
         }
         if (q.skip & 96u) { if (member) { s.max_d2 = 0.5f * guess; s.todo = false; } continue; }   // diagnostic: 32 / 64 = no selection
-        const bool ok = gather_serve<BVH>(q, sc_arg, l, shell, s, ws, member, g_use, rho, M, g_cnt);
+        const bool ok = gather_serve<BVH>(q, sc_arg, l, shell, s, ws, member, g_use, rho, M, g_cnt, t_sec);
         if (member && !ok) guess = fmaxf(guess, 4.f * g_use);   // too few photons inside: twice the radius next round
         __builtin_amdgcn_wave_barrier();
     }
@@ -1543,6 +1561,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     float prev_r2 = 0.f;  // squared radius of this lane's previous surface gather
     unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
     uint32_t g_cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic (counters build), wave-level: see the end of the kernel
+    unsigned long long t_sec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic: clock ticks of this wave per part of a pixel (counters build)
+    auto tick = [&]() { return a.counters ? __builtin_amdgcn_s_memtime() : 0ull; };
     Anchor anc{mk(0, 0, 0), 0.f, 0u};   // wave-uniform: the surface gather's anchor (ball_anchor)
     // Work decomposition of the camera pass: a wave takes a strip of rows of one 8x8 pixel block and one chunk of up
     // to kSuper samples at a time and walks through the strip's pixels; a pixel's samples are handled 64 at a time:
@@ -1656,6 +1676,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         bool have_xc = false;      // wave-uniform
         V pxc = mk(0, 0, 0);       // wave-uniform: the first surface point among the pixel's samples
         float prho2 = 0.f;         // how far (squared) this lane's surface points lie from it
+        unsigned long long tk = tick();
         if (beam_lanes || pix_gather) {
             for (uint32_t sub = 0; sub < n_sub; sub++) {
                 Rng rng;
@@ -1689,7 +1710,9 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         if (beam_lanes) {
             far2 = wave_max(far2);   // farthest hit of the pixel's samples (inf on a miss)
             near2 = wave_min(near2);  // nearest one
+            { const unsigned long long t1 = tick(); t_sec[0] += t1 - tk; tk = t1; }   // [0] first pass over the rays
             beam_sum = beam_estimate_photon_lanes(q, cand, cand_n, far2, near2, xn, yn, cam_right, cam_up, sigma_t, n_s, rays, pend_list, c_leaf, c_acc);
+            { const unsigned long long t1 = tick(); t_sec[1] += t1 - tk; tk = t1; }   // [1] beam estimate
             __builtin_amdgcn_wave_barrier();   // the gather lists of the surface estimate reuse this LDS
         }
         // ---- the surface gather's candidates, once for all the pixel's samples when their hit points form one cluster: every
@@ -1698,7 +1721,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         lds.keys = reinterpret_cast<float*>(lds.pstack + kBallStack);
         lds.cl = reinterpret_cast<F4*>(lds.keys + q.coop_cap);
         PixelList plist{false, pix_gather && have_xc, 0u, 0.f, pxc};
-        if (plist.have_c) pixel_candidates(q, lds, plist, anc, prev_r2, prho2, g_cnt);
+        if (plist.have_c && !(q.skip & 256u)) pixel_candidates(q, lds, plist, anc, prev_r2, prho2, g_cnt);   // (diagnostic: 256 = no pixel list)
+        { const unsigned long long t1 = tick(); t_sec[2] += t1 - tk; tk = t1; }   // [2] the pixel's candidate list (+ the first pass when there is no beam estimate)
         const ShellBox shell = shell_box<BVH>();
         // ---- the pixel's samples, 64 per trip; lane = sample
         V pixel_sum = mk(0, 0, 0);
@@ -1708,6 +1732,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         uint32_t code, inst;
         Rng rng;
         const bool active = gen_ray(sub, rng, ro, rd, tmin, t, code, inst);
+        { const unsigned long long t1 = tick(); t_sec[3] += t1 - tk; tk = t1; }   // [3] second pass over the rays
         const V wo = -normalize(rd);
         if (active) c_samp++;
         const bool hit = code != CODE_MISS;
@@ -1752,13 +1777,16 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         }
         s.sc_col = mat_emit(s.mat) * mat_color(s.mat);
         WalkScratch ws{stk, c0, c1};
+        { const unsigned long long t1 = tick(); t_sec[4] += t1 - tk; tk = t1; }   // [4] volume estimate with the samples in the lanes, hit record, material
+        if (q.skip & 512u) { s.todo = false; s.max_d2 = 1.f; }   // (diagnostic: 512 = hit record and material only)
         if (!GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u)
-            surface_gather_wave<BVH>(q, sc_arg, lds, shell, s, ws, plist, anc, prev_r2, g_cnt);
+            surface_gather_wave<BVH>(q, sc_arg, lds, shell, s, ws, plist, anc, prev_r2, g_cnt, t_sec);
         if (a.counters) { const uint64_t fm = __ballot(s.todo); if (fm) { g_cnt[10]++; g_cnt[11] += uint32_t(__popcll(fm)); } }
         if (__ballot(s.todo) != 0ull) plist.valid = false;   // (the index lists of these searches lie where the pixel's candidate list is)
         if (s.todo) surface_gather_lane<BVH>(q, sc_arg, lds, shell, s, ws, prev_r2);
         c0 = ws.c0;
         c1 = ws.c1;
+        { const unsigned long long t1 = tick(); t_sec[5] += t1 - tk; tk = t1; }   // [5] surface gather
         V sc_col = s.sc_col;
         const float max_d2 = s.max_d2;
         if (surf) {
@@ -1779,6 +1807,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             sum.z += __shfl_xor(sum.z, off);
         }
         if (lane_ == 0) reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(sum.x, sum.y, sum.z, 0.f);
+        { const unsigned long long t1 = tick(); t_sec[6] += t1 - tk; tk = t1; }   // [6] the pixel's sum
     }
     if (a.counters) {  // diagnostic: [0] camera samples, [5] photon spheres visited, [6] photon spheres accepted
         atomicAdd(&a.counters[0], c_samp);
@@ -1789,6 +1818,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         // second pass, [17] new anchors, [18] / [19] trips / lanes that searched one by one
         if (lane_ == 0u)
             for (int k = 0; k < 12; k++) atomicAdd(&a.counters[8 + k], (unsigned long long)g_cnt[k]);
+        if (lane_ == 0u)   // [24..]: clock ticks (100 MHz) per part, summed over the waves
+            for (int k = 0; k < 10; k++) atomicAdd(&a.counters[24 + k], t_sec[k]);
     }
 }
 

@@ -15,7 +15,8 @@ r.gather_size(cfg["gather_size"]).gather_size_volume(cfg["gather_size_volume"]).
 print(r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM))
 for skip, what in ((0, "full"), (1, "no volume (beam) estimate"), (2, "no surface estimate"), (3, "primary rays only"),
                    (6, "beam walk without the per-ray tests"), (9, "surface estimate without visibility scans"),
-                   (17, "surface: no second pass"), (33, "surface: collection + ordering only"), (65, "surface: collection only")):
+                   (17, "surface: no second pass"), (33, "surface: collection + ordering only"), (65, "surface: collection only"),
+                   (513, "surface: hit record + material only"), (769, "... and no pixel list either")):
     rpt_amd.set_option("photon_skip", skip)
     ms = []
     for _ in range(2):

@@ -24,3 +24,11 @@ trips = max(int(out[0]), 1)
 print(f"samples {c['samples']}, beam tests per sample {c['bvh_nodes'] / c['samples']:.1f}")
 for k, nm in enumerate(names):
     print(f"  {nm:32s} {int(out[k]):12d}   per trip {int(out[k]) / trips:8.2f}")
+tn = ["first pass over the rays", "beam estimate", "pixel candidate list", "second pass over the rays",
+      "hit record + material (+ volume estimate, samples in lanes)", "surface gather", "pixel sum"]
+tot = sum(int(out[16 + k]) for k in range(len(tn))) or 1
+print("wave clock ticks per part (share of the pixels' time):")
+for k, nm in enumerate(tn):
+    print(f"  {nm:60s} {100.0 * int(out[16 + k]) / tot:6.2f} %")
+for k, nm in ((7, "selection"), (8, "scan mask, thresholds"), (9, "terms")):
+    print(f"    of the surface gather: {nm:36s} {100.0 * int(out[16 + k]) / tot:6.2f} %")
