@@ -841,8 +841,10 @@ RPT_DEV uint32_t ball_anchor(const BvhNode* nodes, uint32_t n, V c, float R2) {
 // Every photon below the inner node `start` within sqrt(R2) of c, as (position, index) records in cand[0 .. return value);
 // the set is a function of (c, R2) alone when `start` is an anchor of a ball that contains this one.  kCoopOverflow if the
 // stack or the list does not hold them.  `lscratch`: 64 dwords of wave-private LDS.
+// `box_on`, `box_lo`, `box_hi`: the room shell's box (ShellBox); a candidate inside it carries bit 31 in its index word.
+static constexpr uint32_t kCandInShell = 0x80000000u;
 RPT_DEV uint32_t ball_collect(const BvhNode* nodes, const PhotonRec* p, uint32_t n, uint32_t start, V c, float R2, uint32_t* pstack,
-                              uint32_t* lscratch, F4* cand, uint32_t cap, uint32_t& steps) {
+                              uint32_t* lscratch, F4* cand, uint32_t cap, uint32_t& steps, bool box_on, F4 box_lo, F4 box_hi) {
     const uint32_t lane = threadIdx.x & 63u;
     auto prefix = [](uint64_t m) { return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)); };
     uint32_t count = 1u, M = 0u;  // wave-uniform
@@ -893,7 +895,11 @@ RPT_DEV uint32_t ball_collect(const BvhNode* nodes, const PhotonRec* p, uint32_t
                     const uint64_t tm = __ballot(take);
                     const uint32_t nt = uint32_t(__popcll(tm));
                     if (M + nt > cap) return kCoopOverflow;
-                    if (take) cand[M + prefix(tm)] = F4{pr.x, pr.y, pr.z, __uint_as_float(first + k0 + k)};
+                    if (take) {
+                        const bool inside = !box_on || (pr.x >= box_lo.x && pr.x <= box_hi.x && pr.y >= box_lo.y && pr.y <= box_hi.y &&
+                                                        pr.z >= box_lo.z && pr.z <= box_hi.z);
+                        cand[M + prefix(tm)] = F4{pr.x, pr.y, pr.z, __uint_as_float((first + k0 + k) | (inside ? kCandInShell : 0u))};
+                    }
                     M += nt;
                 }
             }
@@ -1359,7 +1365,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
         // lane l fetches what the term needs of candidate base + l; the records are then handed round by readlane
         F4 fdir{}, fpow{};
         if (base + lane_ < M && keys[base + lane_] <= thr2_max) {
-            const uint32_t idx = __float_as_uint(cl[base + lane_].w);
+            const uint32_t idx = __float_as_uint(cl[base + lane_].w) & ~kCandInShell;
             fdir = q.s_ph[idx].dir;
             fpow = q.s_ph[idx].pow;
         }
@@ -1370,6 +1376,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
             const uint32_t j = base + jj;
             const float kj = k_nx;
             const V po = xyz(c_nx);
+            const bool po_in = (__float_as_uint(c_nx.w) & kCandInShell) != 0u;   // (wave-uniform) the photon lies inside the room shell
             {
                 const uint32_t jn = min(j + 1u, M - 1u);
                 k_nx = keys[jn];
@@ -1383,7 +1390,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
             auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), jj)); };
             const V pdir = mk(rl(fdir.x), rl(fdir.y), rl(fdir.z)), ppow = mk(rl(fpow.x), rl(fpow.y), rl(fpow.z));
             if (a.counters) g_cnt[8]++;
-            const bool lane_free = lane_clear && shell.holds(po);   // (po is wave-uniform)
+            const bool lane_free = lane_clear && po_in;
             const bool no_scan = __ballot(in && !lane_free) == 0ull;
             if (a.counters && no_scan) g_cnt[1]++;
             if (no_scan && all_diffuse) {   // (wave-uniform) visible by construction, diffuse: the term itself
@@ -1428,7 +1435,8 @@ RPT_DEV void anchor_for(QueryK q, Anchor& anc, V c, float R, uint32_t* g_cnt) {
 }
 // Once per pixel: collect and order the candidates of all its samples (prho2: how far, squared, this lane's surface points
 // lie from pix.c; prev_r2: the lane's last gather radius, squared).
-RPT_DEV void pixel_candidates(QueryK q, const GatherLds& l, PixelList& pix, Anchor& anc, float prev_r2, float prho2, uint32_t* g_cnt) {
+RPT_DEV void pixel_candidates(QueryK q, const GatherLds& l, const ShellBox& shell, PixelList& pix, Anchor& anc, float prev_r2, float prho2,
+                              uint32_t* g_cnt) {
     const float G = wave_max(prev_r2 > 0.f ? 2.f * prev_r2 : 0.f);
     const float rho_max2 = wave_max(prho2);
     if (!(G > 0.f && rho_max2 <= G)) return;
@@ -1436,7 +1444,7 @@ RPT_DEV void pixel_candidates(QueryK q, const GatherLds& l, PixelList& pix, Anch
     anchor_for(q, anc, pix.c, pix.R, g_cnt);
     uint32_t steps = 0;
     pix.M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc.node, pix.c, pix.R * pix.R, l.pstack, reinterpret_cast<uint32_t*>(l.keys), l.cl,
-                         q.coop_cap, steps);
+                         q.coop_cap, steps, shell.on, shell.lo, shell.hi);
     if (q.r.counters) { g_cnt[2] += steps; if (pix.M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += pix.M; }
     if (pix.M != kCoopOverflow) {
         if (!(q.skip & 64u)) sort_candidates(l.cl, l.keys, pix.M, pix.c);   // (diagnostic: 64 = collection only)
@@ -1486,7 +1494,8 @@ RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const Gather
             const float R = wave_max(member ? __builtin_sqrtf(guess) + rho : 0.f) * (1.f + 1e-5f);
             anchor_for(q, anc, xc, R, g_cnt);
             uint32_t steps = 0;
-            M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc.node, xc, R * R, l.pstack, reinterpret_cast<uint32_t*>(l.keys), l.cl, q.coop_cap, steps);
+            M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc.node, xc, R * R, l.pstack, reinterpret_cast<uint32_t*>(l.keys), l.cl, q.coop_cap, steps,
+                             shell.on, shell.lo, shell.hi);
             if (a.counters) { g_cnt[2] += steps; if (M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += M; }
             if (M == kCoopOverflow) break;   // the lanes still to do search one by one
             if (q.skip & 64u) { if (member) { s.max_d2 = 0.5f * guess; s.todo = false; } continue; }   // diagnostic: collection only
@@ -1721,9 +1730,9 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         lds.keys = reinterpret_cast<float*>(lds.pstack + kBallStack);
         lds.cl = reinterpret_cast<F4*>(lds.keys + q.coop_cap);
         PixelList plist{false, pix_gather && have_xc, 0u, 0.f, pxc};
-        if (plist.have_c && !(q.skip & 256u)) pixel_candidates(q, lds, plist, anc, prev_r2, prho2, g_cnt);   // (diagnostic: 256 = no pixel list)
-        { const unsigned long long t1 = tick(); t_sec[2] += t1 - tk; tk = t1; }   // [2] the pixel's candidate list (+ the first pass when there is no beam estimate)
         const ShellBox shell = shell_box<BVH>();
+        if (plist.have_c && !(q.skip & 256u)) pixel_candidates(q, lds, shell, plist, anc, prev_r2, prho2, g_cnt);   // (diagnostic: 256 = no pixel list)
+        { const unsigned long long t1 = tick(); t_sec[2] += t1 - tk; tk = t1; }   // [2] the pixel's candidate list (+ the first pass when there is no beam estimate)
         // ---- the pixel's samples, 64 per trip; lane = sample
         V pixel_sum = mk(0, 0, 0);
         for (uint32_t sub = 0; sub < n_sub; sub++) {
