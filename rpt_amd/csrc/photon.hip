@@ -820,6 +820,11 @@ RPT_DEV uint32_t gather_knn(const BvhNode* nodes, const PhotonRec* photons, uint
 static constexpr uint32_t kBallStack = 128;   // pending tree entries of ball_collect (LDS, per wave)
 static constexpr uint32_t kCoopCap = 256;     // candidates at most (four per lane in sort_candidates)
 static constexpr uint32_t kCoopOverflow = 0xFFFFFFFFu;
+// Diagnostic counters of the camera pass (counters build): bumped in memory where they occur, by one lane -- kept in
+// registers for the kernel's life they cost the ordinary build a quarter of its VGPR budget's slack.
+RPT_DEV void diag_add(unsigned long long* counters, int k, unsigned long long v) {
+    if (counters && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) atomicAdd(&counters[k], v);
+}
 // The deepest inner node below which every photon within sqrt(R2) of c lies: down from the root while only one child's
 // box is in reach (c, R2 wave-uniform; the nodes come through scalar loads).  A pixel's query ball is tiny against the
 // map: most of a walk from the root is this chain of one-child steps, a dependent load each -- so the wave keeps the end
@@ -959,8 +964,9 @@ typedef const __attribute__((address_space(4))) QueryArgs& QueryK;
 // has no candidate list): the sum of the weighted photon powers along this lane's ray, before the medium's colour.
 template <int KIND>
 RPT_DEV V volume_estimate_sample_lanes(QueryK q, bool active, V ro, V rd, bool hit, float t, float sigma_t, float phase,
-                                       uint32_t* wstack, F4* stage, unsigned long long& c_leaf, unsigned long long& c_acc) {
+                                       uint32_t* wstack, F4* stage) {
     V vc = mk(0, 0, 0);
+    unsigned long long c_leaf = 0, c_acc = 0;   // diagnostic: photons (beams) tested / accepted by this lane's ray
     // The staging lane pre-computes what depends on the photon only: pos_r.w = r^2, pow = power *
     // 3/pi * phase / r^2, pow.w = 1/r^2 (src/photon.rs:474-493: k2(d^2/r^2)/r^2 with k2(x) = 3/pi (1-x)^2).
     auto prep_point = [&](PhotonRec ph) {
@@ -1052,6 +1058,7 @@ RPT_DEV V volume_estimate_sample_lanes(QueryK q, bool active, V ro, V rd, bool h
         if (!beam_walk_packet<true>(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_packet, visit_packet))
             beam_walk_batch(q.v_nodes, q.v_ph, q.n_v, active, ro, rd, wstack, stage, q.overflow, prep_point, visit);
     }
+    if (q.r.counters) { atomicAdd(&q.r.counters[5], c_leaf); atomicAdd(&q.r.counters[6], c_acc); }
     return vc;
 }
 
@@ -1059,8 +1066,7 @@ RPT_DEV V volume_estimate_sample_lanes(QueryK q, bool active, V ro, V rd, bool h
 // reach into the strip's frustum, `rays` holds the pixel's n_s rays (unit direction, squared hit distance; far2 / near2:
 // the largest / smallest of those distances).  Returns this lane's photons' sum over all the rays, before the medium's colour.
 RPT_DEV V beam_estimate_photon_lanes(QueryK q, const uint32_t* cand, uint32_t cand_n, float far2, float near2, float xn, float yn,
-                                     V cam_right, V cam_up, float sigma_t, uint32_t n_s, const float4* rays, uint32_t* pend_list,
-                                     unsigned long long& c_leaf, unsigned long long& c_acc) {
+                                     V cam_right, V cam_up, float sigma_t, uint32_t n_s, const float4* rays, uint32_t* pend_list) {
     const auto& a = q.r;
     const uint32_t lane_ = threadIdx.x & 63u;
     V beam_sum = mk(0, 0, 0);
@@ -1113,7 +1119,7 @@ RPT_DEV V beam_estimate_photon_lanes(QueryK q, const uint32_t* cand, uint32_t ca
                 }
             }
             beam_sum = fma3(wsum, pw, beam_sum);
-            if (decltype(counting)::value) { c_leaf += n_s; c_acc += n_ok; }
+            if (decltype(counting)::value) { atomicAdd(&a.counters[5], (unsigned long long)n_s); atomicAdd(&a.counters[6], (unsigned long long)n_ok); }
         }
     };
     auto flush_batch = [&](const uint32_t* list, uint32_t nb, auto plain) {
@@ -1243,10 +1249,10 @@ RPT_DEV void add_photon_term(QueryK q, const SceneView& sc_arg, SurfaceSample& s
 }
 // Every member lane picks its K nearest out of the M ordered candidates (centre: where `rho` is measured from) inside its
 // search radius `guess`, then sums the terms of the photons within its K-th distance, in candidate order.  Lanes that
-// found K are done (s.todo, s.max_d2).  g_cnt: diagnostic counters of the wave.
+// found K are done (s.todo, s.max_d2).
 template <bool BVH>
 RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
-                          WalkScratch& ws, bool member, float guess, float rho, uint32_t M, uint32_t* g_cnt, unsigned long long* t_sec) {
+                          WalkScratch& ws, bool member, float guess, float rho, uint32_t M) {
     const auto& a = q.r;
     const auto& sc = a.sc;
     const uint32_t lane_ = threadIdx.x & 63u;
@@ -1255,8 +1261,8 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
     const float* const keys = l.keys;
     const F4* const cl = l.cl;
     const V x = s.x;
-    unsigned long long tk = a.counters ? __builtin_amdgcn_s_memtime() : 0ull;   // (diagnostic: t_sec[7..9] = selection, mask, terms)
-    auto lap = [&](int k) { if (a.counters) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); t_sec[k] += t1 - tk; tk = t1; } };
+    unsigned long long tk = a.counters ? __builtin_amdgcn_s_memtime() : 0ull;   // (diagnostic: clock ticks of selection, mask, terms)
+    auto lap = [&](int k) { if (a.counters) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); diag_add(a.counters, 24 + k, t1 - tk); tk = t1; } };
     // -- each member's K nearest distances (list in LDS; entries beyond `guess` do not count)
     uint32_t found = 0, wslot = 0;
     float worst = 0.f;
@@ -1277,7 +1283,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
             k_next = keys[jn];
             c_next = cl[jn];
         }
-        if (a.counters) g_cnt[5]++;
+        if (a.counters) diag_add(q.r.counters, 13, 1ull);
         if (member) {
             gd[j * 64u] = d2;
             if (d2 > worst) { worst = d2; wslot = j; }
@@ -1297,7 +1303,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
             c_next = cl[jn];
         }
         if (__ballot(kj <= thr) == 0ull) break;   // no member's ball reaches this far from the centre
-        if (a.counters) g_cnt[5]++;
+        if (a.counters) diag_add(q.r.counters, 13, 1ull);
         const V d = xyz(cj) - x;
         const float d2 = dot(d, d);
         bool changed = false;
@@ -1331,7 +1337,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
                 thr = reach * reach * (1.f + 1e-5f);
             }
         }
-        if (a.counters && __ballot(changed) != 0ull) g_cnt[6]++;
+        if (a.counters && __ballot(changed) != 0ull) diag_add(q.r.counters, 14, 1ull);
     }
     const bool ok = member && found >= want_k;
     float r2k = found == K ? worst : 0.f;
@@ -1383,16 +1389,16 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
                 c_nx = cl[jn];
             }
             if (__ballot(kj <= thr2) == 0ull) { more = false; break; }
-            if (a.counters) g_cnt[7]++;
+            if (a.counters) diag_add(q.r.counters, 15, 1ull);
             const V dd = po - x;
             const bool in = ok && dot(dd, dd) <= r2k;
             if (__ballot(in) == 0ull) continue;
             auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), jj)); };
             const V pdir = mk(rl(fdir.x), rl(fdir.y), rl(fdir.z)), ppow = mk(rl(fpow.x), rl(fpow.y), rl(fpow.z));
-            if (a.counters) g_cnt[8]++;
+            if (a.counters) diag_add(q.r.counters, 16, 1ull);
             const bool lane_free = lane_clear && po_in;
             const bool no_scan = __ballot(in && !lane_free) == 0ull;
-            if (a.counters && no_scan) g_cnt[1]++;
+            if (a.counters && no_scan) diag_add(q.r.counters, 9, 1ull);
             if (no_scan && all_diffuse) {   // (wave-uniform) visible by construction, diffuse: the term itself
                 if (in) {
                     const float c = fminf(fmaxf(dot(pdir, s.n), 0.f), 1.f);
@@ -1424,28 +1430,27 @@ struct Anchor {
     float R;
     uint32_t node;
 };
-RPT_DEV void anchor_for(QueryK q, Anchor& anc, V c, float R, uint32_t* g_cnt) {
+RPT_DEV void anchor_for(QueryK q, Anchor& anc, V c, float R) {
     const V da = c - anc.c;
     if (!(anc.R > 0.f) || __builtin_sqrtf(dot(da, da)) + R > anc.R) {   // kept while the queries stay inside a ball twice as wide
         anc.c = c;
         anc.R = 2.f * R;
         anc.node = ball_anchor(q.s_nodes, q.n_s, c, anc.R * anc.R);
-        if (q.r.counters) g_cnt[9]++;
+        if (q.r.counters) diag_add(q.r.counters, 17, 1ull);
     }
 }
 // Once per pixel: collect and order the candidates of all its samples (prho2: how far, squared, this lane's surface points
 // lie from pix.c; prev_r2: the lane's last gather radius, squared).
-RPT_DEV void pixel_candidates(QueryK q, const GatherLds& l, const ShellBox& shell, PixelList& pix, Anchor& anc, float prev_r2, float prho2,
-                              uint32_t* g_cnt) {
+RPT_DEV void pixel_candidates(QueryK q, const GatherLds& l, const ShellBox& shell, PixelList& pix, Anchor& anc, float prev_r2, float prho2) {
     const float G = wave_max(prev_r2 > 0.f ? 2.f * prev_r2 : 0.f);
     const float rho_max2 = wave_max(prho2);
     if (!(G > 0.f && rho_max2 <= G)) return;
     pix.R = (__builtin_sqrtf(G) + __builtin_sqrtf(rho_max2)) * (1.f + 1e-5f);
-    anchor_for(q, anc, pix.c, pix.R, g_cnt);
+    anchor_for(q, anc, pix.c, pix.R);
     uint32_t steps = 0;
     pix.M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc.node, pix.c, pix.R * pix.R, l.pstack, reinterpret_cast<uint32_t*>(l.keys), l.cl,
                          q.coop_cap, steps, shell.on, shell.lo, shell.hi);
-    if (q.r.counters) { g_cnt[2] += steps; if (pix.M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += pix.M; }
+    if (q.r.counters) { diag_add(q.r.counters, 10, (unsigned long long)(steps)); if (pix.M == kCoopOverflow) diag_add(q.r.counters, 12, 1ull); else diag_add(q.r.counters, 11, (unsigned long long)(pix.M)); }
     if (pix.M != kCoopOverflow) {
         if (!(q.skip & 64u)) sort_candidates(l.cl, l.keys, pix.M, pix.c);   // (diagnostic: 64 = collection only)
         pix.valid = true;
@@ -1458,7 +1463,7 @@ RPT_DEV void pixel_candidates(QueryK q, const GatherLds& l, const ShellBox& shel
 // an edge, a radius was too small or there is no pixel list.  Lanes it cannot serve keep s.todo.
 template <bool BVH>
 RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
-                                 WalkScratch& ws, PixelList& pix, Anchor& anc, float prev_r2, uint32_t* g_cnt, unsigned long long* t_sec) {
+                                 WalkScratch& ws, PixelList& pix, Anchor& anc, float prev_r2) {
     const auto& a = q.r;
     const V x = s.x;
     float guess = prev_r2 > 0.f ? 2.f * prev_r2 : 0.f;
@@ -1466,7 +1471,7 @@ RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const Gather
         const float g = wave_max(s.todo ? guess : 0.f);
         if (!(guess > 0.f)) guess = g;
     }
-    if (a.counters && __ballot(s.todo) != 0ull) g_cnt[0]++;
+    if (a.counters && __ballot(s.todo) != 0ull) diag_add(q.r.counters, 8, 1ull);
     for (uint32_t round = pix.valid ? 0u : 1u; round < 7u; round++) {
         const uint64_t cm = __ballot(s.todo && guess > 0.f);
         if (cm == 0ull) break;
@@ -1492,11 +1497,11 @@ RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const Gather
             rho = __builtin_sqrtf(rho2);
             g_use = guess;
             const float R = wave_max(member ? __builtin_sqrtf(guess) + rho : 0.f) * (1.f + 1e-5f);
-            anchor_for(q, anc, xc, R, g_cnt);
+            anchor_for(q, anc, xc, R);
             uint32_t steps = 0;
             M = ball_collect(q.s_nodes, q.s_ph, q.n_s, anc.node, xc, R * R, l.pstack, reinterpret_cast<uint32_t*>(l.keys), l.cl, q.coop_cap, steps,
                              shell.on, shell.lo, shell.hi);
-            if (a.counters) { g_cnt[2] += steps; if (M == kCoopOverflow) g_cnt[4]++; else g_cnt[3] += M; }
+            if (a.counters) { diag_add(q.r.counters, 10, (unsigned long long)(steps)); if (M == kCoopOverflow) diag_add(q.r.counters, 12, 1ull); else diag_add(q.r.counters, 11, (unsigned long long)(M)); }
             if (M == kCoopOverflow) break;   // the lanes still to do search one by one
             if (q.skip & 64u) { if (member) { s.max_d2 = 0.5f * guess; s.todo = false; } continue; }   // diagnostic: collection only
             // ordered, like the pixel's list, by distance to the pixel's first surface point when there is one: the order
@@ -1507,7 +1512,7 @@ RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const Gather
             rho = __builtin_sqrtf(dot(dk, dk));
         }
         if (q.skip & 96u) { if (member) { s.max_d2 = 0.5f * guess; s.todo = false; } continue; }   // diagnostic: 32 / 64 = no selection
-        const bool ok = gather_serve<BVH>(q, sc_arg, l, shell, s, ws, member, g_use, rho, M, g_cnt, t_sec);
+        const bool ok = gather_serve<BVH>(q, sc_arg, l, shell, s, ws, member, g_use, rho, M);
         if (member && !ok) guess = fmaxf(guess, 4.f * g_use);   // too few photons inside: twice the radius next round
         __builtin_amdgcn_wave_barrier();
     }
@@ -1568,9 +1573,6 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
 
     uint32_t c0 = 0, c1 = 0;
     float prev_r2 = 0.f;  // squared radius of this lane's previous surface gather
-    unsigned long long c_leaf = 0, c_acc = 0, c_samp = 0;
-    uint32_t g_cnt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic (counters build), wave-level: see the end of the kernel
-    unsigned long long t_sec[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic: clock ticks of this wave per part of a pixel (counters build)
     auto tick = [&]() { return a.counters ? __builtin_amdgcn_s_memtime() : 0ull; };
     Anchor anc{mk(0, 0, 0), 0.f, 0u};   // wave-uniform: the surface gather's anchor (ball_anchor)
     // Work decomposition of the camera pass: a wave takes a strip of rows of one 8x8 pixel block and one chunk of up
@@ -1719,9 +1721,9 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         if (beam_lanes) {
             far2 = wave_max(far2);   // farthest hit of the pixel's samples (inf on a miss)
             near2 = wave_min(near2);  // nearest one
-            { const unsigned long long t1 = tick(); t_sec[0] += t1 - tk; tk = t1; }   // [0] first pass over the rays
-            beam_sum = beam_estimate_photon_lanes(q, cand, cand_n, far2, near2, xn, yn, cam_right, cam_up, sigma_t, n_s, rays, pend_list, c_leaf, c_acc);
-            { const unsigned long long t1 = tick(); t_sec[1] += t1 - tk; tk = t1; }   // [1] beam estimate
+            { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 0, t1 - tk); tk = t1; }   // [0] first pass over the rays
+            beam_sum = beam_estimate_photon_lanes(q, cand, cand_n, far2, near2, xn, yn, cam_right, cam_up, sigma_t, n_s, rays, pend_list);
+            { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 1, t1 - tk); tk = t1; }   // [1] beam estimate
             __builtin_amdgcn_wave_barrier();   // the gather lists of the surface estimate reuse this LDS
         }
         // ---- the surface gather's candidates, once for all the pixel's samples when their hit points form one cluster: every
@@ -1731,8 +1733,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         lds.cl = reinterpret_cast<F4*>(lds.keys + q.coop_cap);
         PixelList plist{false, pix_gather && have_xc, 0u, 0.f, pxc};
         const ShellBox shell = shell_box<BVH>();
-        if (plist.have_c && !(q.skip & 256u)) pixel_candidates(q, lds, shell, plist, anc, prev_r2, prho2, g_cnt);   // (diagnostic: 256 = no pixel list)
-        { const unsigned long long t1 = tick(); t_sec[2] += t1 - tk; tk = t1; }   // [2] the pixel's candidate list (+ the first pass when there is no beam estimate)
+        if (plist.have_c && !(q.skip & 256u)) pixel_candidates(q, lds, shell, plist, anc, prev_r2, prho2);   // (diagnostic: 256 = no pixel list)
+        { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 2, t1 - tk); tk = t1; }   // [2] the pixel's candidate list (+ the first pass when there is no beam estimate)
         // ---- the pixel's samples, 64 per trip; lane = sample
         V pixel_sum = mk(0, 0, 0);
         for (uint32_t sub = 0; sub < n_sub; sub++) {
@@ -1741,9 +1743,9 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         uint32_t code, inst;
         Rng rng;
         const bool active = gen_ray(sub, rng, ro, rd, tmin, t, code, inst);
-        { const unsigned long long t1 = tick(); t_sec[3] += t1 - tk; tk = t1; }   // [3] second pass over the rays
+        { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 3, t1 - tk); tk = t1; }   // [3] second pass over the rays
         const V wo = -normalize(rd);
-        if (active) c_samp++;
+        if (a.counters) diag_add(a.counters, 0, (unsigned long long)__popcll(__ballot(active)));
         const bool hit = code != CODE_MISS;
         V color = mk(0, 0, 0);
         bool surface_on = hit;
@@ -1771,7 +1773,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 }
             }
         } else if (MEDIUM && !(q.skip & 1u) && !beam_lanes) {  // beam estimates with the samples in the lanes
-            const V vc = volume_estimate_sample_lanes<KIND>(q, active, ro, rd, hit, t, sigma_t, sc.medium_phase, wstack, stage, c_leaf, c_acc);
+            const V vc = volume_estimate_sample_lanes<KIND>(q, active, ro, rd, hit, t, sigma_t, sc.medium_phase, wstack, stage);
             color = vc * mcol0;
         }
         if (active && !hit && !MEDIUM) color = env_color(sc_arg, rd);  // src/photon.rs:597
@@ -1786,16 +1788,16 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         }
         s.sc_col = mat_emit(s.mat) * mat_color(s.mat);
         WalkScratch ws{stk, c0, c1};
-        { const unsigned long long t1 = tick(); t_sec[4] += t1 - tk; tk = t1; }   // [4] volume estimate with the samples in the lanes, hit record, material
+        { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 4, t1 - tk); tk = t1; }   // [4] volume estimate with the samples in the lanes, hit record, material
         if (q.skip & 512u) { s.todo = false; s.max_d2 = 1.f; }   // (diagnostic: 512 = hit record and material only)
         if (!GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u)
-            surface_gather_wave<BVH>(q, sc_arg, lds, shell, s, ws, plist, anc, prev_r2, g_cnt, t_sec);
-        if (a.counters) { const uint64_t fm = __ballot(s.todo); if (fm) { g_cnt[10]++; g_cnt[11] += uint32_t(__popcll(fm)); } }
+            surface_gather_wave<BVH>(q, sc_arg, lds, shell, s, ws, plist, anc, prev_r2);
+        if (a.counters) { const uint64_t fm = __ballot(s.todo); if (fm) { diag_add(q.r.counters, 18, 1ull); diag_add(q.r.counters, 19, (unsigned long long)(uint32_t(__popcll(fm)))); } }
         if (__ballot(s.todo) != 0ull) plist.valid = false;   // (the index lists of these searches lie where the pixel's candidate list is)
         if (s.todo) surface_gather_lane<BVH>(q, sc_arg, lds, shell, s, ws, prev_r2);
         c0 = ws.c0;
         c1 = ws.c1;
-        { const unsigned long long t1 = tick(); t_sec[5] += t1 - tk; tk = t1; }   // [5] surface gather
+        { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 5, t1 - tk); tk = t1; }   // [5] surface gather
         V sc_col = s.sc_col;
         const float max_d2 = s.max_d2;
         if (surf) {
@@ -1816,20 +1818,13 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             sum.z += __shfl_xor(sum.z, off);
         }
         if (lane_ == 0) reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(sum.x, sum.y, sum.z, 0.f);
-        { const unsigned long long t1 = tick(); t_sec[6] += t1 - tk; tk = t1; }   // [6] the pixel's sum
+        { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 6, t1 - tk); tk = t1; }   // [6] the pixel's sum
     }
-    if (a.counters) {  // diagnostic: [0] camera samples, [5] photon spheres visited, [6] photon spheres accepted
-        atomicAdd(&a.counters[0], c_samp);
-        atomicAdd(&a.counters[5], c_leaf);
-        atomicAdd(&a.counters[6], c_acc);
-        // the wave-level surface gather: [8] trips with a gather, [9] photon terms without a visibility scan, [10] steps of the ball walks, [11] candidates,
-        // [12] overfull walks, [13] / [14] selection steps / list updates, [15] / [16] candidates looked at / photon terms of the
-        // second pass, [17] new anchors, [18] / [19] trips / lanes that searched one by one
-        if (lane_ == 0u)
-            for (int k = 0; k < 12; k++) atomicAdd(&a.counters[8 + k], (unsigned long long)g_cnt[k]);
-        if (lane_ == 0u)   // [24..]: clock ticks (100 MHz) per part, summed over the waves
-            for (int k = 0; k < 10; k++) atomicAdd(&a.counters[24 + k], t_sec[k]);
-    }
+    // Diagnostic counters (counters build; added where they occur, diag_add): [0] camera samples, [5] / [6] photon spheres visited /
+    // accepted; the wave-level surface gather: [8] trips with a gather, [9] photon terms without a visibility scan, [10] steps of
+    // the ball walks, [11] candidates, [12] overfull walks, [13] / [14] selection steps / list updates, [15] / [16] candidates looked
+    // at / photon terms of the second pass, [17] new anchors, [18] / [19] trips / lanes that searched one by one; [24..33] clock
+    // ticks (100 MHz) per part of a pixel, summed over the waves.
 }
 
 }  // namespace rptg
