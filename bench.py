@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C4|C5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C4|C5] [--no-secondary]
 
 One "step" = one pass of the hot path over the whole workload: Renderer::sample of the
 lampshade scene in fog (BASELINE config C3, examples/volumetric_pathtrace_lampshade.rs) at
 1024x1024 pixels x 256 paths per pixel, scene resident in HBM before the timed region.  With
-N > 1 the 32x32 pixel tiles are sharded over one rank per GPU and the frame is assembled on rank 0
-with one RCCL sum-reduce per step; the total work is fixed, so scaling is "strong".  `python bench.py
---gpus N` starts its N ranks itself (fresh children through torch.distributed.run, before this process
-has touched a GPU); under torch.distributed.run it is one of the ranks.  Rank 0 prints ONE JSON line.
+N > 1 the 32x32 pixel tiles are sharded over one rank per GPU and rank 0 assembles the frame from the owned tiles
+of every rank (rpt_gather_frame_device: packed f64 tiles over RCCL, behind the C ABI); the total work is fixed, so
+scaling is "strong".  `python bench.py --gpus N` starts its N ranks itself (fresh children through
+torch.distributed.run, before this process has touched a GPU); under torch.distributed.run it is one of the
+ranks.  Rank 0 prints ONE JSON line.
 
-Figures in the line:
+The headline (`value`, `config`, `roofline`, `cpu_baseline`) is C3.  At N = 1 the same line carries a `secondary`
+array with the other BASELINE configurations (C2 cornell 512x512x64, C4 beam x point photon map 1024x1024x256 with
+1 M photons, C5 100k-triangle mesh in fog 2048x2048x1024) at 2 steps each, every entry with its own value, ms_per_step,
+roofline, issue figures and cpu_baseline.
+
+Figures:
   value                 camera samples per second, whole job, frame resident in HBM at the end of a step
-  value_host_resident   the same with the frame on the host of rank 0 (SURVEY.md 8d's wall definition)
+  ms_per_step           pipelined: consecutive steps alternate between two HIP streams (an iterative render's batches)
+  wall_clock_s          one step alone: launch -> frame in HBM, strictly one stream, synchronised after every step
+  value_host_resident   pipelined steps with the frame copied to the host of rank 0 (SURVEY.md 8d's wall definition)
   roofline              bound "hbm": measured HBM bytes of the dominant kernel / its duration against 8 TB/s.
-                        The path is NOT HBM-bound (frac ~ 0.02); what binds it is fp32 VALU issue:
+                        The path is NOT HBM-bound (frac ~ 0.01); what binds it is fp32 VALU issue:
   valu_frac             algorithmic fp32 flops (SURVEY.md 8d's per-primitive counts on the reference's
                         structure x exact device counters) / kernel time / 157.3 TFLOP/s
   valu_issue_frac       wave-level VALU instructions issued / (SIMDs x clk/2 x kernel time), from the PMC profile
   active_lanes          mean fraction of the 64 lanes that are enabled in an issued VALU instruction (PMC), and
   path_lanes            fraction of lanes holding a live path vertex per loop trip (device counters of this run)
+A PMC profile is used only if it was taken from exactly the kernel sources in the tree (`_source_digest`).
 """
 import argparse
 import glob
@@ -101,10 +110,19 @@ def algorithmic_work(stats, n_objects, counters, samples):
     return total_bytes / samples, total_flops / samples, rays / samples
 
 
+def source_digest():
+    """Digest of the kernel sources the library in the tree was built from (the stamp __graft_entry__.build() keeps)."""
+    from __graft_entry__ import library_source_digest
+    return library_source_digest()
+
+
 def pmc_profile(workload, width, height, spp, world, photons=0):
     """The committed rocprofv3 PMC summary of the dominant kernel for exactly this configuration
     (profiles/rNN/pmc_<workload>.json, written by tools/pmc_passes.sh + tools/pmc_collect.py: separate --pmc passes,
-    per-launch sums), newest round first; (None, None) when this configuration was never profiled."""
+    per-launch sums), newest round first.  Returns (pmc, path, current): `current` says whether the profile was taken
+    from the very sources in the tree (its _source_digest); (None, None, False) when this configuration was never profiled."""
+    digest = source_digest()
+    stale = (None, None, False)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{workload}.json")), reverse=True):
         try:
             pmc = json.load(open(path))
@@ -115,38 +133,47 @@ def pmc_profile(workload, width, height, spp, world, photons=0):
             continue
         if photons and cfg.get("photons") != photons:
             continue
-        return pmc, os.path.relpath(path, ROOT)
-    return None, None
+        if pmc.get("_source_digest") == digest:
+            return pmc, os.path.relpath(path, ROOT), True
+        if stale[0] is None:
+            stale = (pmc, os.path.relpath(path, ROOT), False)
+    return stale
 
 
-def roofline_block(kernel, k_ms, k_ms_source, grid_blocks, pmc, pmc_path, compulsory_bytes, model_bytes, extra=None):
+def roofline_block(kernel, k_ms, k_ms_source, grid_blocks, pmc, pmc_path, pmc_current, compulsory_bytes, model_bytes, gather_type, extra=None):
     """The bench contract's roofline object for the dominant kernel, HBM view: achieved = HBM bytes per launch /
     launch duration.  Bytes are the measured ones (2 x FETCH_SIZE + WRITE_SIZE of the PMC profile of this very
-    configuration, MI355X_MICROARCH.md section HBM) when such a profile is committed, else the bytes the kernel
-    moves by design (partial-sum slab written + read back, frame written).  `compulsory_bytes` is what the
-    algorithm has to move (the fp32 RGB frame): traffic / compulsory is the waste factor."""
-    traffic, source = None, None
-    if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    configuration AND these very sources, MI355X_MICROARCH.md section HBM) when such a profile is committed, else the
+    bytes the kernel moves by design (partial-sum slab written + read back, frame written).  `traffic_x1` is
+    FETCH_SIZE + WRITE_SIZE: the guide's doubling of FETCH_SIZE is calibrated on wide coalesced streaming reads; for a
+    kernel whose reads are 64-byte node / record gathers (`gather_type`) the undoubled figure is the safer reading.
+    `compulsory_bytes` is what the algorithm has to move (the fp32 RGB frame)."""
+    traffic, traffic_x1, source = None, None, None
+    if pmc and pmc_current and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)   # rocprofv3 reports KB
-        source = f"{pmc_path}: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this configuration (not this run)"
+        traffic_x1 = int((pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
+        source = f"{pmc_path}: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this configuration and these sources (not this run)"
+    elif pmc:
+        source = f"none: {pmc_path} was taken from other kernel sources than the ones in the tree; `achieved` uses bytes_by_design"
     used = traffic if traffic is not None else model_bytes
     ach = used / (k_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-           "traffic": traffic, "traffic_source": source or "no PMC profile of this configuration: `achieved` uses bytes_by_design",
+           "traffic": traffic, "traffic_x1": traffic_x1, "gather_type_reads": bool(gather_type),
+           "traffic_source": source or "no PMC profile of this configuration: `achieved` uses bytes_by_design",
            "bytes_by_design": int(model_bytes), "compulsory_bytes": int(compulsory_bytes),
            "kernel": kernel, "kernel_ms": round(k_ms, 3), "kernel_ms_source": k_ms_source, "grid_blocks": grid_blocks,
            "note": "not HBM-bound: scene records are wave-uniform scalar-cache reads; the binding resource is fp32 VALU "
-                   "issue -- see the top-level valu_frac / valu_issue_frac / active_lanes"}
+                   "issue -- see valu_frac / valu_issue_frac / active_lanes beside this block"}
     if extra:
         out.update(extra)
     return out
 
 
-def issue_view(pmc, k_ms):
+def issue_view(pmc, current):
     """(valu_issue_frac, active_lanes, s_waitcnt share) from the PMC summary: VALU instructions issued against the
     chip's issue slots over the profiled launch (its own GRBM_GUI_ACTIVE cycles give the clock), enabled lanes
     per issued VALU instruction, share of wave cycles spent waiting in s_waitcnt."""
-    if not pmc or "SQ_INSTS_VALU" not in pmc or "GRBM_GUI_ACTIVE" not in pmc:
+    if not pmc or not current or "SQ_INSTS_VALU" not in pmc or "GRBM_GUI_ACTIVE" not in pmc:
         return None, None, None
     slots = N_SIMD * (pmc["GRBM_GUI_ACTIVE"] / N_XCD) / 2.0
     issue = pmc["SQ_INSTS_VALU"] / slots
@@ -181,10 +208,11 @@ def cpu_baseline(scene, cam, cfg, width, height, target_seconds=15.0):
     }
 
 
-def cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, watts, npix=4096):
+def cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, watts, npix=16384):
     """C4 on the CPU: the oracle shoots the same number of photons and builds the map once (the whole of
-    photon.rs:656-704), then runs the camera pass on a random pixel subset at 1 sample per pixel; the camera time
-    is scaled to the full frame and sample count (cost is linear in both)."""
+    photon.rs:656-704), then runs the camera pass on a random pixel subset at 1 sample per pixel.  `value` puts the two
+    together for the full frame (the camera time scaled: its cost is linear in pixels and samples) and says so; the
+    measured parts are given beside it."""
     import numpy as np
     from oracle.pyoracle import OracleScene
     threads = usable_cpus()
@@ -194,14 +222,19 @@ def cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, watts, n
     pix = np.sort(np.random.default_rng(0).choice(width * height, size=min(npix, width * height), replace=False)).astype(np.uint32)
     t0 = time.perf_counter()
     pm.render(cam, width, height, 1, seed=0, pixels=pix, threads=threads)
-    t_cam = (time.perf_counter() - t0) * (width * height / len(pix)) * spp
+    t_pix = time.perf_counter() - t0
+    t_cam = t_pix * (width * height / len(pix)) * spp
     return {
         "value": round(width * height * spp / (t_map + t_cam) / 1e6, 4),
         "unit": "Msamples/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{n_photons} photons shot + map built ({t_map:.1f} s) + camera pass on {len(pix)} random pixels x 1 spp scaled to "
-                  f"{width}x{height}x{spp} ({t_cam:.0f} s extrapolated); fp64 C++ restatement of src/photon.rs, {threads} threads",
+        "extrapolated": True,
+        "map_build_s": round(t_map, 2),
+        "camera_pass_Msamples_per_s": round(len(pix) / t_pix / 1e6, 4),
+        "sample": f"measured: {n_photons} photons shot + map built ({t_map:.1f} s) and the camera pass on {len(pix)} random pixels x 1 spp "
+                  f"({t_pix:.2f} s); `value` scales that camera time to {width}x{height}x{spp} ({t_cam:.0f} s) and adds the map build; "
+                  f"fp64 C++ restatement of src/photon.rs, {threads} threads",
     }
 
 
@@ -216,14 +249,295 @@ def parse_args(argv):
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--photons", type=int, default=0, help="C4 only: photons shot per step (default: the config's 1,000,000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="headline workload only (default at N = 1 with the default workload and "
+                                                               "size: C2, C4 and C5 follow at 2 steps each in `secondary`)")
     ap.add_argument("--streams", type=int, default=0, choices=(0, 1, 2),
                     help="HIP streams the consecutive steps alternate between (2, the default: the start of a step overlaps the tail "
                          "of the previous one, as consecutive batches of an iterative render do; 1: strictly one launch at a time)")
+    ap.add_argument("--exchange", default="gather", choices=("gather", "reduce"),
+                    help="N > 1: how rank 0 gets the frame -- gather of the owned tiles through the library's own RCCL communicator "
+                         "(rpt_gather_frame_device, default) or torch.distributed's sum-reduce of zero-padded full frames")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise torch.distributed (nccl) even with one rank, to rehearse the N > 1 code path")
+                    help="initialise torch.distributed (nccl) and the frame exchange even with one rank, to rehearse the N > 1 code path")
     ap.add_argument("--dryrun-cpu", action="store_true",
                     help="no GPU: rehearse launch, rendezvous (gloo), frame reduce and the JSON line with an all-zero frame")
     return ap.parse_args(argv)
+
+
+class Exchange:
+    """What a step does with its frame when the job has more than one rank (or --force-dist): assemble it on rank 0.
+    "gather": the library's communicator, every transfer enqueued on one exchange stream behind the step's render
+    (HIP events order render -> exchange -> next writer of that frame).  "reduce": torch.distributed's async sum-reduce."""
+
+    def __init__(self, torch, dist, mode, width, height, local_rank):
+        self.torch, self.dist, self.mode, self.w, self.h = torch, dist, mode, width, height
+        self.comm, self.stream = None, None
+        if mode == "gather":
+            from rpt_amd.dist import FrameComm
+            self.comm = FrameComm.from_torch(dist, local_rank)
+            self.stream = torch.cuda.Stream()
+
+    def issue(self, frame, on):
+        """Behind the render that `on` has just been given; returns what the next user of `frame` has to wait for."""
+        torch = self.torch
+        if self.mode == "gather":
+            ev = torch.cuda.Event()
+            ev.record(on)
+            self.stream.wait_event(ev)
+            self.comm.gather(self.w, self.h, frame.data_ptr(), frame.data_ptr(), self.stream.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            return done
+        with torch.cuda.stream(on):
+            return self.dist.reduce(frame, dst=0, op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def wait(self, handle, on):
+        """Make stream `on` wait for a handle of issue()."""
+        if handle is None:
+            return
+        if self.mode == "gather":
+            on.wait_event(handle)
+        else:
+            with self.torch.cuda.stream(on):
+                handle.wait()
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+
+
+def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local_rank, world, headline):
+    """Run one workload and return its fields of the JSON line (rank 0; None elsewhere)."""
+    import rpt_amd
+    from rpt_amd import Renderer, scenes
+    from rpt_amd.dist import photon_map_build_sharded
+
+    scene, cam, cfg = scenes.CONFIGS[workload]()
+    width = (args.width if headline else 0) or cfg["width"]
+    height = (args.height if headline else 0) or cfg["height"]
+    spp = (args.spp if headline else 0) or cfg["spp"]
+    rpt_amd.set_option("timing", 1)
+    rpt_amd.set_option("counters", 0)
+    r = Renderer(scene, cam).width(width).height(height).max_bounces(cfg["max_bounces"]).seed(0)
+    r.device(local_rank).shard(rank, world)
+    photon = "photons" in cfg   # C4: Renderer::photon_render = shoot + build the map + camera pass, every step
+    n_photons = 0
+    if photon:
+        n_photons = (args.photons if headline else 0) or cfg["photons"]
+        r.gather_size(cfg["gather_size"]).gather_size_volume(cfg["gather_size_volume"])
+        r.watts(cfg["renderer_watts"] / cfg["photons"] * n_photons)
+    # Two HIP streams used alternately -- what an iterative render does with consecutive batches: the first blocks
+    # of step k + 1 take over the CUs that the last paths of step k no longer fill (the library keeps a slab + work
+    # counter per stream).  The frames form a ring of THREE so that, with N > 1, step k + 2 does not write the frame whose
+    # exchange (issued behind step k, running beside step k + 1's persistent grid) may still be reading it.  Every frame
+    # carries the handle of whatever touched it last -- its render's event, or its exchange -- and its next writer
+    # (another stream) waits for that.
+    n_streams = 1 if photon else (streams_opt or 2)   # the photon map is built on the null stream
+    n_frames = 3
+    frames = [torch.zeros(width * height * 3, dtype=torch.float64, device="cuda") for _ in range(n_frames)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    xchg = Exchange(torch, dist, args.exchange, width, height, local_rank) if dist is not None else None
+    last_use = [None] * n_frames     # (kind, handle): "event" = torch.cuda.Event, "xchg" = Exchange handle
+    step_no = [0]
+
+    def stream_of(k):
+        return torch.cuda.default_stream() if (photon or n_streams == 1) else streams[k % 2]
+
+    def wait_frame(fi, on):
+        if last_use[fi] is None:
+            return
+        kind, h = last_use[fi]
+        if kind == "event":
+            on.wait_event(h)
+        else:
+            xchg.wait(h, on)
+
+    def step():
+        r._sample_offset = 0
+        k = step_no[0]
+        step_no[0] += 1
+        fi, on = k % n_frames, stream_of(k)
+        wait_frame(fi, on)   # the last reader / writer of this frame (another stream, or the exchange)
+        with torch.cuda.stream(on):
+            st = on.cuda_stream
+            if photon:
+                if dist is not None:   # shooting sharded by photon index, records all-gathered over RCCL
+                    photon_map_build_sharded(r, n_photons, Renderer.PHOTON_POINT_BEAM, rank, world)
+                else:
+                    r.photon_map_build(n_photons, Renderer.PHOTON_POINT_BEAM)
+                r.photon_sample_device(spp, frames[fi].data_ptr(), st)
+            else:
+                r.sample_device(spp, frames[fi].data_ptr(), st)
+        if xchg is not None:
+            last_use[fi] = ("xchg", xchg.issue(frames[fi], on))
+        else:
+            ev = torch.cuda.Event()
+            ev.record(on)
+            last_use[fi] = ("event", ev)
+        return fi, on
+
+    def drain():
+        for fi in range(n_frames):
+            if last_use[fi] is not None and last_use[fi][0] == "xchg" and args.exchange == "reduce":
+                last_use[fi][1].wait()
+        torch.cuda.synchronize()
+
+    # W untimed steps, and with two streams at least one on each: the scratch of a stream is allocated by its first launch
+    for _ in range(max(warmup, n_streams) if warmup else 0):
+        step()
+    drain()
+    if warmup:
+        r.timing_mean()   # start the kernel-time measurement at the timed region
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):   # nothing in a step waits for the device: the launches queue up behind each other
+        step()
+    drain()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    grid_blocks = r.timing()[2]
+    k_ms = r.timing_mean()[0]   # HIP events around every timed launch of the dominant kernel, on the stream it ran on
+    k_src = "HIP events around each launch of the timed region"
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- one step alone: strictly one stream, synchronised after every step (launch -> frame in HBM).  With two launches
+    # in flight the HIP events of one also span its wait for the other grid's CUs, so the kernel's own duration comes
+    # from these launches as well.
+    single_s = None
+    if n_streams == 2:
+        n1 = max(1, min(steps, 3))
+        saved, n_streams = n_streams, 1
+        ts = []
+        for _ in range(n1):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            drain()
+            ts.append(time.perf_counter() - t1)
+        n_streams = saved
+        single_s = sum(ts) / len(ts)
+        k_ms, k_src = r.timing_mean()[0], f"HIP events around {n1} launches that ran alone on one stream, after the timed region (its launches overlap on two)"
+    else:
+        single_s = elapsed / steps
+
+    # ---- the pipelined steps with the frame delivered to the host of rank 0 (SURVEY.md 8d: "kernel launch -> framebuffer
+    # resident on host"): one pinned 24 B/pixel fp64 copy per step, on the step's stream, behind its render and exchange
+    host_elapsed = None
+    if headline and (not photon or dist is None):
+        host_frame = torch.empty(width * height * 3, dtype=torch.float64, pin_memory=True) if rank == 0 else None
+        n_host = max(1, min(steps, 5))
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_host):
+            fi, on = step()
+            if rank == 0:
+                wait_frame(fi, on)   # the exchange of this frame (N > 1), else its own render: already in stream order
+                with torch.cuda.stream(on):
+                    host_frame.copy_(frames[fi], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(on)
+                last_use[fi] = ("event", ev)
+        drain()
+        if dist is not None:
+            dist.barrier()
+        host_elapsed = (time.perf_counter() - t0) / n_host
+        r.timing_mean()
+
+    samples_per_step = width * height * spp
+    ms_per_step = elapsed / steps * 1e3
+    value = samples_per_step * steps / elapsed / 1e6
+    local_samples = samples_per_step / world          # tiles are sharded evenly over ranks
+    n_owned_px = width * height / world
+    pmc, pmc_path, pmc_current = pmc_profile(workload, width, height, spp, world, n_photons)
+    issue, lanes, wait = issue_view(pmc, pmc_current)
+    compulsory = n_owned_px * 12.0   # fp32 RGB per owned pixel, written once (SURVEY.md 8d)
+    out = {
+        "value": round(value, 3),
+        "unit": "Msamples/s",
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "ms_per_step_is": "pipelined over two HIP streams" if n_streams == 2 else "one stream",
+        "wall_clock_s": round(single_s, 5),
+        "dtype": "f32",
+    }
+    if host_elapsed is not None:
+        out["value_host_resident"] = round(samples_per_step / host_elapsed / 1e6, 3)
+        out["ms_per_step_host_resident"] = round(host_elapsed * 1e3, 3)
+    parallelism = f"tile-shard x{world}" + (f", frame {args.exchange} on rank 0" if dist is not None else "")
+
+    # one extra, untimed pass with device counters on (rank-local work) for the algorithmic figures
+    r.scene.set_option("timing", 0)
+    r.scene.set_option("counters", 1)
+    r._sample_offset = 0
+    cspp = min(spp, 16)
+    if photon:
+        r.photon_sample_device(cspp, frames[0].data_ptr(), 0)
+    else:
+        r.sample_device(cspp, frames[0].data_ptr(), 0)
+    torch.cuda.synchronize()
+    cnt = r.counters()
+    if xchg is not None:
+        xchg.close()
+    if rank != 0:
+        return None
+
+    stats = r.scene_stats()
+    samples_c = max(cnt["samples"], 1)
+    if photon:
+        # slab: one float4 per (pixel, 64-sample chunk) written by the camera pass and read by the resolve; frame: 24 B/pixel
+        n_chunks = (spp + 63) // 64
+        model = n_owned_px * (32.0 * n_chunks + 24.0)
+        # algorithmic flops of the camera pass per sample: the camera ray against the reference's object list (as in
+        # algorithmic_work), 20 per (ray, photon sphere) pair the beam estimate tests + 25 more per accepted pair (kernel
+        # weight, transmittance), 40 per gathered surface photon (K = gather_size: cosine, bsdf, power, kernel) -- the
+        # visibility rays of the gathered photons (photon.rs:357-361) are NOT counted: the device proves most of them
+        # unnecessary, and counting them on the reference's structure would flatter the figure
+        cubes, tris = stats["cubes"] + stats["aabbs"], stats["tris"] + 2 * stats["rects"]
+        ray_flops = (56 + 25) * stats["spheres"] + (56 + 30) * cubes + 12 * stats["planes"] + 75 * tris
+        flops_ps = ray_flops + 300 + (20.0 * cnt["bvh_nodes"] + 25.0 * cnt["bvh_tris"]) / samples_c + 40.0 * cfg["gather_size"]
+        ach_tflops = flops_ps * local_samples / (k_ms * 1e-3) / 1e12
+        out["config"] = {"workload": f"{WORKLOAD_NAMES['C4']} {width}x{height}x{spp}spp, {n_photons} photons shot + map build + "
+                                     f"camera pass per step", "scene": SCENE_FILES["C4"], "parallelism": parallelism,
+                         "streams": n_streams, "camera_pass_kernel_ms": round(k_ms, 3),
+                         "beam_tests_per_sample": round(cnt["bvh_nodes"] / samples_c, 1),
+                         "beam_accepted_per_sample": round(cnt["bvh_tris"] / samples_c, 1)}
+        out["roofline"] = roofline_block("rptg::photon_query_kernel", k_ms, k_src, grid_blocks, pmc, pmc_path, pmc_current, compulsory, model, True)
+        out.update({"valu_frac": round(ach_tflops / FP32_PEAK_TFLOPS, 4), "valu_tflops": round(ach_tflops, 3),
+                    "valu_peak_tflops": FP32_PEAK_TFLOPS, "algorithmic_flops_per_sample": round(flops_ps, 1),
+                    "valu_frac_is": "camera pass only (the map build is ~10 % of a step): camera ray on the reference's object list + 20 per "
+                                    "tested and 25 per accepted (ray, photon) pair + 40 per gathered surface photon; visibility rays not counted",
+                    "valu_issue_frac": issue, "active_lanes": lanes, "s_waitcnt_share": wait, "pmc_source": pmc_path if pmc_current else None})
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, r.watts_)
+        return out
+
+    bytes_ps, flops_ps, rays_ps = algorithmic_work(stats, len(scene.objects), cnt, samples_c)
+    ach_tflops = flops_ps * local_samples / (k_ms * 1e-3) / 1e12
+    chunk_spp, n_chunks = r.chunking(spp)
+    model = n_owned_px * (32.0 * n_chunks + 24.0)   # slab written + read, fp64 frame written
+    out["config"] = {"workload": f"{WORKLOAD_NAMES[workload]} {width}x{height}x{spp}spp", "scene": SCENE_FILES[workload],
+                     "parallelism": parallelism, "streams": n_streams, "rays_per_sample": round(rays_ps, 3),
+                     "Mrays_per_s": round(value * rays_ps, 1), "chunk_spp": chunk_spp}
+    out["roofline"] = roofline_block("rptg::render_kernel", k_ms, k_src, grid_blocks, pmc, pmc_path, pmc_current, compulsory, model,
+                                     stats["bvh_nodes"] > 0, {"algorithmic_scene_bytes_per_sample": round(bytes_ps, 1)})
+    out.update({"valu_frac": round(ach_tflops / FP32_PEAK_TFLOPS, 4), "valu_tflops": round(ach_tflops, 3),
+                "valu_peak_tflops": FP32_PEAK_TFLOPS, "algorithmic_flops_per_sample": round(flops_ps, 1),
+                "valu_frac_is": "flops counted on the REFERENCE's structure (every object tested per ray); the device tests fewer, "
+                                "specialised records, so this flatters the kernel -- valu_issue_frac x active_lanes is the lane-slot utilisation",
+                "valu_issue_frac": issue, "active_lanes": lanes, "s_waitcnt_share": wait, "pmc_source": pmc_path if pmc_current else None,
+                "lane_slot_utilisation": None if issue is None or lanes is None else round(issue * lanes, 4),
+                "path_lanes": round(cnt["vertices"] / max(1, 64 * cnt["wave_trips"]), 4)})
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene, cam, cfg, width, height, 15.0 if headline else 8.0)
+        out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    return out
 
 
 def main(argv=None):
@@ -254,204 +568,24 @@ def main(argv=None):
         return dryrun_cpu(args, dist, rank, world)
     torch.cuda.set_device(local_rank)
 
-    import numpy as np
-    import rpt_amd
-    from rpt_amd import Renderer, scenes
-    from rpt_amd.dist import photon_map_build_sharded
-
-    scene, cam, cfg = scenes.CONFIGS[args.workload]()
-    width = args.width or cfg["width"]
-    height = args.height or cfg["height"]
-    spp = args.spp or cfg["spp"]
-    r = Renderer(scene, cam).width(width).height(height).max_bounces(cfg["max_bounces"]).seed(0)
-    r.device(local_rank).shard(rank, world)
-    # Two HIP streams used alternately -- what an iterative render does with consecutive batches: the first blocks
-    # of step k + 1 take over the CUs that the last paths of step k no longer fill (the library keeps a slab + work
-    # counter per stream) -- and, for N > 1, the sum-reduce of step k on RCCL's own stream.  The persistent grid of step
-    # k + 1 holds every CU slot until it drains, so the reduce of step k gets its workgroups only then, next to the first
-    # blocks of step k + 2: the frames form a ring of THREE, so that step k + 2 does not write the frame that reduce is
-    # still reading (with two, every step would wait for a reduce with the GPU otherwise idle).  Everything has completed
-    # before the closing synchronize + barrier of the timed region.
-    n_frames = 3
-    frames = [torch.zeros(width * height * 3, dtype=torch.float64, device="cuda") for _ in range(n_frames)]
-    if args.streams == 0:
-        args.streams = 2   # consecutive steps alternate between two streams: the start of one overlaps the tail of the other
-    streams = [torch.cuda.Stream() for _ in range(2)]
-    d_out = frames[0]
-    pending = [None] * n_frames
-    step_no = [0]
-    stream = torch.cuda.current_stream().cuda_stream
-    rpt_amd.set_option("timing", 1)
-
-    photon = "photons" in cfg   # C4: Renderer::photon_render = shoot + build the map + camera pass, every step
-    n_photons = 0
-    if photon:
-        n_photons = args.photons or cfg["photons"]
-        r.gather_size(cfg["gather_size"]).gather_size_volume(cfg["gather_size_volume"])
-        r.watts(cfg["renderer_watts"] / cfg["photons"] * n_photons)
-
-    def step():
-        r._sample_offset = 0
-        slot = step_no[0] % 2 if (args.streams == 2 and not photon) else 0   # the photon map is built on the null stream
-        fi = step_no[0] % n_frames
-        step_no[0] += 1
-        frame = frames[fi]
-        on = torch.cuda.default_stream() if (photon or args.streams == 1) else streams[slot]
-        with torch.cuda.stream(on):
-            st = on.cuda_stream
-            if pending[fi] is not None:   # the reduce that last used this frame must be done before it is overwritten
-                pending[fi].wait()
-                pending[fi] = None
-            if photon:
-                if dist is not None:   # shooting sharded by photon index, records all-gathered over RCCL
-                    photon_map_build_sharded(r, n_photons, Renderer.PHOTON_POINT_BEAM, rank, world)
-                else:
-                    r.photon_map_build(n_photons, Renderer.PHOTON_POINT_BEAM)
-                r.photon_sample_device(spp, frame.data_ptr(), st)
-            else:
-                r.sample_device(spp, frame.data_ptr(), st)
-            if dist is not None:
-                pending[fi] = dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM, async_op=True)
-
-    def drain():
-        for i in range(n_frames):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
-
-    # W untimed steps, and with two streams at least one on each: the scratch of a stream is allocated by its first launch
-    for _ in range(max(args.warmup, args.streams) if args.warmup else 0):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if args.warmup:
-        r.timing_mean()   # start the kernel-time measurement at the timed region
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):   # nothing in a step waits for the device: the launches queue up behind each other
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    grid_blocks = r.timing()[2]
-    k_ms = r.timing_mean()[0]   # HIP events around every timed launch of the dominant kernel, on the stream it ran on
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- the same steps with the frame delivered to the host of rank 0 ("kernel launch -> framebuffer
-    # resident on host"): one pinned 24 B/pixel fp64 copy per step behind the render (and the reduce)
-    host_elapsed = None
-    if not photon or dist is None:
-        host_frame = torch.empty(width * height * 3, dtype=torch.float64, pin_memory=True) if rank == 0 else None
-        n_host = max(1, min(args.steps, 5))
-        if dist is not None:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(n_host):
-            step()
-            drain()
-            if rank == 0:
-                slot = (step_no[0] - 1) % 2 if (args.streams == 2 and not photon) else 0
-                on = torch.cuda.default_stream() if (photon or args.streams == 1) else streams[slot]
-                with torch.cuda.stream(on):
-                    host_frame.copy_(frames[(step_no[0] - 1) % n_frames], non_blocking=True)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        host_elapsed = (time.perf_counter() - t0) / n_host
-        r.timing_mean()
-
-    samples_per_step = width * height * spp
-    ms_per_step = elapsed / args.steps * 1e3
-    value = samples_per_step * args.steps / elapsed / 1e6
-    local_samples = samples_per_step / world          # tiles are sharded evenly over ranks
-    n_owned_px = width * height / world
-    overlapped = args.streams == 2 and not photon
-    k_src = "HIP events around each launch"
-    if overlapped:
-        # two launches were in flight during the timed region: the events of one span its wait for the CUs the other
-        # still holds.  The kernel's own duration is measured on a few launches that follow each other on one stream
-        # (the host-resident pass above has already read, and thereby reset, the event ring).
-        for _ in range(3):
-            r._sample_offset = 0
-            r.sample_device(spp, frames[0].data_ptr(), stream)
-        torch.cuda.synchronize()
-        k_ms, k_src = r.timing_mean()[0], "HIP events around 3 launches on one stream, after the timed region (its launches overlap on two)"
-    pmc, pmc_path = pmc_profile(args.workload, width, height, spp, world, n_photons)
-    issue, lanes, wait = issue_view(pmc, k_ms)
-    compulsory = n_owned_px * 12.0   # fp32 RGB per owned pixel, written once
-    out = {
-        "metric": "Msamples/sec",
-        "value": round(value, 3),
-        "unit": "Msamples/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
-        "wall_clock_s": round(ms_per_step / 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-    }
-    if host_elapsed is not None:
-        out["value_host_resident"] = round(samples_per_step / host_elapsed / 1e6, 3)
-        out["ms_per_step_host_resident"] = round(host_elapsed * 1e3, 3)
-
-    if photon:
-        # slab: one float4 per (pixel, 64-sample chunk) written by the camera pass and read by the resolve; frame: 24 B/pixel
-        n_chunks = (spp + 63) // 64
-        model = n_owned_px * (32.0 * n_chunks + 24.0)
-        out["config"] = {"workload": f"{WORKLOAD_NAMES['C4']} {width}x{height}x{spp}spp, {n_photons} photons shot + map build + "
-                                     f"camera pass per step", "scene": SCENE_FILES["C4"], "parallelism": f"tile-shard x{world}",
-                         "streams": args.streams, "camera_pass_kernel_ms": round(k_ms, 3)}
-        out["roofline"] = roofline_block("rptg::photon_query_kernel", k_ms, k_src, grid_blocks, pmc, pmc_path, compulsory, model)
-        out.update({"valu_frac": None, "valu_issue_frac": issue, "active_lanes": lanes, "s_waitcnt_share": wait,
-                    "pmc_source": pmc_path})
-        if rank == 0:
-            if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, r.watts_)
-                out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
-            print(json.dumps(out), flush=True)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    # one extra, untimed pass with device counters on (rank-local work) for the roofline figures
-    rpt_amd.set_option("counters", 1)
-    rpt_amd.set_option("timing", 0)
-    r._sample_offset = 0
-    cspp = min(spp, 16)
-    r.sample_device(cspp, d_out.data_ptr(), stream)
-    torch.cuda.synchronize()
-    cnt = r.counters()
-    rpt_amd.set_option("counters", 0)
-
+    head = measure(args.workload, args, args.steps, args.warmup, args.streams, torch, dist, rank, local_rank, world, True)
+    out = None
     if rank == 0:
-        stats = r.scene_stats()
-        bytes_ps, flops_ps, rays_ps = algorithmic_work(stats, len(scene.objects), cnt, max(cnt["samples"], 1))
-        ach_tflops = flops_ps * local_samples / (k_ms * 1e-3) / 1e12
-        chunk_spp, n_chunks = r.chunking(spp)
-        model = n_owned_px * (32.0 * n_chunks + 24.0)   # slab written + read, fp64 frame written
-        out["config"] = {"workload": f"{WORKLOAD_NAMES[args.workload]} {width}x{height}x{spp}spp", "scene": SCENE_FILES[args.workload],
-                         "parallelism": f"tile-shard x{world}", "streams": args.streams, "rays_per_sample": round(rays_ps, 3),
-                         "Mrays_per_s": round(value * rays_ps, 1), "chunk_spp": chunk_spp}
-        out["roofline"] = roofline_block("rptg::render_kernel", k_ms, k_src, grid_blocks, pmc, pmc_path, compulsory, model,
-                                         {"algorithmic_scene_bytes_per_sample": round(bytes_ps, 1)})
-        out.update({"valu_frac": round(ach_tflops / FP32_PEAK_TFLOPS, 4), "valu_tflops": round(ach_tflops, 3),
-                    "valu_peak_tflops": FP32_PEAK_TFLOPS, "algorithmic_flops_per_sample": round(flops_ps, 1),
-                    "valu_issue_frac": issue, "active_lanes": lanes, "s_waitcnt_share": wait, "pmc_source": pmc_path,
-                    "path_lanes": round(cnt["vertices"] / max(1, 64 * cnt["wave_trips"]), 4)})
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cam, cfg, width, height)
-            out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        out = {"metric": "Msamples/sec", "value": head.pop("value"), "unit": head.pop("unit"), "n_gpus": world,
+               "steps": head.pop("steps"), "warmup": head.pop("warmup"), "ms_per_step": head.pop("ms_per_step"),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": head.pop("dtype"), "data": "synthetic"}
+        out.update(head)
+    default_run = args.workload == "C3" and not (args.width or args.height or args.spp)
+    if world == 1 and dist is None and default_run and not args.no_secondary:
+        secondary = []
+        for wl in ("C2", "C4", "C5"):
+            entry = measure(wl, args, 2, 1, 1, torch, None, rank, local_rank, world, False)
+            entry = dict({"workload": wl}, **entry)
+            secondary.append(entry)
+        out["secondary"] = secondary
+        out["secondary_note"] = ("the other BASELINE configurations at their configured sizes, 2 timed steps each after 1 warm-up, strictly one "
+                                 "stream (ms_per_step = wall_clock_s x 1000), same definitions as the headline")
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -167,6 +167,9 @@ int rpt_get_timing_mean(rpt_scene*, double* render_ms, double* resolve_ms, int32
  * `iterations` and the "chunk_spp" option): samples per work item and work items (= partial-sum slab entries of
  * 16 bytes) per pixel. */
 int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_chunks);
+/* The same for one scene: reads that scene's "chunk_spp" option (rpt_scene_set_option), i.e. exactly what its
+ * renders use; rpt_render_chunking reads the process defaults. */
+int rpt_scene_render_chunking(rpt_scene*, uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_chunks);
 /* Options.  Every scene has its own set: a copy of the process defaults taken by rpt_scene_create, changed with
  * rpt_scene_set_option (before rpt_scene_commit for the options the commit reads, at any time for the others; nothing
  * a commit or render reads is process-global, so scenes with different options may be driven from different host
@@ -251,6 +254,41 @@ int rpt_photon_render_sample(rpt_scene*, const rpt_camera*, const rpt_render_par
 int rpt_photon_render_sample_device(rpt_scene*, const rpt_camera*, const rpt_render_params*, uint64_t gather_size,
                                     uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed,
                                     uint32_t sample_offset, void* d_out_rgb, void* hip_stream);
+
+/* ---- frame exchange between the GPUs of one node (the loop being sharded is src/renderer.rs:158-171) ----
+ * One process per GPU renders the 32x32 tiles it owns (rpt_render_params.shard_rank / shard_count) into a full-size
+ * device frame; rank 0 assembles the image.  The exchange is a gather of the OWNED tiles over RCCL (xGMI), not a reduce
+ * of whole frames: rank r packs its tiles (rpt_shard_tiles order; 32 x 32 pixels x 3 f64 each, pixels of a clipped tile
+ * that lie outside the image are zero) and sends them to rank 0, which receives every rank's block in one ncclGroup and
+ * scatters it into its frame.  The payload stays f64 -- the frame's own type -- so the assembled frame is bit-identical
+ * to the one a single GPU renders (C5: 12.6 MB per rank instead of a 100 MB zero-padded frame per rank).
+ * RCCL is loaded at run time (dlopen of librccl.so.1, the copy already in the process if there is one): the library
+ * has no link-time dependency on it and single-GPU users never touch it. */
+typedef struct rpt_comm rpt_comm;
+#define RPT_COMM_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to the other ranks by any means (the launcher's store). */
+int rpt_comm_unique_id(void* id_out);
+/* ncclCommInitRank on `device` (collective over the n_ranks processes). */
+int rpt_comm_create(const void* id, int rank, int n_ranks, int device, rpt_comm** out);
+void rpt_comm_destroy(rpt_comm*);
+int rpt_comm_rank(const rpt_comm*, int* rank, int* n_ranks);
+/* Collective.  d_shard: this rank's frame (width*height*3 f64 on its device, as written by rpt_render_sample_device
+ * with shard_rank = the communicator's rank); d_frame: on rank 0 the assembled frame (may be d_shard itself: the
+ * received tiles are then written in place), ignored on the other ranks.  Everything is enqueued on hip_stream.
+ * flags: RPT_GATHER_LOOPBACK makes rank 0 send its own tiles to itself through RCCL as well (self-test of the
+ * transport with one rank; needs d_frame != d_shard to be observable). */
+#define RPT_GATHER_LOOPBACK 1u
+int rpt_gather_frame_device(rpt_comm*, uint32_t width, uint32_t height, const void* d_shard, void* d_frame,
+                            uint32_t flags, void* hip_stream);
+/* The packed layout (pure host function): tile_offsets[r] = first tile of rank r's block in the gathered buffer,
+ * r = 0..n_ranks (tile_offsets[n_ranks] = tiles of the whole frame); a tile is 32*32*3 f64. */
+int rpt_frame_pack_layout(uint32_t width, uint32_t height, uint32_t n_ranks, uint64_t* tile_offsets);
+/* Pack / unpack on one device without any transport (what the exchange does on either side; test hooks):
+ * d_packed holds rpt_shard_tiles(rank).count * 3072 f64. */
+int rpt_frame_pack_device(uint32_t width, uint32_t height, uint32_t rank, uint32_t n_ranks, const void* d_frame,
+                          void* d_packed, void* hip_stream);
+int rpt_frame_unpack_device(uint32_t width, uint32_t height, uint32_t rank, uint32_t n_ranks, const void* d_packed,
+                            void* d_frame, void* hip_stream);
 
 /* ---- device self-test hooks (each runs the device function in a one-block kernel) ---- */
 int rpt_debug_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out);

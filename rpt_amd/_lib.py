@@ -94,6 +94,7 @@ SYMBOLS = [
     ("rpt_get_timing", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("rpt_get_timing_mean", C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("rpt_render_chunking", C.c_int, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("rpt_scene_render_chunking", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("rpt_set_option", C.c_int, [C.c_char_p, C.c_int64]),
     ("rpt_scene_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("rpt_buffer_create", _P, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -116,6 +117,14 @@ SYMBOLS = [
      [_P, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, _P]),
     ("rpt_photon_render_sample_device", C.c_int,
      [_P, C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, _P, _P]),
+    ("rpt_comm_unique_id", C.c_int, [_P]),
+    ("rpt_comm_create", C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("rpt_comm_destroy", None, [_P]),
+    ("rpt_comm_rank", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("rpt_gather_frame_device", C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, _P]),
+    ("rpt_frame_pack_layout", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("rpt_frame_pack_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    ("rpt_frame_unpack_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
     ("rpt_debug_rng_u32", C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("rpt_debug_material_sample_f", C.c_int,
      [C.POINTER(MaterialDesc), C.c_uint64, _P, _P, C.c_uint64, _P, _P, _P]),

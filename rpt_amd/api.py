@@ -801,11 +801,11 @@ class Renderer:
         _lib.check(_lib.load().rpt_get_timing_mean(self.scene._handle, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
 
-    @staticmethod
-    def chunking(iterations):
-        """(samples per work item, work items per pixel) of a sample(iterations) call (rpt_render_chunking)."""
+    def chunking(self, iterations):
+        """(samples per work item, work items per pixel) of this renderer's sample(iterations) calls: the scene's own
+        "chunk_spp" option applies (rpt_scene_render_chunking), as in its renders."""
         c, n = C.c_uint32(), C.c_uint32()
-        _lib.check(_lib.load().rpt_render_chunking(int(iterations), C.byref(c), C.byref(n)))
+        _lib.check(_lib.load().rpt_scene_render_chunking(self.scene._commit(self.device_), int(iterations), C.byref(c), C.byref(n)))
         return int(c.value), int(n.value)
 
     def scene_stats(self):

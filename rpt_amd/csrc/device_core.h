@@ -557,12 +557,12 @@ RPT_DEV bool mesh_roots_hit(const SceneView& scene_, V o, V d, float tmin, float
 }
 template <bool COUNT, bool ANY>
 RPT_DEV void walk_meshes(const SceneView& scene_, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst,
-                         uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris, AnyHit any) {
+                         uint32_t* stk, uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris, AnyHit any, uint32_t cap = 32u) {
     const auto& sc = *kernarg_scene();   // (see kernarg_scene)
     for (uint32_t i = 0; i < sc.n_mesh; i++) {
         const MeshRef m = uload(&sc.meshes[i]);
         if (ANY && code != CODE_MISS && any.blocks(tbest, code)) break;  // (per lane) already occluded
-        bvh_traverse<COUNT, false, ANY>(scene_, m.root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
+        bvh_traverse<COUNT, false, ANY>(scene_, m.root, o, d, tmin, tbest, code, inst, stk, stride, cap, c_nodes, c_tris, any);
     }
 }
 // The same walk as a resumable one (deferred walks of the render kernel): the lane's position -- current entry,

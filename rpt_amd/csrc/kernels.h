@@ -29,6 +29,8 @@ struct RenderArgs {
     uint32_t defer_lanes;     // per-mesh-tree kernels: parked tree walks per wave that trigger a walk (1..64)
     uint32_t defer_stop;      // ... and the number of still-walking lanes below which the wave leaves the walk
     uint32_t walk_leaf_quarters;  // ... and the descent of a walk pauses for the leaves when 4 x (lanes at a leaf) >= this x (lanes descending); 0: never
+    uint32_t detach;              // per-mesh-tree kernels in a medium: shadow queries that need a tree walk leave their path (wave queue in LDS)
+    uint32_t detach_trigger;      // ... and a walk session is due as soon as the queue holds this many (1..32)
 };
 
 // The device functions read the scene view at kernarg + 0 (kernarg_scene in device_core.h): every kernel that calls them
@@ -41,7 +43,7 @@ struct KernelInfo {
 
 // Persistent megakernel: grid = n_blocks x 256 threads.
 hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream);
-hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu);  // bvh: bvh_mode()
+hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu, bool detach = false);  // bvh: bvh_mode()
 int bvh_mode(const SceneView& sc);  // 0 no tree, 1 per-mesh trees, 2 scene-level tree
 // out[pixel] = sum_chunks slab / iterations * scale for owned pixels (others untouched).
 hipError_t launch_buffer_add(uint32_t n_pixels, const double* d_batch, double* d_sum, double* d_sumsq, hipStream_t st);
@@ -50,6 +52,11 @@ hipError_t launch_buffer_image(uint32_t w, uint32_t h, uint32_t radius, uint32_t
 hipError_t launch_buffer_variance(uint32_t n_pixels, uint32_t n_batches, const double* d_sum, const double* d_sumsq, double* d_out,
                                   hipStream_t st);
 hipError_t launch_resolve(const RenderArgs& a, double scale, double* d_out, hipStream_t stream);
+// Frame exchange: owned tiles <-> packed blocks of 32 x 32 x 3 f64 (tile list on the device).
+hipError_t launch_frame_pack(const double* d_frame, double* d_packed, const uint32_t* d_tiles, uint32_t n_tiles, uint32_t tiles_x,
+                             uint32_t width, uint32_t height, hipStream_t st);
+hipError_t launch_frame_unpack(const double* d_packed, double* d_frame, const uint32_t* d_tiles, uint32_t n_tiles, uint32_t tiles_x,
+                               uint32_t width, uint32_t height, hipStream_t st);
 hipError_t launch_intersect(const SceneView& sc, uint64_t n, const float* d_o, const float* d_d, float* d_t,
                             int32_t* d_obj, float* d_n, bool bvh, hipStream_t stream);
 hipError_t launch_debug_rng(uint64_t seed_mixed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* d_out,

@@ -62,6 +62,32 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 #define RPT_MIN_WAVES_SCAN_MEDIUM 5  // ... in a medium.  6 (80 VGPRs) renders C3 in 25.3 instead of 26.0 ms but spills 84 B/lane, a scratch
                                      // footprint just over the XCD's L2: 32 GB of HBM writes per launch instead of 1.1 -- not taken
 #endif
+// LDS of the per-mesh-tree kernel with detached shadow queries (render_kernel<true, 1, *, false, true>), in dwords per block
+// of 256 lanes: [stack rows][5 state rows][staged tables][pend: 256][acc: 3 x 256 u64][4 wave queues].  40,320 B: four
+// blocks per CU fit the 160 KB.
+static constexpr uint32_t kDetachStackRows = 20u;   // a mesh tree is at most 20 levels deep: it pushes at most 19 entries
+static constexpr uint32_t kQCap = 32u;              // detached shadow queries a wave can hold
+static constexpr uint32_t kQFields = 11u;           // origin, direction, end of the interval, contribution if visible, owner lane
+static constexpr uint32_t kQWaveDwords = 8u + kQFields * kQCap;   // [0]: slots in use, [1]: slots being walked (bit masks); fields from [8], field-major
+static_assert(kQCap == 32u, "one mask bit per slot");
+static constexpr uint32_t kTabDwords = (2u * 32u + 6u * 8u) * 4u;   // LdsTables: 32 materials + 8 light triangles
+static constexpr uint32_t kDetachPendBase = (kDetachStackRows + 5u) * 256u + kTabDwords;
+static constexpr uint32_t kDetachAccBase = kDetachPendBase + 256u;
+static constexpr uint32_t kDetachQBase = kDetachAccBase + 3u * 256u * 2u;
+static constexpr uint32_t kDetachDwords = kDetachQBase + 4u * kQWaveDwords;
+static_assert(kDetachAccBase % 2u == 0u, "the 64-bit accumulators are 8-byte aligned");
+static_assert(kDetachDwords * 4u * 4u <= 160u * 1024u, "four blocks per CU");
+// Radiance -> unsigned 32.32 fixed point (negative values and NaN -> 0, values from 2^32 up saturate).  Sums of such
+// numbers do not depend on the order of the additions: that is what lets a detached shadow query add its term to
+// its pixel whenever its walk happens to run.
+RPT_DEV unsigned long long to_fixed(float v) {
+    v = fminf(fmaxf(v, 0.f), 4294967040.f);
+    const uint32_t hi = uint32_t(v);
+    const uint32_t lo = uint32_t((v - float(hi)) * 4294967296.f);   // exact: the fraction has at most 24 bits
+    return ((unsigned long long)hi << 32) | lo;
+}
+RPT_DEV float from_fixed(unsigned long long x) { return float(double(x) * 0x1p-32); }
+
 // Diagnostic sections of the megakernel (COUNT build): per section, counters[8 + 2k] counts wave-level
 // executions and counters[9 + 2k] the lanes active in them (lane utilisation of divergent code).
 // -DRPT_MARKERS additionally drops "; SECT k" comments into the ISA for static instruction counts.
@@ -168,9 +194,11 @@ RPT_DEV bool stage_bounce(const RenderArgs& a, float albedo_med, V rd, uint32_t 
 
 // GROUPS: some Light::Object is a KdTree group (per-lane leaf sampler).  A separate instantiation: the extra
 // sampler copy costs the plain kernels 6 % through register allocation alone, and a call costs 6x.
-template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false>
+// DETACH (per-mesh-tree kernels in a medium): shadow queries that need a tree walk leave their path (see the loop body).
+template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false, bool DETACH = false>
 __global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : BVH == 1 ? RPT_MIN_WAVES_MESH : RPT_MIN_WAVES)
 void render_kernel(const RenderArgs a) {
+    static_assert(!DETACH || (MEDIUM && BVH == 1 && !GROUPS), "detached shadow queries: per-mesh-tree kernels in a medium only");
     extern __shared__ uint32_t dyn_lds[];
     const SceneView& sc = a.sc;
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
@@ -191,12 +219,13 @@ void render_kernel(const RenderArgs a) {
     // The tree-walking instantiations (128 VGPRs, 32 KB of LDS stack per block) park only the five values that
     // are read once per sample: 4 blocks x (32 + 5) KB still fit the CU's 160 KB.
     // rows of the traversal stack: scene tree + mesh tree need up to 32; a mesh tree alone is at most 20 levels deep
-    constexpr uint32_t kStackRows = BVH == 1 ? 21u : 32u;
+    constexpr uint32_t kStackRows = BVH == 1 ? (DETACH ? kDetachStackRows : 21u) : 32u;
     constexpr uint32_t kStateBase = BVH ? kStackRows * 256u : 0u;  // dwords: after the traversal stack
     uint32_t* const ls = dyn_lds + kStateBase + threadIdx.x;  // [slots][256] dwords, one column per lane
-    enum { S_SLAB = 0, S_END = 1, S_PIX = 2, S_XN = 3, S_YN = 4, S_S = 5, S_ACC = 6, S_P = 9, S_Q = 12, S_RC = 15, S_MAT = 18, S_N = 24 };
+    enum { S_SLAB = 0, S_END = 1, S_PIX = 2, S_XN = 3, S_YN = 4, S_S = 5, S_ACC = 6, S_P = 9, S_Q = 12, S_RC = 15, S_ROWS = 18 };
+    static_assert(S_RC + 3 == S_ROWS, "the staged tables begin right behind the state rows");
     // Material and light-triangle tables of small scenes, staged once per block behind the lane state
-    constexpr uint32_t kTabBase = kStateBase + (BVH == 0 ? 18u : 5u) * 256u;   // dwords
+    constexpr uint32_t kTabBase = kStateBase + (BVH == 0 ? uint32_t(S_ROWS) : 5u) * 256u;   // dwords
     LdsTables tab;
     {
         const F4* const t4 = reinterpret_cast<const F4*>(dyn_lds + kTabBase);
@@ -216,11 +245,26 @@ void render_kernel(const RenderArgs a) {
     auto ldf = [&](int k, float reg) { return in_lds(k) ? __uint_as_float(ls[k * 256]) : reg; };
     auto stu = [&](int k, uint32_t& reg, uint32_t v) { if (in_lds(k)) ls[k * 256] = v; else reg = v; };
     auto stf = [&](int k, float& reg, float v) { if (in_lds(k)) ls[k * 256] = __float_as_uint(v); else reg = v; };
+    // DETACH: the item's sum is kept in fixed point in LDS (acc64[channel][lane]) where other lanes of the wave can add to
+    // it; pend = detached shadow queries of the lane's item that are still in the wave's queue
+    volatile uint32_t* const ls_pend = dyn_lds + (DETACH ? kDetachPendBase : 0u);                      // [256]
+    unsigned long long* const acc64 = reinterpret_cast<unsigned long long*>(dyn_lds + (DETACH ? kDetachAccBase : 0u));   // [3][256]
+    volatile uint32_t* const wq = dyn_lds + (DETACH ? kDetachQBase + (threadIdx.x >> 6) * kQWaveDwords : 0u);   // this wave's queue
     auto acc_add = [&](V v) {
-        stf(S_ACC + 0, acc_r.x, ldf(S_ACC + 0, acc_r.x) + v.x);
-        stf(S_ACC + 1, acc_r.y, ldf(S_ACC + 1, acc_r.y) + v.y);
-        stf(S_ACC + 2, acc_r.z, ldf(S_ACC + 2, acc_r.z) + v.z);
+        if constexpr (DETACH) {
+            atomicAdd(&acc64[threadIdx.x], to_fixed(v.x));
+            atomicAdd(&acc64[256u + threadIdx.x], to_fixed(v.y));
+            atomicAdd(&acc64[512u + threadIdx.x], to_fixed(v.z));
+        } else {
+            stf(S_ACC + 0, acc_r.x, ldf(S_ACC + 0, acc_r.x) + v.x);
+            stf(S_ACC + 1, acc_r.y, ldf(S_ACC + 1, acc_r.y) + v.y);
+            stf(S_ACC + 2, acc_r.z, ldf(S_ACC + 2, acc_r.z) + v.z);
+        }
     };
+    if constexpr (DETACH) {
+        if ((threadIdx.x & 63u) == 0u) { wq[0] = 0u; wq[1] = 0u; }
+        ls_pend[threadIdx.x] = 0u;
+    }
     // The radiance carrier (P, Q, Rc) is read and written once per vertex: in the scan instantiations it lives in LDS
     // as well, which takes 6 (9 without a medium) long-lived values out of the 96-VGPR budget.
     auto ldv = [&](int k, V reg) { return BVH == 0 ? mk(__uint_as_float(ls[k * 256]), __uint_as_float(ls[(k + 1) * 256]), __uint_as_float(ls[(k + 2) * 256])) : reg; };
@@ -252,6 +296,9 @@ void render_kernel(const RenderArgs a) {
     Mat v_mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
     bool v_medium = false;
     WalkState walk{kWalkDone, 0u, 0u};
+    uint32_t fuse = 0u;   // (DETACH) trips of this wave
+    constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
+    uint32_t h_e = kNoEntry;   // (DETACH) queue entry whose unfinished walk this lane holds
 
     for (;;) {
         // ---- work distribution (wave-convergent).  A wave draws batches of 64 items from the global
@@ -259,12 +306,20 @@ void render_kernel(const RenderArgs a) {
         // item through a ballot/mbcnt prefix; the batch cursor lives in wave-uniform registers.
         // (One atomic per lane-pull saturated the counter at ~80 M dequeues/s: profiles/r01.)
         bool want = alive && need_path && item_done;
+        // DETACH: an item is written out once the last of its detached shadow queries has been answered
+        if constexpr (DETACH) want = want && (!have_item || ls_pend[threadIdx.x] == 0u);
         if (__any(want)) {
             const auto& ka = *kernarg_args<RenderArgs>();   // item bookkeeping reads its arguments here, not from registers held since kernel entry
             SECT(0);
             if (want && have_item) {
-                reinterpret_cast<float4*>(ka.slab)[ldu(S_SLAB, slab_idx_r)] =
-                    make_float4(ldf(S_ACC + 0, acc_r.x), ldf(S_ACC + 1, acc_r.y), ldf(S_ACC + 2, acc_r.z), 0.f);
+                if constexpr (DETACH) {
+                    const volatile unsigned long long* av = acc64;
+                    reinterpret_cast<float4*>(ka.slab)[ldu(S_SLAB, slab_idx_r)] =
+                        make_float4(from_fixed(av[threadIdx.x]), from_fixed(av[256u + threadIdx.x]), from_fixed(av[512u + threadIdx.x]), 0.f);
+                } else {
+                    reinterpret_cast<float4*>(ka.slab)[ldu(S_SLAB, slab_idx_r)] =
+                        make_float4(ldf(S_ACC + 0, acc_r.x), ldf(S_ACC + 1, acc_r.y), ldf(S_ACC + 2, acc_r.z), 0.f);
+                }
                 have_item = false;
             }
             for (;;) {
@@ -317,9 +372,14 @@ void render_kernel(const RenderArgs a) {
                         have_item = true;
                         item_done = false;
                         stu(S_SLAB, slab_idx_r, item);
-                        stf(S_ACC + 0, acc_r.x, 0.f);
-                        stf(S_ACC + 1, acc_r.y, 0.f);
-                        stf(S_ACC + 2, acc_r.z, 0.f);
+                        if constexpr (DETACH) {
+                            volatile unsigned long long* av = acc64;
+                            av[threadIdx.x] = 0ull; av[256u + threadIdx.x] = 0ull; av[512u + threadIdx.x] = 0ull;
+                        } else {
+                            stf(S_ACC + 0, acc_r.x, 0.f);
+                            stf(S_ACC + 1, acc_r.y, 0.f);
+                            stf(S_ACC + 2, acc_r.z, 0.f);
+                        }
                         const uint32_t s0 = chunk * ka.chunk_spp;
                         stu(S_S, s_r, s0);
                         stu(S_END, s_end_r, min(s0 + ka.chunk_spp, ka.iterations));
@@ -331,7 +391,7 @@ void render_kernel(const RenderArgs a) {
                 }
             }
         }
-        if (need_path && alive) {
+        if (need_path && alive && !(DETACH && item_done)) {   // (DETACH: a lane whose finished item still waits for shadow answers has no sample to start)
             if (alive) {  // src/renderer.rs:179-181
                 const auto& ka = *kernarg_args<RenderArgs>();
                 SECT(1);
@@ -359,6 +419,289 @@ void render_kernel(const RenderArgs a) {
         }
         if (!__any(alive)) break;
         if (COUNT && (threadIdx.x & 63u) == 0) c_trips++;
+        if constexpr (DETACH) {
+            // ---- per-mesh-tree flavour in a medium, shadow queries detached.  A primary query that has to walk a tree
+            // parks its lane as below (PH_WAITP).  A shadow query that has to walk leaves its path instead: in a medium
+            // the radiance of a path is linear in every light term (no firefly clamp, src/renderer.rs:229-232), so the
+            // term enters the pixel's sum as Q x term if the light is visible, whenever that becomes known, and the path
+            // goes on at once.  The query (ray, interval, contribution, owner lane) waits in a queue of this wave in LDS;
+            // in a walk session the lanes with a parked primary query walk their own and every other lane of the wave
+            // takes a queued shadow query, so a session starts with up to 64 walks and refills lanes from the queue as
+            // they finish.  The item's sum is kept in fixed point: it does not depend on when the terms arrive, so the
+            // image is still bit-identical for every schedule.
+            // ---- A: a new path vertex: distance sample, scan, do the trees matter?
+            if (alive && !need_path && phase == PH_NEW) {
+                if (COUNT) c_vertices++;
+                SECT(2);
+                stage_distance<MEDIUM>(rng, inv_sigma_t, v_dmed, q_t);
+                const float tmin = ray_tmin(ro);
+                q_code = CODE_MISS;
+                scan_prims(sc, ro, rd, tmin, q_t, q_code);
+                if (COUNT) c_rays++;
+                phase = mesh_roots_hit(sc, ro, rd, tmin, q_t) ? PH_WAITP : PH_HAVEP;
+                if (h_e == kNoEntry) walk = walk_begin(sc);   // (else `walk` is the entry's walk; this query begins at the root when that one is through)
+            }
+            // ---- B, L, C: event, next-event estimation, continue or end -- in one go, nothing waits in between
+            if (alive && phase == PH_HAVEP) {
+                SECT(3);
+                const bool hit = q_code != CODE_MISS;
+                const bool ev_medium = v_dmed < (hit ? q_t : 400.f);
+                phase = PH_NEW;
+                if (!ev_medium && !hit) {
+                    SECT(4);
+                    acc_add(fma3(Q, env_color(sc, rd), P));
+                    need_path = true;
+                } else {
+                    V x, n = mk(0, 1, 0), mcol = mk(0, 0, 0), E;
+                    Mat mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
+                    stage_event<COUNT>(a, tab, ro, rd, depth, ev_medium, v_dmed, q_t, q_code, 0u, x, n, mcol, mat, E);
+                    for (uint32_t li = 0; li < sc.n_lights; li++) {
+                        const Light L = uload(&sc.lights[li]);
+                        if (L.kind == L_AMBIENT) {
+                            E = fma3(xyz(L.color), ev_medium ? mcol : mat_color(mat), E);
+                        } else if (L.kind == L_OBJECT) {
+                            V I, wi;
+                            float dist;
+                            SECT(7);
+                            illuminate_object<false>(sc, L, x, rng, I, wi, dist, tab);
+                            if (L.twin_object >= 0) {
+                                SECT(8);
+                                const float tm = ray_tmin(x);
+                                float ts = dist * (1.f + 1e-3f);
+                                uint32_t cs = CODE_MISS;
+                                scan_prims(sc, x, wi, tm, ts, cs);
+                                if (COUNT) c_rays++;
+                                // the light's twin lies among the scanned records (the host selects this kernel only then): the
+                                // light can be visible only if the scan's closest hit is the twin at the sampled distance, and
+                                // then it is visible unless a tree holds a triangle in front of that hit
+                                const bool twin = (L.twin_lo <= L.twin_hi) ? (cs >= L.twin_lo && cs <= L.twin_hi)
+                                                                           : (cs != CODE_MISS && code_object(sc, cs, 0u) == uint32_t(L.twin_object));
+                                if (cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) && twin) {
+                                    SECT(9);
+                                    V T;
+                                    if (ev_medium) {
+                                        T = (albedo_med * sc.medium_phase) * (I * mcol);
+                                    } else {
+                                        const V f = bsdf(mat, n, -normalize(rd), wi);
+                                        T = dot(wi, n) * (f * I);
+                                    }
+                                    if (!mesh_roots_hit(sc, x, wi, tm, ts)) {
+                                        E = E + T;
+                                    } else {
+                                        SECT(21);
+                                        const V cand = Q * T;
+                                        const uint64_t m = __ballot(true);   // the lanes that detach a query now
+                                        uint32_t fr = ~wq[0];                // free slots (every lane reads before any lane claims)
+                                        for (uint32_t i = mbcnt64(m); i != 0u; i--) fr &= fr - 1u;   // ... this lane's: the rank-th of them
+                                        if (fr != 0u) {
+                                            const uint32_t e = uint32_t(__builtin_ctz(fr));
+                                            volatile uint32_t* const q = wq + 8u + e;
+                                            q[0u * kQCap] = __float_as_uint(x.x); q[1u * kQCap] = __float_as_uint(x.y); q[2u * kQCap] = __float_as_uint(x.z);
+                                            q[3u * kQCap] = __float_as_uint(wi.x); q[4u * kQCap] = __float_as_uint(wi.y); q[5u * kQCap] = __float_as_uint(wi.z);
+                                            q[6u * kQCap] = __float_as_uint(ts);
+                                            q[7u * kQCap] = __float_as_uint(cand.x); q[8u * kQCap] = __float_as_uint(cand.y); q[9u * kQCap] = __float_as_uint(cand.z);
+                                            q[10u * kQCap] = threadIdx.x;
+                                            atomicOr(const_cast<uint32_t*>(wq), 1u << e);
+                                            ls_pend[threadIdx.x] = ls_pend[threadIdx.x] + 1u;
+                                        } else {   // every slot is taken (a session is due as soon as detach_trigger entries wait): walk here
+                                            SECT(22);
+                                            if (h_e != kNoEntry) {   // this lane's stack column holds a suspended shadow walk: that one starts again later, from the root
+                                                atomicAnd(const_cast<uint32_t*>(wq) + 1, ~(1u << h_e));
+                                                h_e = kNoEntry;
+                                            }
+                                            uint32_t cw = CODE_MISS, is = 0u;   // (the scan's hit is the end of the interval)
+                                            walk_meshes<COUNT, true>(sc, x, wi, tm, ts, cw, is, stk, stride, c_nodes, c_btris, AnyHit{kInf, 1u, 0u}, kStackRows);
+                                            if (cw == CODE_MISS) acc_add(cand);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    V wi = mk(0, 0, 1), k = mk(0, 0, 0);
+                    const bool cont = stage_bounce<MEDIUM, COUNT>(a, albedo_med, rd, depth, ev_medium, n, mcol, mat, rng, wi, k);
+                    SECT(14);
+                    P = fma3(Q, E, P);
+                    if (cont) {
+                        Q = Q * k;
+                        ro = x;
+                        rd = wi;
+                        depth++;
+                    } else {
+                        acc_add(P);
+                        need_path = true;
+                    }
+                }
+            }
+            // ---- the walks: parked primary queries + the queue.  A queue entry is a slot (wq[0]: slots in use, wq[1]: slots some
+            // lane is walking or holds suspended); the walk of a shadow query can be left unfinished like a parked primary walk:
+            // the lane keeps the entry's index (h_e), the position in `walk` and the stack in its LDS column, the ray stays in
+            // the slot.  A lane's column holds at most one unfinished walk, its own or an entry's; its own parked query starts
+            // only after the entry's walk is through.
+            {
+                const bool waitp = alive && phase == PH_WAITP;
+                const bool susp = h_e != kNoEntry;
+                const uint32_t used = __builtin_amdgcn_readfirstlane(wq[0]), claimed = __builtin_amdgcn_readfirstlane(wq[1]);
+                uint32_t avail = used & ~claimed;   // entries nobody has taken yet (wave-uniform)
+                const uint32_t n_new = uint32_t(__popc(avail));
+                const uint32_t n_work = uint32_t(__popcll(__ballot(waitp || susp))) + n_new;
+                const bool stalled = alive && need_path && item_done && have_item && ls_pend[threadIdx.x] != 0u;
+                const bool idle = __ballot(alive && !waitp && !stalled) == 0ull;   // nothing else this wave could do
+                if (n_work == 0u) {
+                    // nothing to walk.  (A lane can only be stalled while the queue holds a query of its item; should the
+                    // bookkeeping ever disagree, the lane writes its item out rather than spin.)
+                    if (idle && stalled) ls_pend[threadIdx.x] = 0u;
+                } else if (n_work >= a.defer_lanes || n_new >= a.detach_trigger || idle) {
+                    if (COUNT) c_wave[0] = c_wave[1] = 0;
+                    SECT(15);
+                    const uint32_t min_active = idle ? 1u : a.defer_stop;
+                    const BvhNode* const nodes = sc.nodes;
+                    const uint32_t root0 = uload(&sc.meshes[0]).root;
+                    // the walk at hand of this lane: 0 none, 1 its own parked primary query, 2 the entry h_e
+                    uint32_t mode = susp ? 2u : (waitp ? 1u : 0u);
+                    V wo = ro, wd = rd;
+                    float wt = q_t;
+                    uint32_t wc = q_code;
+                    uint32_t cur = mode ? walk.cur : kWalkDone, sp = mode ? walk.sp : 0u, mesh = mode ? walk.mesh : 0u;
+                    if (susp) {
+                        const volatile uint32_t* const q = wq + 8u + h_e;
+                        wo = mk(__uint_as_float(q[0u * kQCap]), __uint_as_float(q[1u * kQCap]), __uint_as_float(q[2u * kQCap]));
+                        wd = mk(__uint_as_float(q[3u * kQCap]), __uint_as_float(q[4u * kQCap]), __uint_as_float(q[5u * kQCap]));
+                        wt = __uint_as_float(q[6u * kQCap]);
+                        wc = CODE_MISS;
+                    }
+                    float wtmin = ray_tmin(wo);
+                    V inv = mk(rcp(wd.x), rcp(wd.y), rcp(wd.z));
+                    for (;;) {
+                        if (avail != 0u) {   // lanes without a walk take entries
+                            const bool free_lane = cur == kWalkDone;
+                            const uint64_t m = __ballot(free_lane);
+                            if (m != 0ull) {
+                                const uint32_t take = min(uint32_t(__popcll(m)), uint32_t(__popc(avail))), rank = mbcnt64(m);
+                                if (free_lane && rank < take) {
+                                    uint32_t f = avail;
+                                    for (uint32_t i = rank; i != 0u; i--) f &= f - 1u;
+                                    h_e = uint32_t(__builtin_ctz(f));
+                                    atomicOr(const_cast<uint32_t*>(wq) + 1, 1u << h_e);
+                                    const volatile uint32_t* const q = wq + 8u + h_e;
+                                    wo = mk(__uint_as_float(q[0u * kQCap]), __uint_as_float(q[1u * kQCap]), __uint_as_float(q[2u * kQCap]));
+                                    wd = mk(__uint_as_float(q[3u * kQCap]), __uint_as_float(q[4u * kQCap]), __uint_as_float(q[5u * kQCap]));
+                                    wt = __uint_as_float(q[6u * kQCap]);
+                                    wtmin = ray_tmin(wo);
+                                    wc = CODE_MISS;
+                                    inv = mk(rcp(wd.x), rcp(wd.y), rcp(wd.z));
+                                    cur = root0; sp = 0u; mesh = 0u;
+                                    mode = 2u;
+                                }
+                                for (uint32_t i = take; i != 0u; i--) avail &= avail - 1u;
+                            }
+                        }
+                        const uint64_t act = __ballot(cur != kWalkDone);
+                        if (act == 0ull) break;
+                        if (uint32_t(__popcll(act)) < min_active) break;   // too few are left to walk for: they go on in the next session
+                        for (;;) {  // the descent (kWalkDone has the leaf bit set: finished lanes take no part)
+                            const bool inner = !(cur & BVH_LEAF);
+                            const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
+                            if (n_inner == 0u) break;
+                            if (a.walk_leaf_quarters != 0u && 4u * uint32_t(__popcll(__ballot(!inner && cur != kWalkDone))) >= a.walk_leaf_quarters * n_inner) break;
+                            if (COUNT) c_wave[0]++;
+                            if (!inner) continue;
+                            const BvhNode nd = nodes[cur];
+                            if (COUNT) c_nodes++;
+                            float n0, f0, n1, f1;
+                            slab2(nd.lo0, nd.hi0, wo, inv, n0, f0);
+                            slab2(nd.lo1, nd.hi1, wo, inv, n1, f1);
+                            const bool h0 = fmaxf(n0, wtmin) <= fminf(f0, wt);
+                            const bool h1 = fmaxf(n1, wtmin) <= fminf(f1, wt);
+                            if (h0 && h1) {
+                                const bool first0 = n0 <= n1;
+                                if (sp < kStackRows) { stk[sp * stride] = first0 ? nd.e1 : nd.e0; sp++; }
+                                cur = first0 ? nd.e0 : nd.e1;
+                            } else if (h0 || h1) {
+                                cur = h0 ? nd.e0 : nd.e1;
+                            } else if (sp) {
+                                sp--;
+                                cur = stk[sp * stride];
+                            } else {
+                                cur = kWalkDone;
+                            }
+                        }
+                        if (COUNT) {
+                            uint32_t mx = 0;
+                            for (uint32_t k = 1; k <= 4u; k++)
+                                if (__ballot((cur & BVH_LEAF) && cur != kWalkDone && ((cur >> 26) & 31u) + 1u >= k) != 0ull) mx = k;
+                            c_wave[1] += mx;
+                        }
+                        if ((cur & BVH_LEAF) && cur != kWalkDone) {   // (lanes that are still descending go on with the next round)
+                            const uint32_t first = cur & BVH_INDEX_MASK;
+                            const uint32_t count = ((cur >> 26) & 31u) + 1u;
+                            TriScan nxt = sc.btri[first];
+                            for (uint32_t i = 0; i < count; i++) {  // the next triangle is in flight while this one is tested
+                                const TriScan tr = nxt;
+                                if (i + 1u < count) nxt = sc.btri[first + i + 1u];
+                                if (COUNT) c_btris++;
+                                const float t = hit_tri(tr.pn, tr.A, tr.B, wo, wd, wtmin, wt);
+                                if (t >= 0.f) { wt = t; wc = (K_BVHTRI << 28) | (first + i); }
+                            }
+                            // a shadow query is answered by its first triangle
+                            if (mode == 2u && wc != CODE_MISS) { sp = 0u; mesh = sc.n_mesh; }
+                            if (sp) {
+                                sp--;
+                                cur = stk[sp * stride];
+                            } else {
+                                cur = kWalkDone;
+                            }
+                        }
+                        if (cur == kWalkDone && mesh + 1u < sc.n_mesh) {  // the next mesh's tree
+                            mesh++;
+                            cur = sc.meshes[mesh].root;
+                        }
+                        if (cur == kWalkDone) {
+                            if (mode == 2u) {   // a shadow query is answered: visible iff no tree holds a triangle in its interval
+                                const volatile uint32_t* const q = wq + 8u + h_e;
+                                const uint32_t owner = q[10u * kQCap];
+                                if (COUNT) { SECT(18); }
+                                if (wc == CODE_MISS) {
+                                    atomicAdd(&acc64[owner], to_fixed(__uint_as_float(q[7u * kQCap])));
+                                    atomicAdd(&acc64[256u + owner], to_fixed(__uint_as_float(q[8u * kQCap])));
+                                    atomicAdd(&acc64[512u + owner], to_fixed(__uint_as_float(q[9u * kQCap])));
+                                }
+                                atomicSub(const_cast<uint32_t*>(ls_pend) + owner, 1u);
+                                atomicAnd(const_cast<uint32_t*>(wq), ~(1u << h_e));
+                                atomicAnd(const_cast<uint32_t*>(wq) + 1, ~(1u << h_e));
+                                h_e = kNoEntry;
+                                mode = 0u;
+                                if (waitp && phase == PH_WAITP) {   // now this lane's own parked query (not begun: its column was taken)
+                                    wo = ro; wd = rd; wt = q_t; wc = q_code;
+                                    wtmin = ray_tmin(wo);
+                                    inv = mk(rcp(wd.x), rcp(wd.y), rcp(wd.z));
+                                    cur = root0; sp = 0u; mesh = 0u;
+                                    mode = 1u;
+                                }
+                            } else if (mode == 1u) {
+                                SECT(16);
+                                if ((wc >> 28) == K_BVHTRI) { SECT(17); }
+                                mode = 0u;
+                                phase = PH_HAVEP;
+                                q_t = wt;
+                                q_code = wc;
+                            }
+                        }
+                    }
+                    if (mode != 0u) walk = WalkState{cur, sp, mesh};   // an unfinished walk goes on in the next session
+                    if (mode == 1u) { q_t = wt; q_code = wc; }
+                    if (COUNT) {
+                        for (int k = 0; k < 2; k++) {
+                            uint32_t v = c_wave[k];
+                            for (int off = 32; off; off >>= 1) v = max(v, uint32_t(__shfl_xor(int(v), off)));
+                            w_tot[k] += v;
+                        }
+                    }
+                }
+            }
+            if (++fuse == 0x01000000u) break;   // (no wave of a valid launch comes near 2^24 trips: the loop cannot spin for ever)
+            continue;
+        }
         if constexpr (BVH == 1) {
             // ---- A: a new path vertex: distance sample, scan, do the trees matter?
             if (alive && phase == PH_NEW) {
@@ -651,6 +994,24 @@ __global__ __launch_bounds__(256) void buffer_variance_kernel(uint32_t n_pixels,
     out[p] = fmax(ss, 0.0) / (n - 1.0);
 }
 
+// ------------------------------------------------------------------ frame exchange (rpt_gather_frame_device)
+// Element e of the packed block = channel e % 3 of pixel (e / 3) % 1024 (row-major in the tile) of tile e / 3072 of
+// the list: consecutive lanes touch consecutive doubles on both sides (96 per tile row).
+template <bool PACK>
+__global__ __launch_bounds__(256) void frame_tiles_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                          const uint32_t* __restrict__ tiles, uint32_t n_tiles, uint32_t tiles_x,
+                                                          uint32_t width, uint32_t height) {
+    const uint64_t e = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (e >= uint64_t(n_tiles) * 3072u) return;
+    const uint32_t t = uint32_t(e / 3072u), r = uint32_t(e % 3072u), p = r / 3u, c = r - 3u * p;
+    const uint32_t tile = tiles[t], ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t x = tx * 32u + (p & 31u), y = ty * 32u + (p >> 5);
+    const bool inside = x < width && y < height;
+    const size_t f = (size_t(y) * width + x) * 3u + c;
+    if (PACK) dst[e] = inside ? src[f] : 0.0;
+    else if (inside) dst[f] = src[e];
+}
+
 template <int BVH>
 __global__ __launch_bounds__(256) void intersect_kernel(const SceneView sc, uint64_t n, const float* __restrict__ o,
                                                         const float* __restrict__ d, float* __restrict__ t_out,
@@ -729,10 +1090,18 @@ static constexpr size_t kTabBytes = (2u * 32u + 6u * 8u) * 16u;   // LdsTables: 
 static constexpr size_t kStateBytes = 18u * 256u * sizeof(uint32_t) + kTabBytes;      // LDS-resident lane state of the scan instantiations
 static constexpr size_t kStateBytesBvh = 5u * 256u * sizeof(uint32_t) + kTabBytes;   // ... of the tree-walking ones (behind the stack)
 static constexpr size_t kMeshTreeBytes = (21u + 5u) * 256u * sizeof(uint32_t) + kTabBytes;   // per-mesh-tree kernels: 21 stack rows + lane state
+static constexpr size_t kDetachBytes = kDetachDwords * sizeof(uint32_t);                      // ... with detached shadow queries
+static_assert(kTabBytes == kTabDwords * 4u, "one table layout");
 
 template <bool M, int B, bool C>
 static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t stream) {
     const size_t lds = B == 1 ? kMeshTreeBytes : B ? kStackBytes + kStateBytesBvh : kStateBytes;
+    if constexpr (M && B == 1) {
+        if (a.detach && !a.sc.n_lparts) {
+            hipLaunchKernelGGL((render_kernel<true, 1, C, false, true>), dim3(n_blocks), dim3(256), kDetachBytes, stream, a);
+            return hipGetLastError();
+        }
+    }
     // group lights have no counters build: the section counters stay zero for such scenes
     if (a.sc.n_lparts) hipLaunchKernelGGL((render_kernel<M, B, false, true>), dim3(n_blocks), dim3(256), lds, stream, a);
     else hipLaunchKernelGGL((render_kernel<M, B, C>), dim3(n_blocks), dim3(256), lds, stream, a);
@@ -751,7 +1120,9 @@ hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream) 
     if (m) return c ? launch_render_b<true, true>(a, b, n_blocks, stream) : launch_render_b<true, false>(a, b, n_blocks, stream);
     return c ? launch_render_b<false, true>(a, b, n_blocks, stream) : launch_render_b<false, false>(a, b, n_blocks, stream);
 }
-hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu) {
+hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu, bool detach) {
+    if (detach && medium && bvh == 1)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)render_kernel<true, 1, false, false, true>, 256, kDetachBytes);
     const void* f;
     if (medium) f = bvh == 2 ? (const void*)render_kernel<true, 2, false> : bvh == 1 ? (const void*)render_kernel<true, 1, false> : (const void*)render_kernel<true, 0, false>;
     else f = bvh == 2 ? (const void*)render_kernel<false, 2, false> : bvh == 1 ? (const void*)render_kernel<false, 1, false> : (const void*)render_kernel<false, 0, false>;
@@ -775,6 +1146,18 @@ hipError_t launch_buffer_variance(uint32_t n_pixels, uint32_t n_batches, const d
                                   hipStream_t st) {
     hipLaunchKernelGGL(buffer_variance_kernel, dim3((n_pixels + 255) / 256), dim3(256), 0, st, n_pixels, n_batches, d_sum, d_sumsq,
                        d_out);
+    return hipGetLastError();
+}
+hipError_t launch_frame_pack(const double* d_frame, double* d_packed, const uint32_t* d_tiles, uint32_t n_tiles, uint32_t tiles_x,
+                             uint32_t width, uint32_t height, hipStream_t st) {
+    if (!n_tiles) return hipSuccess;
+    hipLaunchKernelGGL(frame_tiles_kernel<true>, dim3(n_tiles * 12u), dim3(256), 0, st, d_frame, d_packed, d_tiles, n_tiles, tiles_x, width, height);
+    return hipGetLastError();
+}
+hipError_t launch_frame_unpack(const double* d_packed, double* d_frame, const uint32_t* d_tiles, uint32_t n_tiles, uint32_t tiles_x,
+                               uint32_t width, uint32_t height, hipStream_t st) {
+    if (!n_tiles) return hipSuccess;
+    hipLaunchKernelGGL(frame_tiles_kernel<false>, dim3(n_tiles * 12u), dim3(256), 0, st, d_packed, d_frame, d_tiles, n_tiles, tiles_x, width, height);
     return hipGetLastError();
 }
 hipError_t launch_intersect(const SceneView& sc, uint64_t n, const float* d_o, const float* d_d, float* d_t,

@@ -67,6 +67,9 @@ struct rpt_options {
     int64_t defer_stop = 16;        // still-walking lanes below which a wave leaves the walk (the rest resume later)
     int64_t walk_leaf_quarters = 6; // deferred walks: test the leaves when 4 x (lanes at a leaf) >= this x (lanes still descending); 0 = when all are there
     int64_t defer_lanes = 32;       // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
+    int64_t detach_shadows = 1;     // per-mesh-tree kernels in a medium: shadow queries that need a tree walk leave their path (0: they park the lane)
+    int64_t detach_lanes = 48;      // ... parked primary + queued shadow queries per wave that trigger a walk session
+    int64_t detach_trigger = 20;    // ... or this many queued shadow queries alone (the queue holds 32)
     int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built
 };
 static rpt_options g_defaults;
@@ -88,6 +91,9 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "bvh_leaf_max") { if (value < 1 || value > 16) return fail(RPT_ERR_INVALID, "bvh_leaf_max must be 1..16"); o.bvh_leaf_max = value; }
     else if (s == "bvh_max_depth") { if (value < 1 || value > 20) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..20"); o.bvh_max_depth = value; }
     else if (s == "walk_leaf_quarters") { if (value < 0 || value > 256) return fail(RPT_ERR_INVALID, "walk_leaf_quarters must be 0..256"); o.walk_leaf_quarters = value; }
+    else if (s == "detach_shadows") o.detach_shadows = value;
+    else if (s == "detach_lanes") { if (value < 1 || value > 96) return fail(RPT_ERR_INVALID, "detach_lanes must be 1..96"); o.detach_lanes = value; }
+    else if (s == "detach_trigger") { if (value < 1 || value > 32) return fail(RPT_ERR_INVALID, "detach_trigger must be 1..32"); o.detach_trigger = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); o.scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option: " + s);
@@ -446,6 +452,7 @@ struct rpt_scene {
     size_t ev_count = 0;  // timed launches since the last rpt_get_timing_mean
     int last_blocks = 0;
     uint64_t prims_per_ray = 0;
+    bool twins_scanned = false;  // every Light::Object that can be visible has its twin among the scanned records, as one range of hit codes
     uint64_t stats[16] = {0};
     void* photon = nullptr;  // PhotonMapDev*, owned by photon.hip
     // mesh data interned by content (hash -> candidates), so Arc<Mesh>-style sharing survives the C ABI
@@ -1412,6 +1419,9 @@ struct Flattener {
         v.hdri_w = s->hdri_w;
         v.hdri_h = s->hdri_h;
         s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size() + aabb.size() + rect.size() + (has_shell ? 1 : 0);
+        s->twins_scanned = true;
+        for (const Light& L : lights)
+            if (L.kind == L_OBJECT && L.twin_object >= 0 && !(L.twin_lo <= L.twin_hi)) s->twins_scanned = false;
         s->stats[0] = sph.size(); s->stats[1] = cub.size(); s->stats[2] = pln.size(); s->stats[3] = tri.size();
         s->stats[4] = aabb.size(); s->stats[5] = rect_sh.size(); s->stats[6] = btri.size(); s->stats[7] = nodes.size();
         // scan-record bytes every closest-hit query walks (the uniform part of the algorithmic bytes)
@@ -1501,6 +1511,15 @@ int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_ch
     return RPT_OK;
 }
 
+int rpt_scene_render_chunking(rpt_scene* s, uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_chunks) {
+    if (!s) return fail(RPT_ERR_INVALID, "null scene");
+    if (iterations == 0) return fail(RPT_ERR_INVALID, "empty render");
+    const uint32_t c = chunk_rule(s->opt.chunk_spp, iterations, 0, 0);
+    if (chunk_spp) *chunk_spp = c;
+    if (n_chunks) *n_chunks = (iterations + c - 1) / c;
+    return RPT_OK;
+}
+
 extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
                          uint64_t seed, uint32_t sample_offset, RenderArgs& a, uint32_t min_chunk, uint32_t fixed_chunk) {
     if (!s || !cam || !prm) return fail(RPT_ERR_INVALID, "null argument");
@@ -1578,6 +1597,15 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     a.defer_lanes = uint32_t(s->opt.defer_lanes);
     a.defer_stop = uint32_t(std::min(s->opt.defer_stop, s->opt.defer_lanes));
     a.walk_leaf_quarters = uint32_t(s->opt.walk_leaf_quarters);
+    // Detached shadow queries: in a medium (a path's radiance is linear in its light terms), per-mesh trees, and every
+    // light that can be visible has its twin among the scanned records as one range of hit codes.
+    a.detach = 0;
+    if (s->opt.detach_shadows && s->view.has_medium && bvh_mode(s->view) == 1 && s->view.n_lparts == 0 && s->twins_scanned) a.detach = 1;
+    a.detach_trigger = uint32_t(s->opt.detach_trigger);
+    if (a.detach) {
+        a.defer_lanes = uint32_t(s->opt.detach_lanes);
+        a.defer_stop = uint32_t(std::min<int64_t>(s->opt.defer_stop, std::min(s->opt.detach_lanes, s->opt.detach_trigger)));   // a session that starts makes progress
+    }
     return RPT_OK;
 }
 
@@ -1636,7 +1664,7 @@ extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm
 static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st) {
     int bpc = int(s->opt.blocks_per_cu);
     if (bpc <= 0) {
-        HIP_TRY(render_occupancy(a.sc.has_medium != 0, bvh_mode(a.sc), &bpc));
+        HIP_TRY(render_occupancy(a.sc.has_medium != 0, bvh_mode(a.sc), &bpc, a.detach != 0));
         if (bpc < 1) bpc = 1;
     }
     return rpti::run_persistent(s, prm, a, d_out, st, bpc,

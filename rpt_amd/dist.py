@@ -7,7 +7,70 @@ CPU tests).  The path has exactly two exchange steps:
     needs the whole map, so the shot records are all-gathered in rank order (`gather_records`,
     `photon_map_build_sharded`).
 
+The frame exchange itself is in the library, behind the C ABI (`FrameComm` = rpt_comm_* / rpt_gather_frame_device:
+owned tiles packed f64, ncclSend / ncclRecv to rank 0); torch.distributed is then only the launcher and the store that
+hands out the communicator id.  `reduce_frame` is the older sum-reduce of zero-padded frames through torch.
+
 torch is imported lazily so that `import rpt_amd` stays numpy-only."""
+import ctypes as _C
+
+from . import _lib
+
+COMM_ID_BYTES = 128  # RPT_COMM_ID_BYTES
+GATHER_LOOPBACK = 1  # RPT_GATHER_LOOPBACK
+
+
+class FrameComm:
+    """rpt_comm: an RCCL communicator of the library's own, one rank per GPU.
+
+    FrameComm.unique_id() on rank 0 -> hand the 128 bytes to every rank -> FrameComm(id, rank, world, device)
+    on every rank (collective).  gather(width, height, d_shard, d_frame, stream) assembles the sharded frames on rank 0."""
+
+    def __init__(self, uid, rank, world, device):
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError("communicator id must be 128 bytes")
+        buf = (_C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+        h = _C.c_void_p()
+        _lib.check(_lib.load().rpt_comm_create(_C.cast(buf, _C.c_void_p), int(rank), int(world), int(device), _C.byref(h)))
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        buf = (_C.c_char * COMM_ID_BYTES)()
+        _lib.check(_lib.load().rpt_comm_unique_id(_C.cast(buf, _C.c_void_p)))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch(cls, dist, device):
+        """Create the communicator of an initialised torch.distributed job: rank 0 draws the id, the job's store /
+        broadcast hands it out (any backend: the id is 128 bytes of host data)."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(box[0], rank, world, device)
+
+    def gather(self, width, height, d_shard, d_frame=None, stream=None, loopback=False):
+        _lib.check(_lib.load().rpt_gather_frame_device(self._h, int(width), int(height), _C.c_void_p(d_shard),
+                                                       _C.c_void_p(d_frame) if d_frame else None,
+                                                       GATHER_LOOPBACK if loopback else 0, _C.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if self._h:
+            _lib.load().rpt_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def frame_pack_layout(width, height, world):
+    """rpt_frame_pack_layout: tile offsets of every rank's block in the gathered buffer (world + 1 values)."""
+    out = (_C.c_uint64 * (world + 1))()
+    _lib.check(_lib.load().rpt_frame_pack_layout(int(width), int(height), int(world), out))
+    return [int(v) for v in out]
 
 RECORD_BYTES = 48  # RPT_PHOTON_RECORD_BYTES
 
@@ -74,4 +137,4 @@ def photon_map_build_sharded(renderer, photon_count, kind, rank, world, group=No
                                             gathered[1].data_ptr(), gathered[1].shape[0])
 
 
-__all__ = ["RECORD_BYTES", "reduce_frame", "gather_records", "photon_map_build_sharded"]
+__all__ = ["RECORD_BYTES", "reduce_frame", "gather_records", "photon_map_build_sharded", "FrameComm", "frame_pack_layout"]

@@ -76,6 +76,7 @@ def test_argument_validation_needs_no_gpu():
         assert lib.rpt_scene_set_option(None, b"chunk_spp", 8) == -1
         c, n = C.c_uint32(), C.c_uint32()
         assert lib.rpt_render_chunking(256, C.byref(c), C.byref(n)) == 0 and (c.value, n.value) == (4, 64)   # the default rule
+        assert lib.rpt_scene_render_chunking(h, 256, C.byref(c), C.byref(n)) == 0 and (c.value, n.value) == (8, 32)   # this scene's option
     finally:
         lib.rpt_scene_destroy(h)
 
@@ -89,6 +90,22 @@ def test_shard_tiles_partition_the_frame():
             assert len({len(p) for p in parts}) == 1                                   # perfectly balanced
     lib = _lib.load()
     assert lib.rpt_shard_tiles(64, 64, 3, 2, None, 0) == -1
+
+
+def test_frame_pack_layout_is_the_concatenation_of_the_shards():
+    """rpt_frame_pack_layout (pure host): rank r's block of the gathered buffer holds exactly the tiles rpt_shard_tiles gives
+    rank r, the blocks follow each other in rank order and together they are every tile of the frame."""
+    from rpt_amd.dist import frame_pack_layout
+    lib = _lib.load()
+    for (w, h, n) in [(1024, 1024, 8), (2048, 2048, 8), (100, 70, 3), (33, 65, 4), (64, 64, 1), (32, 32, 5)]:
+        offs = frame_pack_layout(w, h, n)
+        counts = [lib.rpt_shard_tiles(w, h, r, n, None, 0) for r in range(n)]
+        assert offs[0] == 0 and [offs[r + 1] - offs[r] for r in range(n)] == counts
+        assert offs[n] == ((w + 31) // 32) * ((h + 31) // 32)
+    out = (C.c_uint64 * 2)()
+    assert lib.rpt_frame_pack_layout(0, 8, 1, out) == -1 and lib.rpt_frame_pack_layout(8, 8, 0, out) == -1
+    assert lib.rpt_gather_frame_device(None, 8, 8, None, None, 0, None) == -1
+    assert lib.rpt_comm_create(None, 0, 1, 0, None) == -1
 
 
 @pytest.mark.skipif(_lib.load().rpt_device_count() > 0, reason="a GPU is present")

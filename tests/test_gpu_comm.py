@@ -1,0 +1,75 @@
+"""Frame exchange behind the C ABI (include/rpt_hip.h "frame exchange", rpt_amd/csrc/rpt_comm.cpp): the pack / unpack of
+owned tiles on the device, and the RCCL transport with the one rank a single-GPU box has (rank 0 sends its own tiles
+to itself through ncclSend / ncclRecv).  The N > 1 arithmetic is the same tile lists (CPU test in test_dist_gloo.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rpt_amd import _lib, shard_pixels
+from rpt_amd.dist import FrameComm, frame_pack_layout
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("w,h,n", [(256, 192, 3), (100, 70, 2), (64, 64, 1), (33, 65, 8)])
+def test_pack_and_unpack_move_exactly_the_owned_tiles(w, h, n):
+    import torch
+    lib = _lib.load()
+    rng = np.random.default_rng(w * 7 + n)
+    frame_h = rng.normal(size=(h * w, 3))
+    frame = torch.from_numpy(frame_h.reshape(-1)).cuda()
+    offs = frame_pack_layout(w, h, n)
+    total = torch.zeros(h * w * 3, dtype=torch.float64, device="cuda")
+    for r in range(n):
+        tiles = offs[r + 1] - offs[r]
+        packed = torch.full((max(tiles, 1) * 3072,), 7.0, dtype=torch.float64, device="cuda")
+        _lib.check(lib.rpt_frame_pack_device(w, h, r, n, _ptr(frame), _ptr(packed), None))
+        one = torch.zeros(h * w * 3, dtype=torch.float64, device="cuda")
+        _lib.check(lib.rpt_frame_unpack_device(w, h, r, n, _ptr(packed), _ptr(one), None))
+        torch.cuda.synchronize()
+        got = one.cpu().numpy().reshape(-1, 3)
+        own = shard_pixels(w, h, r, n)
+        exp = np.zeros_like(frame_h)
+        exp[own] = frame_h[own]
+        assert np.array_equal(got, exp)                        # owned pixels bit for bit, nothing else touched
+        if tiles:                                              # out-of-image slots of clipped tiles are zero, not stale
+            assert float(packed[:tiles * 3072].abs().sum()) == pytest.approx(float(np.abs(frame_h[own]).sum()), rel=1e-12)
+        total += one
+    assert np.array_equal(total.cpu().numpy().reshape(-1, 3), frame_h)
+
+
+def test_one_rank_gather_through_rccl():
+    """ncclCommInitRank with one rank, then the gather with RPT_GATHER_LOOPBACK: rank 0's tiles are packed, sent to itself
+    with ncclSend / ncclRecv inside one group, and unpacked into a second frame."""
+    import torch
+    w, h = 200, 136
+    comm = FrameComm(FrameComm.unique_id(), 0, 1, 0)
+    try:
+        rng = np.random.default_rng(5)
+        src_h = rng.normal(size=h * w * 3)
+        src = torch.from_numpy(src_h).cuda()
+        dst = torch.zeros_like(src)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            comm.gather(w, h, src.data_ptr(), dst.data_ptr(), st.cuda_stream, loopback=True)
+        st.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), src_h)
+        # without the loopback flag the own tiles are copied on the device; in place it is a no-op
+        dst2 = torch.zeros_like(src)
+        comm.gather(w, h, src.data_ptr(), dst2.data_ptr(), None)
+        comm.gather(w, h, src.data_ptr(), src.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst2.cpu().numpy(), src_h) and np.array_equal(src.cpu().numpy(), src_h)
+        # another frame size on the same communicator
+        src3 = torch.from_numpy(rng.normal(size=64 * 32 * 3)).cuda()
+        dst3 = torch.zeros_like(src3)
+        comm.gather(64, 32, src3.data_ptr(), dst3.data_ptr(), None, loopback=True)
+        torch.cuda.synchronize()
+        assert torch.equal(src3, dst3)
+    finally:
+        comm.close()

@@ -43,6 +43,8 @@ res["_config"] = {"workload": args.workload, "width": args.width or cfg["width"]
                   "spp": args.spp or cfg["spp"], "n_gpus": 1}
 if "photons" in cfg:
     res["_config"]["photons"] = args.photons or cfg["photons"]
+from __graft_entry__ import library_source_digest  # noqa: E402
+res["_source_digest"] = library_source_digest()   # the kernel sources this profile describes (bench.py uses no other profile)
 res["_how"] = ("rocprofv3 --kernel-trace --pmc <group>, one run per counter group (tools/pmc_passes.sh), bench.py --steps 1 --warmup 1; "
                "values are per-launch means over the timed launches; FETCH_SIZE / WRITE_SIZE in KB")
 path = os.path.join(args.out, f"pmc_{args.workload}.json")
