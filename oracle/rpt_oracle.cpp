@@ -923,7 +923,7 @@ struct Renderer {
     double t_min_for(const Ray& ray) const {
         if (!p.robust) return EPSILON;
         double m = std::fmax(std::fmax(std::fabs(ray.origin.x), std::fabs(ray.origin.y)), std::fabs(ray.origin.z));
-        return 1e-5 * (1.0 + m);
+        return 2e-5 * (1.0 + m);
     }
     // src/renderer.rs:416-425
     bool get_closest_hit(const Ray& ray, HitRecord& h, int& obj) const {

@@ -29,8 +29,12 @@ struct RenderArgs {
     uint32_t defer_lanes;     // per-mesh-tree kernels: parked tree walks per wave that trigger a walk (1..64)
     uint32_t defer_stop;      // ... and the number of still-walking lanes below which the wave leaves the walk
     uint32_t walk_leaf_quarters;  // ... and the descent of a walk pauses for the leaves when 4 x (lanes at a leaf) >= this x (lanes descending); 0: never
-    uint32_t detach;              // per-mesh-tree kernels in a medium: shadow queries that need a tree walk leave their path (wave queue in LDS)
-    uint32_t detach_trigger;      // ... and a walk session is due as soon as the queue holds this many (1..32)
+    uint32_t detach;              // per-mesh-tree kernels in a medium: 1 = shadow queries that need a tree walk leave their path (wave queue
+                                  // in LDS); 2 = every tree walk leaves its path (ring + parked path contexts in stream_scratch)
+    uint32_t detach_trigger;      // detach = 1: a walk session is due as soon as the queue holds this many (1..32)
+    uint32_t stream_backlog;      // detach = 2: ... as soon as the ring holds this many queries
+    uint32_t n_twin_lights;       // object lights that can be visible (each may write one shadow query per lane and trip)
+    uint32_t* stream_scratch;     // detach = 2: stream_scratch_bytes_per_block() per block of the grid
 };
 
 // The device functions read the scene view at kernarg + 0 (kernarg_scene in device_core.h): every kernel that calls them
@@ -43,7 +47,8 @@ struct KernelInfo {
 
 // Persistent megakernel: grid = n_blocks x 256 threads.
 hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream);
-hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu, bool detach = false);  // bvh: bvh_mode()
+hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu, int detach = 0);  // bvh: bvh_mode(); detach: RenderArgs::detach
+size_t stream_scratch_bytes_per_block();
 int bvh_mode(const SceneView& sc);  // 0 no tree, 1 per-mesh trees, 2 scene-level tree
 // out[pixel] = sum_chunks slab / iterations * scale for owned pixels (others untouched).
 hipError_t launch_buffer_add(uint32_t n_pixels, const double* d_batch, double* d_sum, double* d_sumsq, hipStream_t st);

@@ -68,7 +68,7 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 static constexpr uint32_t kDetachStackRows = 20u;   // a mesh tree is at most 20 levels deep: it pushes at most 19 entries
 static constexpr uint32_t kQCap = 32u;              // detached shadow queries a wave can hold
 static constexpr uint32_t kQFields = 11u;           // origin, direction, end of the interval, contribution if visible, owner lane
-static constexpr uint32_t kQWaveDwords = 8u + kQFields * kQCap;   // [0]: slots in use, [1]: slots being walked (bit masks); fields from [8], field-major
+static constexpr uint32_t kQWaveDwords = 16u + kQFields * kQCap;   // [0]: slots in use, [1]: slots being walked (bit masks); fields from [16], field-major
 static_assert(kQCap == 32u, "one mask bit per slot");
 static constexpr uint32_t kTabDwords = (2u * 32u + 6u * 8u) * 4u;   // LdsTables: 32 materials + 8 light triangles
 static constexpr uint32_t kDetachPendBase = (kDetachStackRows + 5u) * 256u + kTabDwords;
@@ -76,6 +76,15 @@ static constexpr uint32_t kDetachAccBase = kDetachPendBase + 256u;
 static constexpr uint32_t kDetachQBase = kDetachAccBase + 3u * 256u * 2u;
 static constexpr uint32_t kDetachDwords = kDetachQBase + 4u * kQWaveDwords;
 static_assert(kDetachAccBase % 2u == 0u, "the 64-bit accumulators are 8-byte aligned");
+// DETACH = 2 ("streamed walks"): per wave, in global memory (RenderArgs::stream_scratch; only this wave ever touches its
+// part), a FIFO ring of queries and kCtxMax parked path contexts per lane.
+static constexpr uint32_t kRingEntries = 512u;   // queries a wave can hold; a session is forced before the ring could overflow
+static constexpr uint32_t kRingDwords = 12u;     // origin, direction | end of the interval, 3 words by kind | meta, pad (3 x 16 B)
+static constexpr uint32_t kCtxMax = 3u;          // parked paths per lane
+static constexpr uint32_t kCtxFields = 20u;      // origin, direction, P, Q, RNG state, depth, medium distance, answer (t, code)
+static constexpr uint32_t kWaveScratchDwords = kRingEntries * kRingDwords + kCtxMax * kCtxFields * 64u;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 static_assert(kDetachDwords * 4u * 4u <= 160u * 1024u, "four blocks per CU");
 // Radiance -> unsigned 32.32 fixed point (negative values and NaN -> 0, values from 2^32 up saturate).  Sums of such
 // numbers do not depend on the order of the additions: that is what lets a detached shadow query add its term to
@@ -195,10 +204,11 @@ RPT_DEV bool stage_bounce(const RenderArgs& a, float albedo_med, V rd, uint32_t 
 // GROUPS: some Light::Object is a KdTree group (per-lane leaf sampler).  A separate instantiation: the extra
 // sampler copy costs the plain kernels 6 % through register allocation alone, and a call costs 6x.
 // DETACH (per-mesh-tree kernels in a medium): shadow queries that need a tree walk leave their path (see the loop body).
-template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false, bool DETACH = false>
+// DETACH = 2: primary queries leave as well -- their paths wait in memory and the lane goes on with another one.
+template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false, int DETACH = 0>
 __global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : BVH == 1 ? RPT_MIN_WAVES_MESH : RPT_MIN_WAVES)
 void render_kernel(const RenderArgs a) {
-    static_assert(!DETACH || (MEDIUM && BVH == 1 && !GROUPS), "detached shadow queries: per-mesh-tree kernels in a medium only");
+    static_assert(DETACH == 0 || (MEDIUM && BVH == 1 && !GROUPS), "detached tree walks: per-mesh-tree kernels in a medium only");
     extern __shared__ uint32_t dyn_lds[];
     const SceneView& sc = a.sc;
     uint32_t* stk = BVH ? (dyn_lds + threadIdx.x) : nullptr;
@@ -249,7 +259,7 @@ void render_kernel(const RenderArgs a) {
     // it; pend = detached shadow queries of the lane's item that are still in the wave's queue
     volatile uint32_t* const ls_pend = dyn_lds + (DETACH ? kDetachPendBase : 0u);                      // [256]
     unsigned long long* const acc64 = reinterpret_cast<unsigned long long*>(dyn_lds + (DETACH ? kDetachAccBase : 0u));   // [3][256]
-    volatile uint32_t* const wq = dyn_lds + (DETACH ? kDetachQBase + (threadIdx.x >> 6) * kQWaveDwords : 0u);   // this wave's queue
+    volatile uint32_t* const wq = dyn_lds + (DETACH ? kDetachQBase + (threadIdx.x >> 6) * kQWaveDwords : 0u);   // this wave's queue (DETACH = 2: its header words only)
     auto acc_add = [&](V v) {
         if constexpr (DETACH) {
             atomicAdd(&acc64[threadIdx.x], to_fixed(v.x));
@@ -262,7 +272,7 @@ void render_kernel(const RenderArgs a) {
         }
     };
     if constexpr (DETACH) {
-        if ((threadIdx.x & 63u) == 0u) { wq[0] = 0u; wq[1] = 0u; }
+        if ((threadIdx.x & 63u) < 16u) wq[threadIdx.x & 63u] = 0u;   // (DETACH = 2 keeps head, tail, low-water mark and the ready masks there)
         ls_pend[threadIdx.x] = 0u;
     }
     // The radiance carrier (P, Q, Rc) is read and written once per vertex: in the scan instantiations it lives in LDS
@@ -299,6 +309,11 @@ void render_kernel(const RenderArgs a) {
     uint32_t fuse = 0u;   // (DETACH) trips of this wave
     constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
     uint32_t h_e = kNoEntry;   // (DETACH) queue entry whose unfinished walk this lane holds
+    // (DETACH = 2) this wave's memory: the ring of queries and the parked path contexts [context][field][lane]
+    uint32_t* const ring_base = DETACH == 2 ? a.stream_scratch + size_t(blockIdx.x * 4u + (threadIdx.x >> 6)) * kWaveScratchDwords : nullptr;
+    uint32_t* const ctx_base = DETACH == 2 ? ring_base + kRingEntries * kRingDwords : nullptr;
+    uint32_t parked_mask = 0u;   // contexts of this lane that wait in memory
+    bool did_work = false;       // this lane took a step in this trip
 
     for (;;) {
         // ---- work distribution (wave-convergent).  A wave draws batches of 64 items from the global
@@ -307,7 +322,37 @@ void render_kernel(const RenderArgs a) {
         // (One atomic per lane-pull saturated the counter at ~80 M dequeues/s: profiles/r01.)
         bool want = alive && need_path && item_done;
         // DETACH: an item is written out once the last of its detached shadow queries has been answered
-        if constexpr (DETACH) want = want && (!have_item || ls_pend[threadIdx.x] == 0u);
+        if constexpr (DETACH != 0) want = want && (!have_item || ls_pend[threadIdx.x] == 0u);
+        if constexpr (DETACH == 2) {
+            // a parked path of this lane whose walk has been answered comes back first (see the loop body)
+            if (alive && need_path && parked_mask != 0u) {
+                const uint32_t lane = threadIdx.x & 63u;
+                uint32_t rc = kCtxMax;
+                for (uint32_t c = 0; c < kCtxMax; c++) {
+                    const uint32_t rdy = wq[4u + 2u * c + (lane >> 5)];
+                    if (rc == kCtxMax && ((parked_mask >> c) & 1u) && ((rdy >> (lane & 31u)) & 1u)) rc = c;
+                }
+                if (rc != kCtxMax) {
+                    const uint32_t* const cx = ctx_base + rc * kCtxFields * 64u + lane;
+                    auto ldn = [&](uint32_t f) { return __builtin_nontemporal_load(cx + f * 64u); };
+                    ro = mk(__uint_as_float(ldn(0)), __uint_as_float(ldn(1)), __uint_as_float(ldn(2)));
+                    rd = mk(__uint_as_float(ldn(3)), __uint_as_float(ldn(4)), __uint_as_float(ldn(5)));
+                    P = mk(__uint_as_float(ldn(6)), __uint_as_float(ldn(7)), __uint_as_float(ldn(8)));
+                    Q = mk(__uint_as_float(ldn(9)), __uint_as_float(ldn(10)), __uint_as_float(ldn(11)));
+                    rng.s0 = ldn(12); rng.s1 = ldn(13); rng.s2 = ldn(14); rng.s3 = ldn(15);
+                    depth = ldn(16);
+                    v_dmed = __uint_as_float(ldn(17));
+                    q_t = __uint_as_float(ldn(18));
+                    q_code = ldn(19);
+                    parked_mask &= ~(1u << rc);
+                    atomicAnd(const_cast<uint32_t*>(wq) + 4u + 2u * rc + (lane >> 5), ~(1u << (lane & 31u)));
+                    phase = PH_HAVEP;
+                    need_path = false;
+                    did_work = true;
+                }
+            }
+            want = want && parked_mask == 0u;
+        }
         if (__any(want)) {
             const auto& ka = *kernarg_args<RenderArgs>();   // item bookkeeping reads its arguments here, not from registers held since kernel entry
             SECT(0);
@@ -391,7 +436,9 @@ void render_kernel(const RenderArgs a) {
                 }
             }
         }
-        if (need_path && alive && !(DETACH && item_done)) {   // (DETACH: a lane whose finished item still waits for shadow answers has no sample to start)
+        // (DETACH: a lane whose finished item still waits for shadow answers has no sample to start; DETACH = 2: nor has a
+        // lane with every context parked)
+        if (need_path && alive && !(DETACH != 0 && item_done) && !(DETACH == 2 && uint32_t(__popc(parked_mask)) >= kCtxMax)) {
             if (alive) {  // src/renderer.rs:179-181
                 const auto& ka = *kernarg_args<RenderArgs>();
                 SECT(1);
@@ -414,12 +461,303 @@ void render_kernel(const RenderArgs a) {
                 stu(S_S, s_r, s + 1u);
                 item_done = s + 1u >= ldu(S_END, s_end_r);
                 need_path = false;
+                if (DETACH == 2) { phase = PH_NEW; did_work = true; }
                 if (COUNT) c_samples++;
             }
         }
         if (!__any(alive)) break;
         if (COUNT && (threadIdx.x & 63u) == 0) c_trips++;
-        if constexpr (DETACH) {
+        if constexpr (DETACH == 2) {
+            // ---- per-mesh-tree flavour in a medium, every tree walk streamed.  A query that has to walk a tree -- primary or
+            // shadow -- is written to a ring of this wave in memory and leaves its lane.  A shadow query carries its
+            // contribution and is added to its item's sum when answered (as with DETACH = 1).  The path of a primary
+            // query is parked: its state (20 dwords) goes to one of the lane's kCtxMax context slots in memory, and the lane
+            // goes on with another of its parked paths whose answer has arrived, or starts the item's next sample.  So a
+            // wave holds up to 4 x 64 paths for its 64 lanes, the stages run for the lanes that have a path to advance,
+            // and a walk session has every lane walking: all 64 take queries from the ring and take the next one when
+            // theirs is done, until the ring is empty.  Paths are independent (own RNG state) and the item sums are fixed
+            // point, so the image does not depend on the order in which anything is answered: still bit-identical.
+            // ---- A: a new path vertex: distance sample, scan, do the trees matter?
+            if (alive && !need_path && phase == PH_NEW) {
+                if (COUNT) c_vertices++;
+                SECT(2);
+                did_work = true;
+                stage_distance<MEDIUM>(rng, inv_sigma_t, v_dmed, q_t);
+                const float tmin = ray_tmin(ro);
+                q_code = CODE_MISS;
+                scan_prims(sc, ro, rd, tmin, q_t, q_code);
+                if (COUNT) c_rays++;
+                phase = PH_HAVEP;
+                if (mesh_roots_hit(sc, ro, rd, tmin, q_t)) {
+                    SECT(21);
+                    const uint32_t lane = threadIdx.x & 63u;
+                    const uint32_t c = uint32_t(__builtin_ctz(~parked_mask));   // a free context (the caller of this stage had one)
+                    // the query
+                    const uint64_t m = __ballot(true);
+                    uint32_t base = 0u;
+                    if (mbcnt64(m) == 0u) base = atomicAdd(const_cast<uint32_t*>(wq), uint32_t(__popcll(m)));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    uint32_t* const e = ring_base + ((base + mbcnt64(m)) % kRingEntries) * kRingDwords;
+                    reinterpret_cast<f4v*>(e)[0] = f4v{ro.x, ro.y, ro.z, rd.x};
+                    reinterpret_cast<f4v*>(e)[1] = f4v{rd.y, rd.z, q_t, __uint_as_float(q_code)};
+                    reinterpret_cast<u4v*>(e)[2] = u4v{0u, 0u, lane | (c << 6) | (1u << 8), 0u};
+                    // the path
+                    uint32_t* const cx = ctx_base + c * kCtxFields * 64u + lane;
+                    cx[0 * 64] = __float_as_uint(ro.x); cx[1 * 64] = __float_as_uint(ro.y); cx[2 * 64] = __float_as_uint(ro.z);
+                    cx[3 * 64] = __float_as_uint(rd.x); cx[4 * 64] = __float_as_uint(rd.y); cx[5 * 64] = __float_as_uint(rd.z);
+                    cx[6 * 64] = __float_as_uint(P.x); cx[7 * 64] = __float_as_uint(P.y); cx[8 * 64] = __float_as_uint(P.z);
+                    cx[9 * 64] = __float_as_uint(Q.x); cx[10 * 64] = __float_as_uint(Q.y); cx[11 * 64] = __float_as_uint(Q.z);
+                    cx[12 * 64] = rng.s0; cx[13 * 64] = rng.s1; cx[14 * 64] = rng.s2; cx[15 * 64] = rng.s3;
+                    cx[16 * 64] = depth;
+                    cx[17 * 64] = __float_as_uint(v_dmed);
+                    parked_mask |= 1u << c;
+                    need_path = true;
+                    phase = PH_NEW;
+                }
+            }
+            // ---- B, L, C: event, next-event estimation, continue or end
+            if (alive && !need_path && phase == PH_HAVEP) {
+                SECT(3);
+                did_work = true;
+                const bool hit = q_code != CODE_MISS;
+                const bool ev_medium = v_dmed < (hit ? q_t : 400.f);
+                phase = PH_NEW;
+                if (!ev_medium && !hit) {
+                    SECT(4);
+                    acc_add(fma3(Q, env_color(sc, rd), P));
+                    need_path = true;
+                } else {
+                    V x, n = mk(0, 1, 0), mcol = mk(0, 0, 0), E;
+                    Mat mat = Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f};
+                    stage_event<COUNT>(a, tab, ro, rd, depth, ev_medium, v_dmed, q_t, q_code, 0u, x, n, mcol, mat, E);
+                    for (uint32_t li = 0; li < sc.n_lights; li++) {
+                        const Light L = uload(&sc.lights[li]);
+                        if (L.kind == L_AMBIENT) {
+                            E = fma3(xyz(L.color), ev_medium ? mcol : mat_color(mat), E);
+                        } else if (L.kind == L_OBJECT) {
+                            V I, wi;
+                            float dist;
+                            SECT(7);
+                            illuminate_object<false>(sc, L, x, rng, I, wi, dist, tab);
+                            if (L.twin_object >= 0) {
+                                SECT(8);
+                                const float tm = ray_tmin(x);
+                                float ts = dist * (1.f + 1e-3f);
+                                uint32_t cs = CODE_MISS;
+                                scan_prims(sc, x, wi, tm, ts, cs);
+                                if (COUNT) c_rays++;
+                                const bool twin = (L.twin_lo <= L.twin_hi) ? (cs >= L.twin_lo && cs <= L.twin_hi)
+                                                                           : (cs != CODE_MISS && code_object(sc, cs, 0u) == uint32_t(L.twin_object));
+                                if (cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) && twin) {   // (see DETACH = 1)
+                                    SECT(9);
+                                    V T;
+                                    if (ev_medium) {
+                                        T = (albedo_med * sc.medium_phase) * (I * mcol);
+                                    } else {
+                                        const V f = bsdf(mat, n, -normalize(rd), wi);
+                                        T = dot(wi, n) * (f * I);
+                                    }
+                                    if (!mesh_roots_hit(sc, x, wi, tm, ts)) {
+                                        E = E + T;
+                                    } else {
+                                        SECT(22);
+                                        const V cand = Q * T;
+                                        const uint64_t m = __ballot(true);
+                                        uint32_t base = 0u;
+                                        if (mbcnt64(m) == 0u) base = atomicAdd(const_cast<uint32_t*>(wq), uint32_t(__popcll(m)));
+                                        base = __builtin_amdgcn_readfirstlane(base);
+                                        uint32_t* const e = ring_base + ((base + mbcnt64(m)) % kRingEntries) * kRingDwords;
+                                        reinterpret_cast<f4v*>(e)[0] = f4v{x.x, x.y, x.z, wi.x};
+                                        reinterpret_cast<f4v*>(e)[1] = f4v{wi.y, wi.z, ts, cand.x};
+                                        reinterpret_cast<u4v*>(e)[2] = u4v{__float_as_uint(cand.y), __float_as_uint(cand.z), threadIdx.x & 63u, 0u};
+                                        ls_pend[threadIdx.x] = ls_pend[threadIdx.x] + 1u;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    V wi = mk(0, 0, 1), k = mk(0, 0, 0);
+                    const bool cont = stage_bounce<MEDIUM, COUNT>(a, albedo_med, rd, depth, ev_medium, n, mcol, mat, rng, wi, k);
+                    SECT(14);
+                    P = fma3(Q, E, P);
+                    if (cont) {
+                        Q = Q * k;
+                        ro = x;
+                        rd = wi;
+                        depth++;
+                    } else {
+                        acc_add(P);
+                        need_path = true;
+                    }
+                }
+            }
+            // ---- the walk session: every lane takes queries from the ring.  wq[0] = entries ever written (head), wq[1] = entries
+            // ever taken (tail), wq[2] = the oldest entry a lane still holds unfinished (low-water mark: entries from there on
+            // must not be overwritten), wq[4 + 2 c ..]: lanes whose parked context c has been answered.
+            {
+                const uint32_t head = __builtin_amdgcn_readfirstlane(wq[0]);
+                uint32_t tail = __builtin_amdgcn_readfirstlane(wq[1]);
+                const uint32_t low = __builtin_amdgcn_readfirstlane(wq[2]);
+                const bool susp = h_e != kNoEntry;
+                const uint32_t n_work = (head - tail) + uint32_t(__popcll(__ballot(susp)));
+                const bool worked = __ballot(did_work) != 0ull;
+                did_work = false;
+                // room for what one more trip can write (a primary query per lane + a shadow query per lane and twin light)
+                const bool tight = head - low > kRingEntries - 64u * (1u + a.n_twin_lights);
+                if (n_work == 0u) {
+                    // nothing to walk: if nothing else moved either, some bookkeeping disagrees -- let the items go rather than spin
+                    if (!worked && alive && need_path && have_item) { ls_pend[threadIdx.x] = 0u; parked_mask = 0u; }
+                } else if (head - tail >= a.stream_backlog || tight || !worked) {
+                    if (COUNT) c_wave[0] = c_wave[1] = 0;
+                    SECT(15);
+                    const uint32_t min_active = (tight || !worked) ? 1u : a.defer_stop;
+                    const BvhNode* const nodes = sc.nodes;
+                    const uint32_t root0 = uload(&sc.meshes[0]).root;
+                    // the walk at hand of this lane (entry h_e): ray, interval, closest hit so far; what the answer needs
+                    V wo = mk(0, 0, 0), wd = mk(0, 0, 1), inv = mk(0, 0, 0);
+                    float wt = 0.f, wtmin = 0.f;
+                    uint32_t wc = CODE_MISS, aux0 = 0u, aux1 = 0u, aux2 = 0u, meta = 0u;
+                    uint32_t cur = kWalkDone, sp = 0u, mesh = 0u;
+                    auto load_entry = [&](uint32_t idx) {
+                        const uint32_t* const e = ring_base + (idx % kRingEntries) * kRingDwords;
+                        const f4v e0 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(e));
+                        const f4v e1 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(e) + 1);
+                        const u4v e2 = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(e) + 2);
+                        wo = mk(e0.x, e0.y, e0.z);
+                        wd = mk(e0.w, e1.x, e1.y);
+                        wt = e1.z;
+                        aux0 = __float_as_uint(e1.w); aux1 = e2.x; aux2 = e2.y; meta = e2.z;
+                        wc = (meta >> 8) ? aux0 : CODE_MISS;   // a primary query starts from the scan's hit
+                        wtmin = ray_tmin(wo);
+                        inv = mk(rcp(wd.x), rcp(wd.y), rcp(wd.z));
+                    };
+                    if (susp) {
+                        load_entry(h_e);
+                        cur = walk.cur; sp = walk.sp; mesh = walk.mesh;
+                    }
+                    for (;;) {
+                        if (tail != head) {   // lanes without a walk take the next entries
+                            const bool free_lane = cur == kWalkDone;
+                            const uint64_t m = __ballot(free_lane);
+                            if (m != 0ull) {
+                                const uint32_t take = min(uint32_t(__popcll(m)), head - tail), rank = mbcnt64(m);
+                                if (free_lane && rank < take) {
+                                    h_e = tail + rank;
+                                    load_entry(h_e);
+                                    cur = root0; sp = 0u; mesh = 0u;
+                                }
+                                tail += take;
+                            }
+                        }
+                        const uint64_t act = __ballot(cur != kWalkDone);
+                        if (act == 0ull) break;
+                        if (tail == head && uint32_t(__popcll(act)) < min_active) break;   // the few that are left go on in the next session
+                        for (;;) {  // the descent (kWalkDone has the leaf bit set: finished lanes take no part)
+                            const bool inner = !(cur & BVH_LEAF);
+                            const uint32_t n_inner = uint32_t(__popcll(__ballot(inner)));
+                            if (n_inner == 0u) break;
+                            if (a.walk_leaf_quarters != 0u && 4u * uint32_t(__popcll(__ballot(!inner && cur != kWalkDone))) >= a.walk_leaf_quarters * n_inner) break;
+                            if (COUNT) c_wave[0]++;
+                            if (!inner) continue;
+                            const BvhNode nd = nodes[cur];
+                            if (COUNT) c_nodes++;
+                            float n0, f0, n1, f1;
+                            slab2(nd.lo0, nd.hi0, wo, inv, n0, f0);
+                            slab2(nd.lo1, nd.hi1, wo, inv, n1, f1);
+                            const bool h0 = fmaxf(n0, wtmin) <= fminf(f0, wt);
+                            const bool h1 = fmaxf(n1, wtmin) <= fminf(f1, wt);
+                            if (h0 && h1) {
+                                const bool first0 = n0 <= n1;
+                                if (sp < kStackRows) { stk[sp * stride] = first0 ? nd.e1 : nd.e0; sp++; }
+                                cur = first0 ? nd.e0 : nd.e1;
+                            } else if (h0 || h1) {
+                                cur = h0 ? nd.e0 : nd.e1;
+                            } else if (sp) {
+                                sp--;
+                                cur = stk[sp * stride];
+                            } else {
+                                cur = kWalkDone;
+                            }
+                        }
+                        if (COUNT) {
+                            uint32_t mx = 0;
+                            for (uint32_t k = 1; k <= 4u; k++)
+                                if (__ballot((cur & BVH_LEAF) && cur != kWalkDone && ((cur >> 26) & 31u) + 1u >= k) != 0ull) mx = k;
+                            c_wave[1] += mx;
+                        }
+                        if ((cur & BVH_LEAF) && cur != kWalkDone) {   // (lanes that are still descending go on with the next round)
+                            const uint32_t first = cur & BVH_INDEX_MASK;
+                            const uint32_t count = ((cur >> 26) & 31u) + 1u;
+                            TriScan nxt = sc.btri[first];
+                            for (uint32_t i = 0; i < count; i++) {  // the next triangle is in flight while this one is tested
+                                const TriScan tr = nxt;
+                                if (i + 1u < count) nxt = sc.btri[first + i + 1u];
+                                if (COUNT) c_btris++;
+                                const float t = hit_tri(tr.pn, tr.A, tr.B, wo, wd, wtmin, wt);
+                                if (t >= 0.f) { wt = t; wc = (K_BVHTRI << 28) | (first + i); }
+                            }
+                            // a shadow query is answered by its first triangle
+                            if ((meta >> 8) == 0u && wc != CODE_MISS) { sp = 0u; mesh = sc.n_mesh; }
+                            if (sp) {
+                                sp--;
+                                cur = stk[sp * stride];
+                            } else {
+                                cur = kWalkDone;
+                            }
+                        }
+                        if (cur == kWalkDone && mesh + 1u < sc.n_mesh && h_e != kNoEntry) {  // the next mesh's tree
+                            mesh++;
+                            cur = sc.meshes[mesh].root;
+                        }
+                        if (cur == kWalkDone && h_e != kNoEntry) {   // answered
+                            const uint32_t owner = meta & 63u;
+                            if ((meta >> 8) == 0u) {   // shadow: visible iff no tree holds a triangle in its interval
+                                if (COUNT) { SECT(18); }
+                                if (wc == CODE_MISS) {
+                                    const uint32_t ol = (threadIdx.x & ~63u) | owner;
+                                    atomicAdd(&acc64[ol], to_fixed(__uint_as_float(aux0)));
+                                    atomicAdd(&acc64[256u + ol], to_fixed(__uint_as_float(aux1)));
+                                    atomicAdd(&acc64[512u + ol], to_fixed(__uint_as_float(aux2)));
+                                }
+                                atomicSub(const_cast<uint32_t*>(ls_pend) + ((threadIdx.x & ~63u) | owner), 1u);
+                            } else {   // primary: the closest hit goes to the parked path, which becomes ready
+                                SECT(16);
+                                if ((wc >> 28) == K_BVHTRI) { SECT(17); }
+                                const uint32_t c = (meta >> 6) & 3u;
+                                uint32_t* const cx = ctx_base + c * kCtxFields * 64u + owner;
+                                cx[18 * 64] = __float_as_uint(wt);
+                                cx[19 * 64] = wc;
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the answer is in memory before the path is called ready
+                                atomicOr(const_cast<uint32_t*>(wq) + 4u + 2u * c + (owner >> 5), 1u << (owner & 31u));
+                            }
+                            h_e = kNoEntry;
+                        }
+                    }
+                    if (h_e != kNoEntry) {   // unfinished: the walk goes on in the next session from where it stands
+                        walk = WalkState{cur, sp, mesh};
+                        if (meta >> 8) {   // (a primary query's closest hit so far travels in its entry)
+                            uint32_t* const e = ring_base + (h_e % kRingEntries) * kRingDwords;
+                            e[6] = __float_as_uint(wt);
+                            e[7] = wc;
+                        }
+                    }
+                    // the oldest entry still in some lane's hands (entries are taken in order: everything before it is answered)
+                    uint32_t lw = h_e != kNoEntry ? tail - h_e : 0u;   // distance back from the tail
+                    for (int off = 32; off; off >>= 1) lw = max(lw, uint32_t(__shfl_xor(int(lw), off)));
+                    if ((threadIdx.x & 63u) == 0u) { wq[1] = tail; wq[2] = tail - lw; }
+                    if (COUNT) {
+                        for (int k = 0; k < 2; k++) {
+                            uint32_t v = c_wave[k];
+                            for (int off = 32; off; off >>= 1) v = max(v, uint32_t(__shfl_xor(int(v), off)));
+                            w_tot[k] += v;
+                        }
+                    }
+                }
+            }
+            if (++fuse == 0x01000000u) break;   // (no wave of a valid launch comes near 2^24 trips: the loop cannot spin for ever)
+            continue;
+        }
+        if constexpr (DETACH == 1) {
             // ---- per-mesh-tree flavour in a medium, shadow queries detached.  A primary query that has to walk a tree
             // parks its lane as below (PH_WAITP).  A shadow query that has to walk leaves its path instead: in a medium
             // the radiance of a path is linear in every light term (no firefly clamp, src/renderer.rs:229-232), so the
@@ -495,7 +833,7 @@ void render_kernel(const RenderArgs a) {
                                         for (uint32_t i = mbcnt64(m); i != 0u; i--) fr &= fr - 1u;   // ... this lane's: the rank-th of them
                                         if (fr != 0u) {
                                             const uint32_t e = uint32_t(__builtin_ctz(fr));
-                                            volatile uint32_t* const q = wq + 8u + e;
+                                            volatile uint32_t* const q = wq + 16u + e;
                                             q[0u * kQCap] = __float_as_uint(x.x); q[1u * kQCap] = __float_as_uint(x.y); q[2u * kQCap] = __float_as_uint(x.z);
                                             q[3u * kQCap] = __float_as_uint(wi.x); q[4u * kQCap] = __float_as_uint(wi.y); q[5u * kQCap] = __float_as_uint(wi.z);
                                             q[6u * kQCap] = __float_as_uint(ts);
@@ -564,7 +902,7 @@ void render_kernel(const RenderArgs a) {
                     uint32_t wc = q_code;
                     uint32_t cur = mode ? walk.cur : kWalkDone, sp = mode ? walk.sp : 0u, mesh = mode ? walk.mesh : 0u;
                     if (susp) {
-                        const volatile uint32_t* const q = wq + 8u + h_e;
+                        const volatile uint32_t* const q = wq + 16u + h_e;
                         wo = mk(__uint_as_float(q[0u * kQCap]), __uint_as_float(q[1u * kQCap]), __uint_as_float(q[2u * kQCap]));
                         wd = mk(__uint_as_float(q[3u * kQCap]), __uint_as_float(q[4u * kQCap]), __uint_as_float(q[5u * kQCap]));
                         wt = __uint_as_float(q[6u * kQCap]);
@@ -583,7 +921,7 @@ void render_kernel(const RenderArgs a) {
                                     for (uint32_t i = rank; i != 0u; i--) f &= f - 1u;
                                     h_e = uint32_t(__builtin_ctz(f));
                                     atomicOr(const_cast<uint32_t*>(wq) + 1, 1u << h_e);
-                                    const volatile uint32_t* const q = wq + 8u + h_e;
+                                    const volatile uint32_t* const q = wq + 16u + h_e;
                                     wo = mk(__uint_as_float(q[0u * kQCap]), __uint_as_float(q[1u * kQCap]), __uint_as_float(q[2u * kQCap]));
                                     wd = mk(__uint_as_float(q[3u * kQCap]), __uint_as_float(q[4u * kQCap]), __uint_as_float(q[5u * kQCap]));
                                     wt = __uint_as_float(q[6u * kQCap]);
@@ -658,7 +996,7 @@ void render_kernel(const RenderArgs a) {
                         }
                         if (cur == kWalkDone) {
                             if (mode == 2u) {   // a shadow query is answered: visible iff no tree holds a triangle in its interval
-                                const volatile uint32_t* const q = wq + 8u + h_e;
+                                const volatile uint32_t* const q = wq + 16u + h_e;
                                 const uint32_t owner = q[10u * kQCap];
                                 if (COUNT) { SECT(18); }
                                 if (wc == CODE_MISS) {
@@ -1097,8 +1435,12 @@ template <bool M, int B, bool C>
 static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t stream) {
     const size_t lds = B == 1 ? kMeshTreeBytes : B ? kStackBytes + kStateBytesBvh : kStateBytes;
     if constexpr (M && B == 1) {
+        if (a.detach == 2 && !a.sc.n_lparts) {
+            hipLaunchKernelGGL((render_kernel<true, 1, C, false, 2>), dim3(n_blocks), dim3(256), kDetachBytes, stream, a);
+            return hipGetLastError();
+        }
         if (a.detach && !a.sc.n_lparts) {
-            hipLaunchKernelGGL((render_kernel<true, 1, C, false, true>), dim3(n_blocks), dim3(256), kDetachBytes, stream, a);
+            hipLaunchKernelGGL((render_kernel<true, 1, C, false, 1>), dim3(n_blocks), dim3(256), kDetachBytes, stream, a);
             return hipGetLastError();
         }
     }
@@ -1120,9 +1462,12 @@ hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream) 
     if (m) return c ? launch_render_b<true, true>(a, b, n_blocks, stream) : launch_render_b<true, false>(a, b, n_blocks, stream);
     return c ? launch_render_b<false, true>(a, b, n_blocks, stream) : launch_render_b<false, false>(a, b, n_blocks, stream);
 }
-hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu, bool detach) {
+size_t stream_scratch_bytes_per_block() { return size_t(kWaveScratchDwords) * 4u * 4u; }
+hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu, int detach) {
+    if (detach == 2 && medium && bvh == 1)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)render_kernel<true, 1, false, false, 2>, 256, kDetachBytes);
     if (detach && medium && bvh == 1)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)render_kernel<true, 1, false, false, true>, 256, kDetachBytes);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)render_kernel<true, 1, false, false, 1>, 256, kDetachBytes);
     const void* f;
     if (medium) f = bvh == 2 ? (const void*)render_kernel<true, 2, false> : bvh == 1 ? (const void*)render_kernel<true, 1, false> : (const void*)render_kernel<true, 0, false>;
     else f = bvh == 2 ? (const void*)render_kernel<false, 2, false> : bvh == 1 ? (const void*)render_kernel<false, 1, false> : (const void*)render_kernel<false, 0, false>;

@@ -64,12 +64,15 @@ struct rpt_options {
     int64_t instancing = 1;         // meshes shared by several shapes are stored once and instanced
     int64_t bvh_leaf_max = 4;       // triangles per leaf of a mesh tree (read by rpt_scene_commit)
     int64_t bvh_max_depth = 20;     // a mesh tree deeper than this is rebuilt balanced (read by rpt_scene_commit)
+    int64_t bvh_sweep_below = 0;    // ranges of at most this many triangles are split by an exact SAH sweep instead of 16 bins (read by rpt_scene_commit; 0 = bins only)
     int64_t defer_stop = 16;        // still-walking lanes below which a wave leaves the walk (the rest resume later)
     int64_t walk_leaf_quarters = 6; // deferred walks: test the leaves when 4 x (lanes at a leaf) >= this x (lanes still descending); 0 = when all are there
     int64_t defer_lanes = 32;       // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
-    int64_t detach_shadows = 1;     // per-mesh-tree kernels in a medium: shadow queries that need a tree walk leave their path (0: they park the lane)
-    int64_t detach_lanes = 48;      // ... parked primary + queued shadow queries per wave that trigger a walk session
-    int64_t detach_trigger = 20;    // ... or this many queued shadow queries alone (the queue holds 32)
+    int64_t detach_shadows = 1;     // per-mesh-tree kernels in a medium: 1 = shadow queries that need a tree walk leave their path (0: they park
+                                    // the lane), 2 = every tree walk leaves its path ("streamed walks": ring + parked paths in memory)
+    int64_t stream_backlog = 128;   // detach_shadows = 2: queries in a wave's ring that trigger a walk session
+    int64_t detach_lanes = 44;      // ... parked primary + queued shadow queries per wave that trigger a walk session
+    int64_t detach_trigger = 28;    // ... or this many queued shadow queries alone (the queue holds 32)
     int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built
 };
 static rpt_options g_defaults;
@@ -89,9 +92,11 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "instancing") o.instancing = value;
     else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); o.defer_lanes = value; }
     else if (s == "bvh_leaf_max") { if (value < 1 || value > 16) return fail(RPT_ERR_INVALID, "bvh_leaf_max must be 1..16"); o.bvh_leaf_max = value; }
+    else if (s == "bvh_sweep_below") { if (value < 0) return fail(RPT_ERR_INVALID, "bvh_sweep_below must be >= 0"); o.bvh_sweep_below = value; }
     else if (s == "bvh_max_depth") { if (value < 1 || value > 20) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..20"); o.bvh_max_depth = value; }
     else if (s == "walk_leaf_quarters") { if (value < 0 || value > 256) return fail(RPT_ERR_INVALID, "walk_leaf_quarters must be 0..256"); o.walk_leaf_quarters = value; }
-    else if (s == "detach_shadows") o.detach_shadows = value;
+    else if (s == "detach_shadows") { if (value < 0 || value > 2) return fail(RPT_ERR_INVALID, "detach_shadows must be 0, 1 or 2"); o.detach_shadows = value; }
+    else if (s == "stream_backlog") { if (value < 1 || value > 256) return fail(RPT_ERR_INVALID, "stream_backlog must be 1..256"); o.stream_backlog = value; }
     else if (s == "detach_lanes") { if (value < 1 || value > 96) return fail(RPT_ERR_INVALID, "detach_lanes must be 1..96"); o.detach_lanes = value; }
     else if (s == "detach_trigger") { if (value < 1 || value > 32) return fail(RPT_ERR_INVALID, "detach_trigger must be 1..32"); o.detach_trigger = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
@@ -282,6 +287,36 @@ struct BvhBuilder {
     // centroid axis, whose depth is ceil(log2(n)) whatever the input looks like.
     bool balanced = false;
     int max_depth = 0;
+    uint32_t sweep_below = 0;   // ranges of at most this many items: exact SAH sweep over the sorted centroids of each axis
+    std::vector<float> sweep_area;
+    // Exact SAH split of [first, first + count): the range is left sorted along the best axis, `mid` is the split.
+    bool sweep_split(uint32_t first, uint32_t count, uint32_t& mid, float& cost_out) {
+        float best = std::numeric_limits<float>::infinity();
+        int best_axis = -1;
+        uint32_t best_k = 0;
+        sweep_area.resize(count);
+        for (int a = 0; a < 3; a++) {
+            std::sort(t.begin() + first, t.begin() + first + count, [a](const BTri& p, const BTri& q) { return p.c[a] < q.c[a] || (p.c[a] == q.c[a] && p.idx < q.idx); });
+            float l0[3], h0[3];
+            for (int k = 0; k < 3; k++) { l0[k] = std::numeric_limits<float>::infinity(); h0[k] = -l0[k]; }
+            for (uint32_t i = count; i-- > 1;) {   // sweep_area[i] = area of items [i, count)
+                for (int k = 0; k < 3; k++) { l0[k] = std::min(l0[k], t[first + i].lo[k]); h0[k] = std::max(h0[k], t[first + i].hi[k]); }
+                sweep_area[i] = area(l0, h0);
+            }
+            for (int k = 0; k < 3; k++) { l0[k] = std::numeric_limits<float>::infinity(); h0[k] = -l0[k]; }
+            for (uint32_t i = 1; i < count; i++) {   // left = [0, i), right = [i, count)
+                for (int k = 0; k < 3; k++) { l0[k] = std::min(l0[k], t[first + i - 1].lo[k]); h0[k] = std::max(h0[k], t[first + i - 1].hi[k]); }
+                const float cost = area(l0, h0) * float(i) + sweep_area[i] * float(count - i);
+                if (cost < best) { best = cost; best_axis = a; best_k = i; }
+            }
+        }
+        if (best_axis < 0) return false;
+        if (best_axis != 2)
+            std::sort(t.begin() + first, t.begin() + first + count, [best_axis](const BTri& p, const BTri& q) { return p.c[best_axis] < q.c[best_axis] || (p.c[best_axis] == q.c[best_axis] && p.idx < q.idx); });
+        mid = first + best_k;
+        cost_out = best;
+        return true;
+    }
     bool can_leaf(uint32_t first, uint32_t count) const {
         if (!solo || count == 1) return true;
         for (uint32_t i = first; i < first + count; i++)
@@ -323,7 +358,9 @@ struct BvhBuilder {
         if (leaf_ok && (count <= leaf_max || (depth >= kMaxDepth && count <= 32))) return make_leaf();
         int best_axis = -1, best_bin = -1;
         float best_cost = std::numeric_limits<float>::infinity();
-        for (int a = 0; a < 3 && !balanced; a++) {
+        uint32_t sweep_mid = 0;
+        const bool swept = !balanced && count <= sweep_below && depth < kMaxDepth && sweep_split(first, count, sweep_mid, best_cost);
+        for (int a = 0; a < 3 && !balanced && !swept; a++) {
             float ext = chi[a] - clo[a];
             if (!(ext > 0.f)) continue;
             uint32_t cnt[kBins] = {0};
@@ -368,7 +405,11 @@ struct BvhBuilder {
             }
         }
         uint32_t mid;
-        if (balanced) {
+        if (swept) {
+            float parent_cost = area(lo, hi) * float(count);
+            if (best_cost >= parent_cost && count <= 8 && leaf_ok) return make_leaf();
+            mid = sweep_mid;
+        } else if (balanced) {
             int axis = 0;
             for (int a = 1; a < 3; a++)
                 if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
@@ -434,6 +475,8 @@ struct rpt_scene {
         float* d_slab = nullptr;
         size_t slab_cap = 0;  // bytes
         unsigned long long* d_queue = nullptr;
+        uint32_t* d_stream = nullptr;   // streamed walks (detach = 2): rings and parked paths of the grid's waves
+        size_t stream_cap = 0;          // bytes
         hipEvent_t done = nullptr;  // recorded after the resolve of the last launch that used the set
         hipEvent_t launched = nullptr;  // recorded right before its render kernel
         hipStream_t stream = nullptr;
@@ -452,6 +495,7 @@ struct rpt_scene {
     size_t ev_count = 0;  // timed launches since the last rpt_get_timing_mean
     int last_blocks = 0;
     uint64_t prims_per_ray = 0;
+    uint32_t n_twin_lights = 0;  // Light::Objects with a twin among the scene's objects (the ones that can be visible)
     bool twins_scanned = false;  // every Light::Object that can be visible has its twin among the scanned records, as one range of hit codes
     uint64_t stats[16] = {0};
     void* photon = nullptr;  // PhotonMapDev*, owned by photon.hip
@@ -564,6 +608,7 @@ void rpt_scene_destroy(rpt_scene* s) {
         for (auto& ls : s->sets) {
             (void)hipFree(ls.d_slab);
             (void)hipFree(ls.d_queue);
+            (void)hipFree(ls.d_stream);
             if (ls.done) (void)hipEventDestroy(ls.done);
             if (ls.launched) (void)hipEventDestroy(ls.launched);
         }
@@ -848,6 +893,7 @@ struct Flattener {
         {
             BvhBuilder b{bt, tmp};
             b.leaf_max = uint32_t(s->opt.bvh_leaf_max);
+            b.sweep_below = uint32_t(std::min<int64_t>(s->opt.bvh_sweep_below, 1 << 30));
             b.build(0, 0, uint32_t(nt), 0);
             depth = b.max_depth;
         }
@@ -855,6 +901,7 @@ struct Flattener {
             tmp.assign(1, TmpNode{});
             BvhBuilder b{bt, tmp};
             b.leaf_max = uint32_t(s->opt.bvh_leaf_max);
+            b.sweep_below = 0;
             b.balanced = true;
             b.build(0, 0, uint32_t(nt), 0);
             depth = b.max_depth;
@@ -1420,8 +1467,11 @@ struct Flattener {
         v.hdri_h = s->hdri_h;
         s->prims_per_ray = sph.size() + cub.size() + pln.size() + tri.size() + aabb.size() + rect.size() + (has_shell ? 1 : 0);
         s->twins_scanned = true;
-        for (const Light& L : lights)
+        s->n_twin_lights = 0;
+        for (const Light& L : lights) {
+            if (L.kind == L_OBJECT && L.twin_object >= 0) s->n_twin_lights++;
             if (L.kind == L_OBJECT && L.twin_object >= 0 && !(L.twin_lo <= L.twin_hi)) s->twins_scanned = false;
+        }
         s->stats[0] = sph.size(); s->stats[1] = cub.size(); s->stats[2] = pln.size(); s->stats[3] = tri.size();
         s->stats[4] = aabb.size(); s->stats[5] = rect_sh.size(); s->stats[6] = btri.size(); s->stats[7] = nodes.size();
         // scan-record bytes every closest-hit query walks (the uniform part of the algorithmic bytes)
@@ -1600,7 +1650,11 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     // Detached shadow queries: in a medium (a path's radiance is linear in its light terms), per-mesh trees, and every
     // light that can be visible has its twin among the scanned records as one range of hit codes.
     a.detach = 0;
-    if (s->opt.detach_shadows && s->view.has_medium && bvh_mode(s->view) == 1 && s->view.n_lparts == 0 && s->twins_scanned) a.detach = 1;
+    if (s->opt.detach_shadows && s->view.has_medium && bvh_mode(s->view) == 1 && s->view.n_lparts == 0 && s->twins_scanned)
+        a.detach = (s->opt.detach_shadows == 2 && s->n_twin_lights <= 3) ? 2u : 1u;
+    a.stream_backlog = uint32_t(s->opt.stream_backlog);
+    a.n_twin_lights = s->n_twin_lights;
+    a.stream_scratch = nullptr;   // (run_render sizes it for the grid)
     a.detach_trigger = uint32_t(s->opt.detach_trigger);
     if (a.detach) {
         a.defer_lanes = uint32_t(s->opt.detach_lanes);
@@ -1661,11 +1715,23 @@ extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm
     HIP_TRY(hipEventRecord(mine.done, st));
     return RPT_OK;
 }
-static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st) {
+static int run_render(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a_in, double* d_out, hipStream_t st) {
+    RenderArgs a = a_in;
     int bpc = int(s->opt.blocks_per_cu);
     if (bpc <= 0) {
-        HIP_TRY(render_occupancy(a.sc.has_medium != 0, bvh_mode(a.sc), &bpc, a.detach != 0));
+        HIP_TRY(render_occupancy(a.sc.has_medium != 0, bvh_mode(a.sc), &bpc, int(a.detach)));
         if (bpc < 1) bpc = 1;
+    }
+    if (a.detach == 2) {   // the waves' rings and parked paths: per launch set, like the slab (two launches may be in flight)
+        rpt_scene::LaunchSet& ls = s->sets[s->sets[0].d_queue == a.queue ? 0 : 1];
+        const size_t need = size_t(s->n_cus) * size_t(bpc) * stream_scratch_bytes_per_block();
+        if (need > ls.stream_cap) {
+            if (ls.d_stream) HIP_TRY(hipFree(ls.d_stream));
+            ls.d_stream = nullptr; ls.stream_cap = 0;
+            HIP_TRY(hipMalloc((void**)&ls.d_stream, need));
+            ls.stream_cap = need;
+        }
+        a.stream_scratch = ls.d_stream;
     }
     return rpti::run_persistent(s, prm, a, d_out, st, bpc,
                                 [](const RenderArgs& ra, int nb, hipStream_t stream) { return launch_render(ra, nb, stream); }, true);

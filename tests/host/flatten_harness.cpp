@@ -6,7 +6,8 @@
 #include "../../rpt_amd/csrc/rpt_capi.cpp"
 namespace rptg {
 hipError_t launch_render(const RenderArgs&, int, hipStream_t) { return hipSuccess; }
-hipError_t render_occupancy(bool, int, int* b, bool) { *b = 4; return hipSuccess; }
+hipError_t render_occupancy(bool, int, int* b, int) { *b = 4; return hipSuccess; }
+size_t stream_scratch_bytes_per_block() { return 0; }
 int bvh_mode(const SceneView& sc) { return sc.scene_bvh ? 2 : (sc.n_nodes ? 1 : 0); }
 hipError_t launch_resolve(const RenderArgs&, double, double*, hipStream_t) { return hipSuccess; }
 hipError_t launch_intersect(const SceneView&, uint64_t, const float*, const float*, float*, int32_t*, float*, bool, hipStream_t) { return hipSuccess; }

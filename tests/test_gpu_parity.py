@@ -354,15 +354,26 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
         # detached shadow queries (kernels.hip, DETACH): when a walk session starts (waiting + queued queries, queued alone), when
         # it is left, a queue that overflows at every vertex (trigger 32 with sessions that start late) -- not one bit
         detached = [render_detached(*v) for v in ((48, 20, 16), (1, 1, 1), (96, 32, 32), (64, 32, 1), (8, 3, 5), (48, 20, 16, 0), (96, 32, 8, 64))] if fog else []
+        # streamed walks (DETACH = 2): primary queries leave as well, their paths wait in memory; session threshold and exit rule
+        streamed = []
+        if fog:
+            rpt_amd.set_option("detach_shadows", 2)
+            for backlog, stop in ((128, 16), (1, 1), (256, 64), (64, 32), (200, 1)):
+                rpt_amd.set_option("stream_backlog", backlog)
+                streamed.append(render(32, stop))
     finally:
+        rpt_amd.set_option("detach_shadows", 1)
+        rpt_amd.set_option("stream_backlog", 128)
         rpt_amd.set_option("defer_lanes", 32)
         rpt_amd.set_option("defer_stop", 16)
         rpt_amd.set_option("walk_leaf_quarters", 6)
-        rpt_amd.set_option("detach_lanes", 48)
-        rpt_amd.set_option("detach_trigger", 20)
+        rpt_amd.set_option("detach_lanes", 44)
+        rpt_amd.set_option("detach_trigger", 28)
     for f in frames[1:]:
         assert np.array_equal(frames[0], f)
     for f in detached[1:]:
+        assert np.array_equal(detached[0], f)
+    for f in streamed:   # same paths, same fixed-point sums as the detached form: the very same frame
         assert np.array_equal(detached[0], f)
     exp = _oracle(sc).render(cam, w, h, spp, 3, seed=6, robust=1)
     assert np.all(np.isfinite(frames[0])) and exp.mean() > 0

@@ -2,7 +2,9 @@
 form, over "detach_lanes" (parked primary + queued shadow queries that trigger a walk session), "detach_trigger" (queued
 shadow queries alone) and "defer_stop".  All detached frames must be bit-identical; the parked frame differs in the last bits
 (another order of the same sums).
-Usage: python tools/detach_sweep.py [workload] [width] [spp] [lanes:trigger:stop[:walk_leaf_quarters] ...]"""
+A value that starts with "s" is the streamed form (detach_shadows = 2: primary queries leave as well, their paths wait in
+memory): s:backlog:stop[:walk_leaf_quarters].
+Usage: python tools/detach_sweep.py [workload] [width] [spp] [lanes:trigger:stop[:walk_leaf_quarters] | s:backlog:stop[:q] ...]"""
 import os
 import sys
 
@@ -15,7 +17,7 @@ from rpt_amd import Renderer, scenes  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "C5"
 width = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-values = [tuple(int(x) for x in v.split(":")) for v in sys.argv[4:]] or [(48, 20, 16), (32, 20, 16), (40, 20, 16), (56, 24, 16), (64, 28, 16), (48, 20, 8),
+values = [tuple(x if x == "s" else int(x) for x in v.split(":")) for v in sys.argv[4:]] or [(48, 20, 16), (32, 20, 16), (40, 20, 16), (56, 24, 16), (64, 28, 16), (48, 20, 8),
                                                                           (48, 20, 24), (48, 12, 16), (48, 28, 16), (64, 32, 24)]
 scene, cam, cfg = scenes.CONFIGS[name]()
 rpt_amd.set_option("timing", 1)
@@ -35,14 +37,20 @@ def run(label):
 
 rpt_amd.set_option("detach_shadows", 0)
 parked = run("parked shadow queries (32:16)      ")
-rpt_amd.set_option("detach_shadows", 1)
 ref = None
 for v in values:
-    rpt_amd.set_option("detach_lanes", v[0])
-    rpt_amd.set_option("detach_trigger", v[1])
+    if v[0] == "s":
+        rpt_amd.set_option("detach_shadows", 2)
+        rpt_amd.set_option("stream_backlog", v[1])
+        label = f"streamed backlog:stop={v[1]:3d}:{v[2]:2d}      "
+    else:
+        rpt_amd.set_option("detach_shadows", 1)
+        rpt_amd.set_option("detach_lanes", v[0])
+        rpt_amd.set_option("detach_trigger", v[1])
+        label = f"detached lanes:trigger:stop={v[0]:2d}:{v[1]:2d}:{v[2]:2d}"
     rpt_amd.set_option("defer_stop", v[2])
     rpt_amd.set_option("walk_leaf_quarters", v[3] if len(v) > 3 else 6)
-    img = run(f"detached lanes:trigger:stop={v[0]:2d}:{v[1]:2d}:{v[2]:2d}" + (f" leaf quarters {v[3]:2d}" if len(v) > 3 else "                 "))
+    img = run(label + (f" leaf quarters {v[3]:2d}" if len(v) > 3 else "                 "))
     if ref is None:
         ref = img
         d = img - parked
