@@ -519,6 +519,11 @@ class Renderer {
     RgbImage photon_beam_query_beam_render(size_t n) { return photon_render(n, PhotonBeamBeam); }   // :646-648
     RgbImage photon_map_render(size_t n) { return photon_render(n, PhotonMap); }                     // :650-652
 
+    // One batch of a multi-GPU render: this rank's tiles into the device frame d_frame
+    // (width * height * 3 f64 on this renderer's device), then the gather of every rank's tiles onto rank 0, all
+    // enqueued on hip_stream.  shard(rank, count) must match the communicator.
+    void sample_sharded(uint32_t iterations, class Comm& comm, void* d_frame, void* hip_stream = nullptr);
+
     // Renderer::sample (renderer.rs:158-171): the call that crosses the C ABI.
     void sample(uint32_t iterations, Buffer& buffer) {  // renderer.rs:158-171; the batch stays on the device
         commit();
@@ -569,5 +574,40 @@ class Renderer {
     rpt_scene* handle_ = nullptr;
     uint32_t sample_offset_ = 0;
 };
+
+// The frame exchange between the GPUs of one node (rpt_comm_*, rpt_gather_frame_device): one process per GPU, rank 0
+// assembles the image from the tiles every rank owns.  Rank 0 draws the id (Comm::unique_id) and hands its 128 bytes to
+// the other ranks by whatever means the launcher offers.
+class Comm {
+  public:
+    using Id = std::array<unsigned char, RPT_COMM_ID_BYTES>;
+    static Id unique_id() {
+        Id id{};
+        check(rpt_comm_unique_id(id.data()));
+        return id;
+    }
+    Comm(const Id& id, int rank, int n_ranks, int device) { check(rpt_comm_create(id.data(), rank, n_ranks, device, &h_)); }
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    ~Comm() { rpt_comm_destroy(h_); }
+    int rank() const { int r = 0; check(rpt_comm_rank(h_, &r, nullptr)); return r; }
+    int size() const { int n = 0; check(rpt_comm_rank(h_, nullptr, &n)); return n; }
+    // Collective: d_shard = this rank's frame, d_frame = where rank 0 assembles (may be d_shard; ignored elsewhere).
+    void gather(uint32_t width, uint32_t height, const void* d_shard, void* d_frame, void* hip_stream = nullptr, bool loopback = false) {
+        check(rpt_gather_frame_device(h_, width, height, d_shard, d_frame, loopback ? RPT_GATHER_LOOPBACK : 0u, hip_stream));
+    }
+    rpt_comm* raw() const { return h_; }
+
+  private:
+    rpt_comm* h_ = nullptr;
+};
+inline void Renderer::sample_sharded(uint32_t iterations, Comm& comm, void* d_frame, void* hip_stream) {
+    commit();
+    rpt_camera cam = camera_.desc();
+    rpt_render_params rp{p_.width, p_.height, p_.exposure_value, p_.max_bounces, p_.shard_rank, p_.shard_count};
+    check(rpt_render_sample_device(handle_, &cam, &rp, iterations, p_.seed, sample_offset_, d_frame, hip_stream));
+    sample_offset_ += iterations;
+    comm.gather(p_.width, p_.height, d_frame, d_frame, hip_stream);
+}
 
 }  // namespace rpt

@@ -290,6 +290,21 @@ int rpt_frame_pack_device(uint32_t width, uint32_t height, uint32_t rank, uint32
 int rpt_frame_unpack_device(uint32_t width, uint32_t height, uint32_t rank, uint32_t n_ranks, const void* d_packed,
                             void* d_frame, void* hip_stream);
 
+/* ---- reference-epsilon mode: rpt_scene_set_option(scene, "epsilon_policy", 1) before rpt_scene_commit ----
+ * The fp32 path replaces the reference's 1e-12 epsilons (src/renderer.rs:17, 348, 396, 420), which fp32 cannot resolve, by
+ * scaled tolerances and a geometric twin test; its images are brighter than rpt's by the energy rpt loses to
+ * self-intersections and near-miss shadow rejections.  A scene committed with epsilon_policy = 1
+ * is rendered by a second, fp64 kernel that follows the reference literally instead: every object tested per ray in scene
+ * order as the generic shape under its own Transformed matrices, t_min = 1e-12, light visible iff |hit - dist| < 1e-12,
+ * f64 colours, no fused multiply-adds.  Same entry points (rpt_render_sample*, rpt_render_into_buffer), same RNG streams,
+ * same sharding; several times slower.  Supported: spheres, cubes, planes, meshes (scanned triangle by triangle), all
+ * materials, lights and media, Environment::Color.  Refused with RPT_ERR_UNSUPPORTED: KdTree groups, Environment::Hdri,
+ * photon mapping.
+ * rpt_debug_epsilon_counters (option "counters" = 1): [0] closest-hit queries, [1] accepted hits, [2] accepted hits with
+ * t < 1e-9 (1 + |origin|) -- a ray hitting the surface it starts on --, [3] shadow tests, [4] passed, [5] failed although
+ * |hit - dist| < 1e-6 dist -- the light's own surface missed by rounding --, [6] camera samples, [7] path vertices. */
+int rpt_debug_epsilon_counters(rpt_scene*, uint64_t out[8]);
+
 /* ---- device self-test hooks (each runs the device function in a one-block kernel) ---- */
 int rpt_debug_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out);
 int rpt_debug_material_sample_f(const rpt_material*, uint64_t n, const float* normals, const float* wos,

@@ -125,6 +125,7 @@ SYMBOLS = [
     ("rpt_frame_pack_layout", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("rpt_frame_pack_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
     ("rpt_frame_unpack_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    ("rpt_debug_epsilon_counters", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("rpt_debug_rng_u32", C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("rpt_debug_material_sample_f", C.c_int,
      [C.POINTER(MaterialDesc), C.c_uint64, _P, _P, C.c_uint64, _P, _P, _P]),

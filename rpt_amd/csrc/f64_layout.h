@@ -61,6 +61,7 @@ struct Args {
     uint32_t n_owned, tiles_x, _pad;
     const uint32_t* tiles;
     uint64_t seed_mixed;
+    double medium_color[3], medium_color_hi[3];   // Medium::color: hex_color(0xD2B48C), or blue (y <= 250) / red for the glowing fog
     double dim;       // max(width, height) as f64 (src/renderer.rs:174)
     double scale;     // 2^exposure_value
     double* out;      // width * height * 3

@@ -16,6 +16,7 @@ struct SceneDev {
     int device, n_cus;
     rptg::SceneView view;
     int first_object_light;  // index into scene.lights of the first Light::Object, or -1
+    bool epsilon64;          // committed in the reference-epsilon mode (fp64 path tracer only: photon mapping is refused)
 };
 SceneDev scene_dev(rpt_scene* s);
 void*& photon_slot(rpt_scene* s);  // owned by photon.hip (PhotonMapDev*), released through photon_release

@@ -33,6 +33,7 @@ struct RenderArgs {
                                   // in LDS); 2 = every tree walk leaves its path (ring + parked path contexts in stream_scratch)
     uint32_t detach_trigger;      // detach = 1: a walk session is due as soon as the queue holds this many (1..32)
     uint32_t stream_backlog;      // detach = 2: ... as soon as the ring holds this many queries
+    uint32_t stream_contexts;     // detach = 2: parked paths per lane (1..6)
     uint32_t n_twin_lights;       // object lights that can be visible (each may write one shadow query per lane and trip)
     uint32_t* stream_scratch;     // detach = 2: stream_scratch_bytes_per_block() per block of the grid
 };
@@ -73,4 +74,9 @@ hipError_t launch_debug_bsdf(const Material& m, uint64_t n, const float* d_n, co
 hipError_t launch_debug_camera(const CameraG& cam, uint32_t w, uint32_t h, uint64_t seed_mixed, uint32_t sample,
                                float* d_o, float* d_d, hipStream_t s);
 
+}  // namespace rptg
+namespace rpt64 { struct Args; }
+namespace rptg {
+// Reference-epsilon mode (kernels_f64.hip): one thread per owned pixel, frame written directly.
+hipError_t launch_render_f64(const rpt64::Args& a, hipStream_t stream);
 }  // namespace rptg

@@ -55,6 +55,9 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 #ifndef RPT_MIN_WAVES_MESH
 #define RPT_MIN_WAVES_MESH 4  // per-mesh-tree instantiations (BVH = 1)
 #endif
+#ifndef RPT_MIN_WAVES_STREAM
+#define RPT_MIN_WAVES_STREAM 4  // per-mesh-tree instantiation with streamed walks (DETACH = 2); 3 (168 VGPRs) has no scratch
+#endif
 #ifndef RPT_MIN_WAVES_SCAN
 #define RPT_MIN_WAVES_SCAN 5  // linear-scan instantiations (BVH = 0) without a medium: 96 VGPRs
 #endif
@@ -80,7 +83,7 @@ static_assert(kDetachAccBase % 2u == 0u, "the 64-bit accumulators are 8-byte ali
 // part), a FIFO ring of queries and kCtxMax parked path contexts per lane.
 static constexpr uint32_t kRingEntries = 512u;   // queries a wave can hold; a session is forced before the ring could overflow
 static constexpr uint32_t kRingDwords = 12u;     // origin, direction | end of the interval, 3 words by kind | meta, pad (3 x 16 B)
-static constexpr uint32_t kCtxMax = 3u;          // parked paths per lane
+static constexpr uint32_t kCtxMax = 6u;          // parked paths per lane (RenderArgs::stream_contexts of them are used)
 static constexpr uint32_t kCtxFields = 20u;      // origin, direction, P, Q, RNG state, depth, medium distance, answer (t, code)
 static constexpr uint32_t kWaveScratchDwords = kRingEntries * kRingDwords + kCtxMax * kCtxFields * 64u;
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -206,7 +209,7 @@ RPT_DEV bool stage_bounce(const RenderArgs& a, float albedo_med, V rd, uint32_t 
 // DETACH (per-mesh-tree kernels in a medium): shadow queries that need a tree walk leave their path (see the loop body).
 // DETACH = 2: primary queries leave as well -- their paths wait in memory and the lane goes on with another one.
 template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false, int DETACH = 0>
-__global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : BVH == 1 ? RPT_MIN_WAVES_MESH : RPT_MIN_WAVES)
+__global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : BVH == 1 ? (DETACH == 2 ? RPT_MIN_WAVES_STREAM : RPT_MIN_WAVES_MESH) : RPT_MIN_WAVES)
 void render_kernel(const RenderArgs a) {
     static_assert(DETACH == 0 || (MEDIUM && BVH == 1 && !GROUPS), "detached tree walks: per-mesh-tree kernels in a medium only");
     extern __shared__ uint32_t dyn_lds[];
@@ -328,7 +331,7 @@ void render_kernel(const RenderArgs a) {
             if (alive && need_path && parked_mask != 0u) {
                 const uint32_t lane = threadIdx.x & 63u;
                 uint32_t rc = kCtxMax;
-                for (uint32_t c = 0; c < kCtxMax; c++) {
+                for (uint32_t c = 0; c < a.stream_contexts; c++) {
                     const uint32_t rdy = wq[4u + 2u * c + (lane >> 5)];
                     if (rc == kCtxMax && ((parked_mask >> c) & 1u) && ((rdy >> (lane & 31u)) & 1u)) rc = c;
                 }
@@ -351,7 +354,8 @@ void render_kernel(const RenderArgs a) {
                     did_work = true;
                 }
             }
-            want = want && parked_mask == 0u;
+            // (a lane that has just taken a path back is not looking for an item, whatever it was a moment ago)
+            want = want && need_path && parked_mask == 0u;
         }
         if (__any(want)) {
             const auto& ka = *kernarg_args<RenderArgs>();   // item bookkeeping reads its arguments here, not from registers held since kernel entry
@@ -438,7 +442,7 @@ void render_kernel(const RenderArgs a) {
         }
         // (DETACH: a lane whose finished item still waits for shadow answers has no sample to start; DETACH = 2: nor has a
         // lane with every context parked)
-        if (need_path && alive && !(DETACH != 0 && item_done) && !(DETACH == 2 && uint32_t(__popc(parked_mask)) >= kCtxMax)) {
+        if (need_path && alive && !(DETACH != 0 && item_done) && !(DETACH == 2 && uint32_t(__popc(parked_mask)) >= a.stream_contexts)) {
             if (alive) {  // src/renderer.rs:179-181
                 const auto& ka = *kernarg_args<RenderArgs>();
                 SECT(1);
@@ -500,7 +504,7 @@ void render_kernel(const RenderArgs a) {
                     uint32_t* const e = ring_base + ((base + mbcnt64(m)) % kRingEntries) * kRingDwords;
                     reinterpret_cast<f4v*>(e)[0] = f4v{ro.x, ro.y, ro.z, rd.x};
                     reinterpret_cast<f4v*>(e)[1] = f4v{rd.y, rd.z, q_t, __uint_as_float(q_code)};
-                    reinterpret_cast<u4v*>(e)[2] = u4v{0u, 0u, lane | (c << 6) | (1u << 8), 0u};
+                    reinterpret_cast<u4v*>(e)[2] = u4v{0u, 0u, lane | (c << 6) | (1u << 12), 0u};
                     // the path
                     uint32_t* const cx = ctx_base + c * kCtxFields * 64u + lane;
                     cx[0 * 64] = __float_as_uint(ro.x); cx[1 * 64] = __float_as_uint(ro.y); cx[2 * 64] = __float_as_uint(ro.z);
@@ -610,6 +614,7 @@ void render_kernel(const RenderArgs a) {
                 } else if (head - tail >= a.stream_backlog || tight || !worked) {
                     if (COUNT) c_wave[0] = c_wave[1] = 0;
                     SECT(15);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this trip's entries are in memory before any lane reads them
                     const uint32_t min_active = (tight || !worked) ? 1u : a.defer_stop;
                     const BvhNode* const nodes = sc.nodes;
                     const uint32_t root0 = uload(&sc.meshes[0]).root;
@@ -627,7 +632,7 @@ void render_kernel(const RenderArgs a) {
                         wd = mk(e0.w, e1.x, e1.y);
                         wt = e1.z;
                         aux0 = __float_as_uint(e1.w); aux1 = e2.x; aux2 = e2.y; meta = e2.z;
-                        wc = (meta >> 8) ? aux0 : CODE_MISS;   // a primary query starts from the scan's hit
+                        wc = (meta >> 12) ? aux0 : CODE_MISS;   // a primary query starts from the scan's hit
                         wtmin = ray_tmin(wo);
                         inv = mk(rcp(wd.x), rcp(wd.y), rcp(wd.z));
                     };
@@ -697,7 +702,7 @@ void render_kernel(const RenderArgs a) {
                                 if (t >= 0.f) { wt = t; wc = (K_BVHTRI << 28) | (first + i); }
                             }
                             // a shadow query is answered by its first triangle
-                            if ((meta >> 8) == 0u && wc != CODE_MISS) { sp = 0u; mesh = sc.n_mesh; }
+                            if ((meta >> 12) == 0u && wc != CODE_MISS) { sp = 0u; mesh = sc.n_mesh; }
                             if (sp) {
                                 sp--;
                                 cur = stk[sp * stride];
@@ -711,7 +716,7 @@ void render_kernel(const RenderArgs a) {
                         }
                         if (cur == kWalkDone && h_e != kNoEntry) {   // answered
                             const uint32_t owner = meta & 63u;
-                            if ((meta >> 8) == 0u) {   // shadow: visible iff no tree holds a triangle in its interval
+                            if ((meta >> 12) == 0u) {   // shadow: visible iff no tree holds a triangle in its interval
                                 if (COUNT) { SECT(18); }
                                 if (wc == CODE_MISS) {
                                     const uint32_t ol = (threadIdx.x & ~63u) | owner;
@@ -723,11 +728,11 @@ void render_kernel(const RenderArgs a) {
                             } else {   // primary: the closest hit goes to the parked path, which becomes ready
                                 SECT(16);
                                 if ((wc >> 28) == K_BVHTRI) { SECT(17); }
-                                const uint32_t c = (meta >> 6) & 3u;
+                                const uint32_t c = (meta >> 6) & 15u;
                                 uint32_t* const cx = ctx_base + c * kCtxFields * 64u + owner;
                                 cx[18 * 64] = __float_as_uint(wt);
                                 cx[19 * 64] = wc;
-                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the answer is in memory before the path is called ready
+                                // (the path is looked for at the top of the next trip, behind the fence that ends this session)
                                 atomicOr(const_cast<uint32_t*>(wq) + 4u + 2u * c + (owner >> 5), 1u << (owner & 31u));
                             }
                             h_e = kNoEntry;
@@ -735,12 +740,13 @@ void render_kernel(const RenderArgs a) {
                     }
                     if (h_e != kNoEntry) {   // unfinished: the walk goes on in the next session from where it stands
                         walk = WalkState{cur, sp, mesh};
-                        if (meta >> 8) {   // (a primary query's closest hit so far travels in its entry)
+                        if (meta >> 12) {   // (a primary query's closest hit so far travels in its entry)
                             uint32_t* const e = ring_base + (h_e % kRingEntries) * kRingDwords;
                             e[6] = __float_as_uint(wt);
                             e[7] = wc;
                         }
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every answer is in memory before any path is taken back
                     // the oldest entry still in some lane's hands (entries are taken in order: everything before it is answered)
                     uint32_t lw = h_e != kNoEntry ? tail - h_e : 0u;   // distance back from the tail
                     for (int off = 32; off; off >>= 1) lw = max(lw, uint32_t(__shfl_xor(int(lw), off)));

@@ -384,6 +384,12 @@ R64_DEV bool light_visible(const Args& a, D pos, D wi, double dist) {
     return miss < kEps;
 }
 
+// Medium::color (src/medium.rs:80-122): hex_color(0xD2B48C) for homogeneous_isotropic; blue below / red above y = 250 for
+// colored_glowing_fog.  The host passes the two colours (color.rs:10-15 evaluated in fp64).
+R64_DEV D medium_color(const Args& a, D pos) {
+    return (a.sc.medium_kind == 1 && pos.y > 250.0) ? ld(a.medium_color_hi) : ld(a.medium_color);
+}
+
 __global__ __launch_bounds__(256) void render_f64_kernel(const Args a) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= a.n_owned) return;
@@ -393,7 +399,6 @@ __global__ __launch_bounds__(256) void render_f64_kernel(const Args a) {
     if (x >= a.width || y >= a.height) return;
     const Scene& sc = a.sc;
     const bool medium = sc.has_medium != 0;
-    const double ext = sc.absorption + sc.scattering;
     // src/renderer.rs:174-176 (2 * x + 1 and 2 * (h - y) - 1 in u32, like the reference)
     const double xn = (double(2u * x + 1u) - double(a.width)) / a.dim;
     const double yn = (double(2u * (a.height - y) - 1u) - double(a.height)) / a.dim;
@@ -406,13 +411,14 @@ __global__ __launch_bounds__(256) void render_f64_kernel(const Args a) {
         D ro, rd;
         cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
         if (a.counters) atomicAdd(&a.counters[6], 1ull);
-        // trace_ray (src/renderer.rs:187-322) as a loop: radiance of the path so far = min(P + Q x, R), x = what the rest returns
+        // trace_ray (src/renderer.rs:187-322) as a loop: the radiance of the path = min(P + Q x, R) per channel, x = what the
+        // rest of the path returns (closed under x -> E + min(k x, 100), :308-313; in a medium there is no clamp, R = inf)
         D P = mk(0, 0, 0), Q = mk(1, 1, 1), R = mk(kInf, kInf, kInf);
         uint32_t depth = 0;
         for (;;) {
             if (a.counters) atomicAdd(&a.counters[7], 1ull);
             double dmed = kInf;
-            if (medium) dmed = -log(rng.range(0.0, 1.0)) / ext;   // Medium::sample_d, src/medium.rs:133-146
+            if (medium) dmed = -log(rng.range(0.0, 1.0)) / (sc.absorption + sc.scattering);   // Medium::sample_d, src/medium.rs:133-146
             const D wo = -normalize(rd);
             Hit h;
             const int obj = closest_hit(a, ro, rd, h);
@@ -423,22 +429,87 @@ __global__ __launch_bounds__(256) void render_f64_kernel(const Args a) {
                 color = color + vmin(P + Q * env, R);
                 break;
             }
-            D E, k = mk(0, 0, 0);
-            D pos;
+            D E, k = mk(0, 0, 0), pos, wi_next = mk(0, 0, 1);
             bool cont = false;
-            D wi_next = mk(0, 0, 1);
             if (ev_medium) {   // :243-283
                 pos = ro + dmed * rd;
-                const bool hi = sc.medium_kind == 1 && pos.y > 250.0;   // colored_glowing_fog, src/medium.rs:99-122
-                const D mcol = sc.medium_kind == 1 ? (hi ? mk(1.0, 0.0, 0.0) : mk(0.0, 0.0, 1.0)) : mk(sc.env[0] * 0.0 + 0.0, 0.0, 0.0);
-                (void)mcol;
-                break;   // replaced below (see medium_color)
+                const D mcol = medium_color(a, pos);
+                const double scat = sc.scattering, extinction = sc.absorption + sc.scattering;
+                const double emm = sc.medium_kind == 1 ? 10.0 : 0.0;
+                const double phase = sc.medium_kind == 1 ? 1.0 / 4.0 * kPi : 1.0 / (4.0 * kPi);   // (sic, src/medium.rs:113)
+                E = depth == 0 ? emm * mcol : mk(0, 0, 0);
+                // sample_lights_for_media, :325-359
+                for (uint32_t li = 0; li < sc.n_lights; li++) {
+                    const Light& L = sc.lights[li];
+                    if (L.kind == LT_AMBIENT) {
+                        E = E + ld(L.color) * mcol;
+                    } else if (L.kind == LT_OBJECT) {
+                        D I, wi;
+                        double dist;
+                        illuminate_object(sc, L, pos, rng, I, wi, dist);
+                        if (light_visible(a, pos, wi, dist)) E = E + ((scat / extinction) * (I * mcol)) * phase;
+                    }
+                    // Point / Directional: illuminate draws nothing and the test |hit - dist| < 1e-12 can never pass
+                    // (dist = the light's position / +inf, src/light.rs:26-33)
+                }
+                if (rng.uniform() < 0.8) {   // :262-281
+                    const double ax = rng.range(-1.0, 1.0), ay = rng.range(-1.0, 1.0), az = rng.range(-1.0, 1.0);
+                    wi_next = normalize(mk(ax, ay, az));   // Medium::sample_ph, src/medium.rs:87-93
+                    k = ((((scat / extinction) / phase) * mcol) * phase) / 0.8;   // (scat/ext) x / ph_p . color * phase / rr_p, ph_p == phase
+                    cont = true;
+                }
+            } else {   // surface event: :207-237 in a medium, :289-318 without
+                pos = ro + h.time * rd;
+                const Mat& mat = sc.objects[obj].mat;
+                const D n = h.normal;
+                E = depth == 0 ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
+                // sample_lights, :362-409
+                for (uint32_t li = 0; li < sc.n_lights; li++) {
+                    const Light& L = sc.lights[li];
+                    if (L.kind == LT_AMBIENT) {
+                        E = E + ld(L.color) * mat_color(mat);
+                    } else if (L.kind == LT_OBJECT) {
+                        D I, wi;
+                        double dist;
+                        illuminate_object(sc, L, pos, rng, I, wi, dist);
+                        if (light_visible(a, pos, wi, dist)) E = E + (bsdf(mat, n, wo, wi) * I) * dot(wi, n);
+                    }
+                }
+                const bool go = medium ? (rng.uniform() < 0.8) : (depth < a.max_bounces);   // :222 / :301
+                if (go) {
+                    double pdf;
+                    if (sample_f(mat, n, wo, rng, wi_next, pdf)) {
+                        const D f = bsdf(mat, n, wo, wi_next);
+                        k = ((1.0 / (medium ? pdf * 0.8 : pdf)) * f) * fabs(dot(wi_next, n));
+                        cont = true;
+                    }
+                }
             }
-            (void)E; (void)k; (void)pos; (void)cont; (void)wi_next; (void)wo; (void)depth;
-            break;
+            P = P + Q * E;
+            if (!cont) {   // (a path whose weight has become zero goes on, as the reference's recursion does: same rays, same draws)
+                color = color + vmin(P, R);
+                break;
+            }
+            if (!medium) R = vmin(R, P + kFireflyClamp * Q);   // FIREFLY_CLAMP, :311-313
+            Q = Q * k;
+            ro = pos;
+            rd = wi_next;
+            depth++;
         }
     }
-    (void)color;
+    const size_t o = (size_t(y) * a.width + x) * 3;
+    const double inv = a.scale / double(a.iterations);   // color / iterations * 2^EV, :183
+    a.out[o] = color.x * inv;
+    a.out[o + 1] = color.y * inv;
+    a.out[o + 2] = color.z * inv;
 }
 
 }  // namespace rpt64
+
+namespace rptg {
+hipError_t launch_render_f64(const rpt64::Args& a, hipStream_t stream) {
+    if (!a.n_owned) return hipSuccess;
+    hipLaunchKernelGGL(rpt64::render_f64_kernel, dim3((a.n_owned + 255u) / 256u), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+}  // namespace rptg

@@ -2148,6 +2148,7 @@ static int photon_args_ok(rpt_scene* s, uint64_t photon_count, int32_t kind) {
     if (!s) return rpti::fail(RPT_ERR_INVALID, "null scene");
     rpti::SceneDev sd = rpti::scene_dev(s);
     if (!sd.committed) return rpti::fail(RPT_ERR_STATE, "rpt_scene_commit must be called first");
+    if (sd.epsilon64) return rpti::fail(RPT_ERR_UNSUPPORTED, "photon mapping is not available in the reference-epsilon mode (epsilon_policy = 1)");
     if (photon_count == 0) return rpti::fail(RPT_ERR_INVALID, "photon_count must be > 0");
     if (kind != RPT_PHOTON_POINT_BEAM && kind != RPT_PHOTON_MAP && kind != RPT_PHOTON_BEAM_BEAM)
         return rpti::fail(RPT_ERR_INVALID, "unknown PhotonRenderKind");

@@ -17,6 +17,7 @@
 #include "../../include/rpt_hip.h"
 #include "host_internal.h"
 #include "kernels.h"
+#include "f64_layout.h"
 
 using namespace rptg;
 
@@ -70,10 +71,12 @@ struct rpt_options {
     int64_t defer_lanes = 32;       // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
     int64_t detach_shadows = 1;     // per-mesh-tree kernels in a medium: 1 = shadow queries that need a tree walk leave their path (0: they park
                                     // the lane), 2 = every tree walk leaves its path ("streamed walks": ring + parked paths in memory)
-    int64_t stream_backlog = 128;   // detach_shadows = 2: queries in a wave's ring that trigger a walk session
+    int64_t stream_backlog = 64;    // detach_shadows = 2: queries in a wave's ring that trigger a walk session
+    int64_t stream_contexts = 4;    // detach_shadows = 2: paths a lane can have waiting in memory (1..6)
     int64_t detach_lanes = 44;      // ... parked primary + queued shadow queries per wave that trigger a walk session
     int64_t detach_trigger = 28;    // ... or this many queued shadow queries alone (the queue holds 32)
     int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built
+    int64_t epsilon_policy = 0;     // 1: the reference-epsilon mode (read by rpt_scene_commit): fp64, generic shapes, t_min = 1e-12, |hit - dist| < 1e-12
 };
 static rpt_options g_defaults;
 static std::mutex g_defaults_mutex;
@@ -96,10 +99,12 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "bvh_max_depth") { if (value < 1 || value > 20) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..20"); o.bvh_max_depth = value; }
     else if (s == "walk_leaf_quarters") { if (value < 0 || value > 256) return fail(RPT_ERR_INVALID, "walk_leaf_quarters must be 0..256"); o.walk_leaf_quarters = value; }
     else if (s == "detach_shadows") { if (value < 0 || value > 2) return fail(RPT_ERR_INVALID, "detach_shadows must be 0, 1 or 2"); o.detach_shadows = value; }
+    else if (s == "stream_contexts") { if (value < 1 || value > 6) return fail(RPT_ERR_INVALID, "stream_contexts must be 1..6"); o.stream_contexts = value; }
     else if (s == "stream_backlog") { if (value < 1 || value > 256) return fail(RPT_ERR_INVALID, "stream_backlog must be 1..256"); o.stream_backlog = value; }
     else if (s == "detach_lanes") { if (value < 1 || value > 96) return fail(RPT_ERR_INVALID, "detach_lanes must be 1..96"); o.detach_lanes = value; }
     else if (s == "detach_trigger") { if (value < 1 || value > 32) return fail(RPT_ERR_INVALID, "detach_trigger must be 1..32"); o.detach_trigger = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
+    else if (s == "epsilon_policy") { if (value < 0 || value > 1) return fail(RPT_ERR_INVALID, "epsilon_policy must be 0 or 1"); o.epsilon_policy = value; }
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); o.scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option: " + s);
     return RPT_OK;
@@ -499,6 +504,11 @@ struct rpt_scene {
     bool twins_scanned = false;  // every Light::Object that can be visible has its twin among the scanned records, as one range of hit codes
     uint64_t stats[16] = {0};
     void* photon = nullptr;  // PhotonMapDev*, owned by photon.hip
+    // reference-epsilon mode (option "epsilon_policy" = 1 at commit): the fp64 scene of kernels_f64.hip
+    void* arena64 = nullptr;
+    rpt64::Scene view64{};
+    double medium_color64[3] = {0, 0, 0}, medium_color_hi64[3] = {0, 0, 0};
+    uint64_t last_counters64[8] = {0};
     // mesh data interned by content (hash -> candidates), so Arc<Mesh>-style sharing survives the C ABI
     std::unordered_map<uint64_t, std::vector<std::shared_ptr<const std::vector<double>>>> mesh_pool;
     // tile cache key
@@ -604,6 +614,7 @@ void rpt_scene_destroy(rpt_scene* s) {
     if (s->committed) {
         (void)hipSetDevice(s->device);
         (void)hipFree(s->arena);
+        (void)hipFree(s->arena64);
         (void)hipFree(s->d_tiles);
         for (auto& ls : s->sets) {
             (void)hipFree(ls.d_slab);
@@ -1497,6 +1508,162 @@ struct Flattener {
 };
 }  // namespace
 
+// ---------------------------------------------------------------------------- reference-epsilon mode (f64_layout.h)
+// The scene as the reference holds it: scene.objects in order, each a generic shape with the matrices Transformed::new
+// derives (src/shape.rs:112-125), meshes as their triangles in local space, materials and lights in fp64.
+static int fill_shape64(const HShape& hs, rpt64::Shape& o, std::vector<rpt64::Tri>& tris) {
+    if (hs.d.kind == RPT_SHAPE_GROUP)
+        return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports sphere, cube, plane and mesh shapes (no KdTree groups)");
+    std::memset(&o, 0, sizeof(o));
+    o.kind = hs.d.kind;
+    Xf x;
+    if (!make_xf(hs.d, x)) return fail(RPT_ERR_INVALID, "singular transform");
+    o.has_xf = x.has ? 1 : 0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) { o.inv[i * 4 + j] = x.Minv[i][j]; o.fwd[i * 4 + j] = x.M[i][j]; }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { o.lin[i * 3 + j] = x.L[i][j]; o.nrm[i * 3 + j] = x.N[i][j]; }
+    o.det = x.det;
+    for (int k = 0; k < 3; k++) o.plane[k] = hs.d.plane_normal[k];
+    o.plane[3] = hs.d.plane_value;
+    if (hs.d.kind == RPT_SHAPE_MESH) {
+        const std::vector<double>& T = hs.T();
+        o.tri_first = uint32_t(tris.size());
+        o.tri_count = uint32_t(T.size() / 18);
+        for (int k = 0; k < 3; k++) { o.bmin[k] = std::numeric_limits<double>::infinity(); o.bmax[k] = -o.bmin[k]; }
+        for (size_t t = 0; t < T.size() / 18; t++) {
+            rpt64::Tri tr;
+            std::memcpy(&tr, T.data() + t * 18, sizeof(tr));
+            tris.push_back(tr);
+            for (int v = 0; v < 3; v++)   // Triangle::bounding_box merged over the mesh (src/kdtree.rs:108-113)
+                for (int k = 0; k < 3; k++) {
+                    o.bmin[k] = std::min(o.bmin[k], T[t * 18 + v * 3 + k]);
+                    o.bmax[k] = std::max(o.bmax[k], T[t * 18 + v * 3 + k]);
+                }
+        }
+    }
+    return RPT_OK;
+}
+static void fill_mat64(const rpt_material& m, rpt64::Mat& o) {
+    std::memset(&o, 0, sizeof(o));
+    o.kind = m.kind;
+    for (int k = 0; k < 3; k++) o.albedo[k] = m.albedo[k];
+    o.emittance = m.emittance;
+    o.shininess = m.shininess;
+    o.ior = m.ior;
+}
+static int build_scene64(rpt_scene* s) {
+    static_assert(sizeof(rpt64::Tri) == 18 * sizeof(double), "a triangle is its 18 doubles");
+    if (s->hdri_w) return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports Environment::Color only");
+    std::vector<rpt64::Object> objs(s->objects.size());
+    std::vector<rpt64::Tri> tris;
+    std::vector<rpt64::Light> lights(s->lights.size());
+    for (size_t i = 0; i < s->objects.size(); i++) {
+        if (int rc = fill_shape64(s->objects[i].shape, objs[i].shape, tris)) return rc;
+        fill_mat64(s->objects[i].mat, objs[i].mat);
+    }
+    for (size_t i = 0; i < s->lights.size(); i++) {
+        const HLight& hl = s->lights[i];
+        rpt64::Light& L = lights[i];
+        std::memset(&L, 0, sizeof(L));
+        L.kind = hl.kind;
+        for (int k = 0; k < 3; k++) L.color[k] = hl.color[k];
+        if (hl.kind == int(L_OBJECT)) {
+            if (int rc = fill_shape64(hl.obj.shape, L.obj.shape, tris)) return rc;
+            fill_mat64(hl.obj.mat, L.obj.mat);
+        }
+    }
+    const size_t b_obj = objs.size() * sizeof(rpt64::Object), b_tri = tris.size() * sizeof(rpt64::Tri), b_l = lights.size() * sizeof(rpt64::Light);
+    const size_t o_tri = (b_obj + 15) & ~size_t(15), o_l = (o_tri + b_tri + 15) & ~size_t(15), total = std::max<size_t>(o_l + b_l, 16);
+    HIP_TRY(hipMalloc(&s->arena64, total));
+    char* base = static_cast<char*>(s->arena64);
+    if (b_obj) HIP_TRY(hipMemcpy(base, objs.data(), b_obj, hipMemcpyHostToDevice));
+    if (b_tri) HIP_TRY(hipMemcpy(base + o_tri, tris.data(), b_tri, hipMemcpyHostToDevice));
+    if (b_l) HIP_TRY(hipMemcpy(base + o_l, lights.data(), b_l, hipMemcpyHostToDevice));
+    rpt64::Scene& v = s->view64;
+    v.objects = reinterpret_cast<const rpt64::Object*>(base);
+    v.tris = reinterpret_cast<const rpt64::Tri*>(base + o_tri);
+    v.lights = reinterpret_cast<const rpt64::Light*>(base + o_l);
+    v.n_objects = uint32_t(objs.size());
+    v.n_lights = uint32_t(lights.size());
+    v.has_medium = s->media.empty() ? 0 : 1;
+    v.medium_kind = 0;
+    v.absorption = v.scattering = 0.0;
+    if (!s->media.empty()) {   // only media[0] is used (src/renderer.rs:190)
+        v.medium_kind = s->media[0].kind;
+        v.absorption = s->media[0].absorption;
+        v.scattering = s->media[0].scattering;
+        const D3 lo = s->media[0].kind == 1 ? hex_color(0x0000FF) : hex_color(0xD2B48C), hi = s->media[0].kind == 1 ? hex_color(0xFF0000) : lo;
+        s->medium_color64[0] = lo.x; s->medium_color64[1] = lo.y; s->medium_color64[2] = lo.z;
+        s->medium_color_hi64[0] = hi.x; s->medium_color_hi64[1] = hi.y; s->medium_color_hi64[2] = hi.z;
+    }
+    for (int k = 0; k < 3; k++) v.env[k] = s->env[k];
+    return RPT_OK;
+}
+// Renderer::sample in the reference-epsilon mode: one lane per pixel, frame written directly (no slab).
+static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations, uint64_t seed,
+                        uint32_t sample_offset, double* d_out, hipStream_t st) {
+    RenderArgs a{};   // (tiles, sharding and argument checks are shared with the fp32 path)
+    int rc = rpti::prepare_render(s, st, cam, prm, iterations, seed, sample_offset, a);
+    if (rc) return rc;
+    rpt64::Args q{};
+    q.sc = s->view64;
+    const D3 dir = d3(cam->direction), up = d3(cam->up);
+    const D3 right = normalize(cross(dir, up));   // src/camera.rs:67-68
+    for (int i = 0; i < 3; i++) {
+        q.cam.eye[i] = cam->eye[i];
+        q.cam.direction[i] = cam->direction[i];
+        q.cam.up[i] = cam->up[i];
+        q.cam.right[i] = comp(right, i);
+        q.medium_color[i] = s->medium_color64[i];
+        q.medium_color_hi[i] = s->medium_color_hi64[i];
+    }
+    q.cam.d = 1.0 / std::tan(cam->fov / 2.0);
+    q.cam.aperture = cam->aperture;
+    q.cam.focal_distance = cam->focal_distance;
+    q.width = prm->width; q.height = prm->height; q.iterations = iterations; q.sample_offset = sample_offset;
+    q.max_bounces = prm->max_bounces;
+    q.n_owned = a.n_owned; q.tiles_x = a.tiles_x; q.tiles = a.tiles;
+    q.seed_mixed = a.seed_mixed;
+    q.dim = double(std::max(prm->width, prm->height));
+    q.scale = std::pow(2.0, prm->exposure_value);
+    q.out = d_out;
+    q.counters = s->opt.counters ? s->d_counters : nullptr;
+    const uint32_t shard_count = prm->shard_count == 0 ? 1 : prm->shard_count;
+    if (shard_count > 1) HIP_TRY(hipMemsetAsync(d_out, 0, size_t(prm->width) * prm->height * 24, st));
+    if (q.counters) HIP_TRY(hipMemsetAsync(q.counters, 0, 512, st));
+    rpt_scene::LaunchSet& mine = s->sets[s->sets[0].d_queue == a.queue ? 0 : 1];
+    hipEvent_t* ev = nullptr;
+    if (s->opt.timing) {
+        const size_t slot = s->ev_count % rpt_scene::kTimedLaunches;
+        while (s->evs.size() < 3 * (slot + 1)) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            s->evs.push_back(e);
+        }
+        ev = &s->evs[3 * slot];
+        HIP_TRY(hipEventRecord(ev[0], st));
+    }
+    HIP_TRY(hipEventRecord(mine.launched, st));
+    HIP_TRY(launch_render_f64(q, st));
+    if (ev) {
+        HIP_TRY(hipEventRecord(ev[1], st));
+        HIP_TRY(hipEventRecord(ev[2], st));
+        s->ev_count++;
+    }
+    s->last_blocks = int((q.n_owned + 255u) / 256u);
+    HIP_TRY(hipEventRecord(mine.done, st));
+    if (q.counters) {
+        HIP_TRY(hipStreamSynchronize(st));
+        std::memset(s->last_counters, 0, sizeof(s->last_counters));
+        HIP_TRY(hipMemcpy(s->last_counters64, q.counters, sizeof(s->last_counters64), hipMemcpyDeviceToHost));
+        s->last_counters[0] = s->last_counters64[6];   // rpt_get_counters: samples, rays, vertices
+        s->last_counters[1] = s->last_counters64[0];
+        s->last_counters[2] = s->last_counters64[7];
+    }
+    return RPT_OK;
+}
+
 int rpt_scene_commit(rpt_scene* s, int device) {
     if (!s) return fail(RPT_ERR_INVALID, "null scene");
     if (s->committed) return fail(RPT_ERR_STATE, "scene already committed");
@@ -1519,7 +1686,13 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     rc = f.build_scene_tree();
     if (rc) return rc;
     f.collect_scan_boxes();
-    return f.upload(device);
+    rc = f.upload(device);
+    if (rc) return rc;
+    if (s->opt.epsilon_policy == 1) {
+        rc = build_scene64(s);
+        if (rc) { s->committed = false; return rc; }
+    }
+    return RPT_OK;
 }
 
 // ---------------------------------------------------------------------------- render
@@ -1653,6 +1826,7 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     if (s->opt.detach_shadows && s->view.has_medium && bvh_mode(s->view) == 1 && s->view.n_lparts == 0 && s->twins_scanned)
         a.detach = (s->opt.detach_shadows == 2 && s->n_twin_lights <= 3) ? 2u : 1u;
     a.stream_backlog = uint32_t(s->opt.stream_backlog);
+    a.stream_contexts = uint32_t(s->opt.stream_contexts);
     a.n_twin_lights = s->n_twin_lights;
     a.stream_scratch = nullptr;   // (run_render sizes it for the grid)
     a.detach_trigger = uint32_t(s->opt.detach_trigger);
@@ -1740,7 +1914,7 @@ extern "C++" rpti::SceneDev rpti::scene_dev(rpt_scene* s) {
     int first = -1;
     for (size_t i = 0; i < s->lights.size(); i++)
         if (s->lights[i].kind == L_OBJECT) { first = int(i); break; }
-    return SceneDev{s->committed, s->device, s->n_cus, s->view, first};
+    return SceneDev{s->committed, s->device, s->n_cus, s->view, first, s->arena64 != nullptr};
 }
 extern "C++" void*& rpti::photon_slot(rpt_scene* s) { return s->photon; }
 extern "C++" int64_t rpti::option_photon_skip(rpt_scene* s) { return s->opt.photon_skip; }
@@ -1769,6 +1943,7 @@ extern "C++" int rpti::fetch_counters(rpt_scene* s, const RenderArgs& a) {
 int rpt_render_sample_device(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
                              uint64_t seed, uint32_t sample_offset, void* d_out_rgb, void* hip_stream) {
     if (!d_out_rgb) return fail(RPT_ERR_INVALID, "null output");
+    if (s && s->arena64) return run_render64(s, cam, prm, iterations, seed, sample_offset, static_cast<double*>(d_out_rgb), static_cast<hipStream_t>(hip_stream));
     RenderArgs a{};
     int rc = rpti::prepare_render(s, static_cast<hipStream_t>(hip_stream), cam, prm, iterations, seed, sample_offset, a);
     if (rc) return rc;
@@ -1793,10 +1968,22 @@ int rpt_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_para
         HIP_TRY(hipMalloc((void**)&s->d_out, bytes));
         s->out_cap = bytes;
     }
+    if (s->arena64) {
+        rc = run_render64(s, cam, prm, iterations, seed, sample_offset, s->d_out, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy(out_rgb, s->d_out, bytes, hipMemcpyDeviceToHost));
+        return RPT_OK;
+    }
     rc = run_render(s, prm, a, s->d_out, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out_rgb, s->d_out, bytes, hipMemcpyDeviceToHost));
     return rpti::fetch_counters(s, a);
+}
+int rpt_debug_epsilon_counters(rpt_scene* s, uint64_t out[8]) {
+    if (!s || !out) return fail(RPT_ERR_INVALID, "null argument");
+    if (!s->arena64) return fail(RPT_ERR_STATE, "the scene was not committed with epsilon_policy = 1");
+    for (int i = 0; i < 8; i++) out[i] = s->last_counters64[i];
+    return RPT_OK;
 }
 
 // ---------------------------------------------------------------------------- Buffer on the device
@@ -1882,6 +2069,10 @@ int rpt_render_into_buffer(rpt_scene* s, const rpt_camera* cam, const rpt_render
     if (!s || !prm) return fail(RPT_ERR_INVALID, "null argument");
     if (prm->width != b->width || prm->height != b->height) return fail(RPT_ERR_INVALID, "Invalid sample dimension");  // buffer.rs:33-36
     if (s->committed && s->device != b->device) return fail(RPT_ERR_INVALID, "buffer and scene live on different devices");
+    if (s->arena64) {
+        int rc64 = run_render64(s, cam, prm, iterations, seed, sample_offset, b->d_stage, nullptr);
+        return rc64 ? rc64 : rpt_buffer_add_samples_device(b, b->d_stage, nullptr);
+    }
     RenderArgs a{};
     int rc = rpti::prepare_render(s, nullptr, cam, prm, iterations, seed, sample_offset, a);
     if (rc) return rc;

@@ -34,6 +34,14 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) <= exported
 
 
+def test_integration_doc_binds_every_entry_point():
+    """INTEGRATION.md section 1 shows the Rust `extern "C"` block a maintainer would add: one declaration per function of the
+    header, no more, no fewer."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rust = set(re.findall(r"pub fn (rpt_[a-z0-9_]+)", text))
+    assert rust == set(header_functions())
+
+
 def test_library_is_built_for_gfx950_only():
     data = open(_lib.LIB_PATH, "rb").read()
     # code objects in the fat binary are tagged hipv4-amdgcn-amd-amdhsa--<arch> (bare arch names also

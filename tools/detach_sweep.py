@@ -3,7 +3,7 @@ form, over "detach_lanes" (parked primary + queued shadow queries that trigger a
 shadow queries alone) and "defer_stop".  All detached frames must be bit-identical; the parked frame differs in the last bits
 (another order of the same sums).
 A value that starts with "s" is the streamed form (detach_shadows = 2: primary queries leave as well, their paths wait in
-memory): s:backlog:stop[:walk_leaf_quarters].
+memory): s:backlog:stop[:contexts].
 Usage: python tools/detach_sweep.py [workload] [width] [spp] [lanes:trigger:stop[:walk_leaf_quarters] | s:backlog:stop[:q] ...]"""
 import os
 import sys
@@ -21,6 +21,8 @@ values = [tuple(x if x == "s" else int(x) for x in v.split(":")) for v in sys.ar
                                                                           (48, 20, 24), (48, 12, 16), (48, 28, 16), (64, 32, 24)]
 scene, cam, cfg = scenes.CONFIGS[name]()
 rpt_amd.set_option("timing", 1)
+if os.environ.get("CHUNK_SPP"):   # samples per work item (the automatic rule follows the sample count: 16 at C5's 1024 spp, 2 at 64)
+    rpt_amd.set_option("chunk_spp", int(os.environ["CHUNK_SPP"]))
 
 
 def run(label):
@@ -31,7 +33,7 @@ def run(label):
         r._sample_offset = 0
         img = r.sample_array(spp)
         ms.append(r.timing()[0])
-    print(f"{name} {width}x{width}x{spp} {label}: kernel {min(ms):9.3f} ms   mean {img.mean():.9f}", flush=True)
+    print(f"{name} {width}x{width}x{spp} {label}: kernel {min(ms):9.3f} ms   mean {img.mean():.9f}   grid {r.timing()[2]} blocks", flush=True)
     return img
 
 
@@ -42,7 +44,9 @@ for v in values:
     if v[0] == "s":
         rpt_amd.set_option("detach_shadows", 2)
         rpt_amd.set_option("stream_backlog", v[1])
-        label = f"streamed backlog:stop={v[1]:3d}:{v[2]:2d}      "
+        rpt_amd.set_option("stream_contexts", v[3] if len(v) > 3 else 4)
+        label = f"streamed backlog:stop:contexts={v[1]:3d}:{v[2]:2d}:{v[3] if len(v) > 3 else 4}"
+        v = v[:3]
     else:
         rpt_amd.set_option("detach_shadows", 1)
         rpt_amd.set_option("detach_lanes", v[0])

@@ -1,5 +1,5 @@
 """Lane utilisation per section of the megakernel's loop body (COUNT build, SECT(k) in kernels.hip).
-Usage: python tools/trips.py [workload] [spp]"""
+Usage: python tools/trips.py [workload] [spp] [detach_shadows 0|1|2]"""
 import ctypes as C
 import sys
 
@@ -10,11 +10,17 @@ from rpt_amd import Renderer, _lib, scenes  # noqa: E402
 NAMES = ["0 work pull", "1 regenerate camera ray", "2 vertex start (medium d, wo)", "3 after primary scan", "4 miss/env",
          "5 medium event setup", "6 surface finalize + material", "7 light sample", "8 shadow scan start",
          "9 after shadow scan (visibility, NEE shading)", "10 bounce start", "11 medium bounce", "12 surface RR",
-         "13 surface sample_f + bsdf", "14 path update", "15 parked tree walks (per-mesh-tree kernels)", "16 walk finished", "17 ... with a triangle hit", "18 ... shadow query"]
+         "13 surface sample_f + bsdf", "14 path update", "15 parked tree walks (per-mesh-tree kernels)", "16 walk finished", "17 ... with a triangle hit", "18 ... shadow query", "19", "20",
+         "21 detached: shadow query queued / streamed: path parked", "22 detached: queue full, walked in place / streamed: shadow query written"]
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 scene, cam, cfg = scenes.CONFIGS[name]()
 r = Renderer(scene, cam).width(min(cfg["width"], 1024)).height(min(cfg["height"], 1024)).max_bounces(cfg["max_bounces"]).seed(0)
+if len(sys.argv) > 3:
+    rpt_amd.set_option("detach_shadows", int(sys.argv[3]))
+import os  # noqa: E402
+if os.environ.get("CHUNK_SPP"):
+    rpt_amd.set_option("chunk_spp", int(os.environ["CHUNK_SPP"]))
 rpt_amd.set_option("counters", 1)
 r.sample_array(spp)
 c = r.counters()
