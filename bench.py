@@ -49,9 +49,11 @@ N_SIMD = 1024              # 256 CUs x 4 SIMDs; one wave64 VALU instruction issu
 N_XCD = 8                  # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs: / 8 = the launch's clock cycles
 
 SCENE_FILES = {"C2": "examples/cornell.rs", "C3": "examples/volumetric_pathtrace_lampshade.rs",
-               "C4": "examples/volumetric_beamphoton_lampshade.rs", "C5": "examples/dragon.rs layout, procedural 100,352-triangle mesh"}
+               "C4": "examples/volumetric_beamphoton_lampshade.rs", "C5": "examples/dragon.rs layout, procedural 100,352-triangle mesh",
+               "C5G": "C5's mesh inside a KdTree<Box<dyn Bounded>> of 64 spheres (the shape of examples/fractal_teapots.rs:56 with one large mesh)"}
 WORKLOAD_NAMES = {"C2": "C2 cornell box path trace", "C3": "C3 lampshade-in-fog path trace",
-                  "C4": "C4 lampshade beam x point photon map", "C5": "C5 100k-triangle mesh in fog path trace"}
+                  "C4": "C4 lampshade beam x point photon map", "C5": "C5 100k-triangle mesh in fog path trace",
+                  "C5G": "C5G (not a BASELINE configuration) 100k-triangle mesh in a kd-tree group of 64 spheres, in fog"}
 
 
 def usable_cpus():
@@ -578,13 +580,14 @@ def main(argv=None):
     default_run = args.workload == "C3" and not (args.width or args.height or args.spp)
     if world == 1 and dist is None and default_run and not args.no_secondary:
         secondary = []
-        for wl in ("C2", "C4", "C5"):
+        for wl in ("C2", "C4", "C5", "C5G"):
             entry = measure(wl, args, 2, 1, 1, torch, None, rank, local_rank, world, False)
             entry = dict({"workload": wl}, **entry)
             secondary.append(entry)
         out["secondary"] = secondary
-        out["secondary_note"] = ("the other BASELINE configurations at their configured sizes, 2 timed steps each after 1 warm-up, strictly one "
-                                 "stream (ms_per_step = wall_clock_s x 1000), same definitions as the headline")
+        out["secondary_note"] = ("the other BASELINE configurations at their configured sizes (and C5G: the scene-tree + parked-mesh-walk flavour, "
+                                 "2048x2048x256), 2 timed steps each after 1 warm-up, strictly one stream (ms_per_step = wall_clock_s x 1000), "
+                                 "same definitions as the headline")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -141,7 +141,7 @@ int rpt_intersect_batch(rpt_scene*, uint64_t n, const float* origins, const floa
  * [2] planes, [3] linearly scanned triangles, [4] axis-aligned boxes, [5] axis-aligned
  * rectangles (pairs of wall triangles), [6] BVH triangles, [7] BVH nodes, [8] bytes of scan
  * records every closest-hit query walks, [9] bytes of scene data resident in HBM, [10] 1 if one scene-level
- * tree replaces the scan, [11] primitives in it, [12] mesh instances, [13] meshes stored once and instanced,
+ * tree replaces the scan (2: ... and the meshes with trees of their own stay outside it, their walks parked), [11] primitives in it, [12] mesh instances, [13] meshes stored once and instanced,
  * [14] wall rectangles folded into a box shell, [15] levels of the deepest walk (scene tree + mesh tree). */
 int rpt_scene_stats(rpt_scene*, uint64_t out[16]);
 /* Counters of the last rpt_render_sample* call on this scene (device-side, exact):

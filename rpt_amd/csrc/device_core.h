@@ -663,10 +663,29 @@ RPT_DEV void closest_hit(const SceneView& scene_, V o, V d, float tmin, float& t
             if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
         }
         bvh_traverse<COUNT, true, ANY>(scene_, sc.top_root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris, any);
+        if (sc.mesh_deferred) walk_meshes<COUNT, ANY>(scene_, o, d, tmin, tbest, code, inst, stk, stride, c_nodes, c_tris, any);   // (wave-uniform)
         return;
     }
     scan_prims(scene_, o, d, tmin, tbest, code);
     if (BVH) walk_meshes<COUNT, ANY>(scene_, o, d, tmin, tbest, code, inst, stk, stride, c_nodes, c_tris, any);
+}
+
+// Everything of a query except the per-mesh trees: the linear scan, or -- BVH = 3: a scene tree whose meshes are walked
+// separately (SceneView::mesh_deferred) -- the planes and the scene tree.
+template <int BVH, bool COUNT>
+RPT_DEV void scan_or_tree(const SceneView& scene_, V o, V d, float tmin, float& tbest, uint32_t& code, uint32_t& inst, uint32_t* stk,
+                          uint32_t stride, uint32_t& c_nodes, uint32_t& c_tris) {
+    if constexpr (BVH == 3) {
+        const auto& sc = *kernarg_scene();
+        for (uint32_t i = 0; i < sc.n_pln; i++) {
+            const F4 nv = uload(&sc.pln[i]).nv;
+            float t = hit_plane(nv, o, d, tmin);
+            if (t >= 0.f && t < tbest) { tbest = t; code = (K_PLANE << 28) | i; }
+        }
+        bvh_traverse<COUNT, true, false>(scene_, sc.top_root, o, d, tmin, tbest, code, inst, stk, stride, 32u, c_nodes, c_tris);
+    } else {
+        scan_prims(scene_, o, d, tmin, tbest, code);
+    }
 }
 
 // Normal and object of the winning primitive (per lane).

@@ -163,6 +163,10 @@ struct SceneView {
     // of them, e.g. KdTree<Box<dyn Bounded>> groups): scene_bvh = 1 replaces the linear scans of
     // sph/cub/aabb/rect/tri and the per-mesh walks by one walk from `top_root`.
     const uint32_t* pleaf; uint32_t n_nodes, scene_bvh, top_root;
+    // scene_bvh with mesh_deferred = 1: the meshes with trees of their own (`meshes`) are NOT leaves of the scene tree -- a
+    // query walks the scene tree for everything else and the mesh trees separately, which lets the render kernel park those
+    // walks (the long ones) as it does in scenes without a scene tree.
+    uint32_t mesh_deferred;
     const InstRec* inst;   uint32_t n_inst;
     const Material* mats;  uint32_t n_obj;   // one material record per scene object
     const Light* lights;   uint32_t n_lights;

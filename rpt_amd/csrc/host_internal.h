@@ -40,6 +40,7 @@ double* scratch_out(rpt_scene* s, size_t bytes);  // cached device frame for the
 int64_t option_photon_skip(rpt_scene* s);  // option "photon_skip" of the scene: diagnostic bit mask for the camera pass
 int64_t option_photon_parts(rpt_scene* s);        // option "photon_parts": strips per 8x8 pixel block of the camera pass (1, 2, 4, 8)
 int64_t option_photon_coop_gather(rpt_scene* s);  // option "photon_coop_gather": wave-level surface gather on (default) / off
+int64_t option_photon_split(rpt_scene* s);        // option "photon_split": volume and surface estimate of the beam kinds in two launches (default off: measured slower)
 int64_t option_photon_block_lists(rpt_scene* s);  // option "photon_block_lists": per-block candidate lists on (default) / off
 }  // namespace rpti
 

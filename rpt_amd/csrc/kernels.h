@@ -23,6 +23,7 @@ struct RenderArgs {
     uint32_t n_owned;         // n_tiles * 1024 pixel slots
     uint32_t n_items;         // n_owned * n_chunks
     float* slab;              // [n_chunks][n_owned] float4 partial sums
+    float* slab2;             // a second term per (chunk, pixel) that resolve_kernel adds (the split photon camera pass), or null
     unsigned long long* queue;  // 64-bit work counter (zeroed before the launch)
     unsigned long long* counters;  // 8 x u64 or nullptr
     uint32_t lds_stack;       // 1: BVH stack in dynamic LDS

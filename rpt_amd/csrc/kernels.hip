@@ -209,7 +209,7 @@ RPT_DEV bool stage_bounce(const RenderArgs& a, float albedo_med, V rd, uint32_t 
 // DETACH (per-mesh-tree kernels in a medium): shadow queries that need a tree walk leave their path (see the loop body).
 // DETACH = 2: primary queries leave as well -- their paths wait in memory and the lane goes on with another one.
 template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false, int DETACH = 0>
-__global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : BVH == 1 ? (DETACH == 2 ? RPT_MIN_WAVES_STREAM : RPT_MIN_WAVES_MESH) : RPT_MIN_WAVES)
+__global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : (BVH == 1 || BVH == 3) ? (DETACH == 2 ? RPT_MIN_WAVES_STREAM : RPT_MIN_WAVES_MESH) : RPT_MIN_WAVES)
 void render_kernel(const RenderArgs a) {
     static_assert(DETACH == 0 || (MEDIUM && BVH == 1 && !GROUPS), "detached tree walks: per-mesh-tree kernels in a medium only");
     extern __shared__ uint32_t dyn_lds[];
@@ -296,7 +296,7 @@ void render_kernel(const RenderArgs a) {
     uint32_t c_samples = 0, c_rays = 0, c_vertices = 0, c_trips = 0, c_nodes = 0, c_btris = 0;
     uint32_t c_wave[2] = {0, 0}, w_tot[2] = {0, 0};   // steps of the deferred walks (descent, triangles): of the walk at hand as its lanes count them; wave-level totals
 
-    // ---- per-mesh-tree flavour (BVH == 1): deferred walks.  In fog most rays never reach a mesh, a few walk
+    // ---- per-mesh-tree flavours (BVH == 1; BVH == 3: the same beside a scene tree that holds everything else): deferred walks.  In fog most rays never reach a mesh, a few walk
     // a hundred nodes, and a wave walks as long as its slowest lane: 43 wave-level node steps per query for 3.4
     // nodes per ray (8 % of the lanes busy) on C5.  So a query is split: the scan and a test of the mesh roots'
     // child boxes run at once; a lane that really has to walk parks the query and waits (phase PH_WAIT*) while the
@@ -1046,8 +1046,8 @@ void render_kernel(const RenderArgs a) {
             if (++fuse == 0x01000000u) break;   // (no wave of a valid launch comes near 2^24 trips: the loop cannot spin for ever)
             continue;
         }
-        if constexpr (BVH == 1) {
-            // ---- A: a new path vertex: distance sample, scan, do the trees matter?
+        if constexpr (BVH == 1 || BVH == 3) {
+            // ---- A: a new path vertex: distance sample, scan (BVH = 3: walk of the scene tree), do the mesh trees matter?
             if (alive && phase == PH_NEW) {
                 if (COUNT) c_vertices++;
                 SECT(2);
@@ -1055,7 +1055,7 @@ void render_kernel(const RenderArgs a) {
                 const float tmin = ray_tmin(ro);
                 q_code = CODE_MISS;
                 q_inst = 0;
-                scan_prims(sc, ro, rd, tmin, q_t, q_code);
+                scan_or_tree<BVH, COUNT>(sc, ro, rd, tmin, q_t, q_code, q_inst, stk, stride, c_nodes, c_btris);
                 if (COUNT) c_rays++;
                 phase = mesh_roots_hit(sc, ro, rd, tmin, q_t) ? PH_WAITP : PH_HAVEP;
                 walk = walk_begin(sc);
@@ -1094,7 +1094,7 @@ void render_kernel(const RenderArgs a) {
                             q_t = v_dist * (1.f + 1e-3f);
                             q_code = CODE_MISS;
                             q_inst = 0;
-                            scan_prims(sc, v_x, v_wi, tm, q_t, q_code);
+                            scan_or_tree<BVH, COUNT>(sc, v_x, v_wi, tm, q_t, q_code, q_inst, stk, stride, c_nodes, c_btris);
                             if (COUNT) c_rays++;
                             const AnyHit any{L.twin_lo <= L.twin_hi ? v_dist * (1.f - 1e-3f) : -kInf, L.twin_lo, L.twin_hi};
                             const bool blocked = q_code != CODE_MISS && any.blocks(q_t, q_code);
@@ -1281,6 +1281,12 @@ __global__ __launch_bounds__(256) void resolve_kernel(const RenderArgs a, double
         r += double(v.x);
         g += double(v.y);
         b += double(v.z);
+        if (a.slab2) {
+            const float4 w = reinterpret_cast<const float4*>(a.slab2)[size_t(c) * a.n_owned + p];
+            r += double(w.x);
+            g += double(w.y);
+            b += double(w.z);
+        }
     }
     size_t o = (size_t(y) * a.width + x) * 3;
     double inv = scale / double(a.iterations);
@@ -1457,11 +1463,12 @@ static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t
 }
 template <bool M, bool C>
 static hipError_t launch_render_b(const RenderArgs& a, int bvh, int n_blocks, hipStream_t stream) {
+    if (bvh == 3) return launch_render_t<M, 3, C>(a, n_blocks, stream);
     if (bvh == 2) return launch_render_t<M, 2, C>(a, n_blocks, stream);
     if (bvh == 1) return launch_render_t<M, 1, C>(a, n_blocks, stream);
     return launch_render_t<M, 0, C>(a, n_blocks, stream);
 }
-int bvh_mode(const SceneView& sc) { return sc.scene_bvh ? 2 : (sc.n_nodes ? 1 : 0); }
+int bvh_mode(const SceneView& sc) { return sc.scene_bvh ? ((sc.mesh_deferred && sc.n_mesh) ? 3 : 2) : (sc.n_nodes ? 1 : 0); }
 hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream) {
     const bool m = a.sc.has_medium != 0, c = a.counters != nullptr;
     const int b = bvh_mode(a.sc);
@@ -1475,6 +1482,8 @@ hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu, int detach
     if (detach && medium && bvh == 1)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)render_kernel<true, 1, false, false, 1>, 256, kDetachBytes);
     const void* f;
+    if (bvh == 3) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, medium ? (const void*)render_kernel<true, 3, false> : (const void*)render_kernel<false, 3, false>,
+                                                                      256, kStackBytes + kStateBytesBvh);
     if (medium) f = bvh == 2 ? (const void*)render_kernel<true, 2, false> : bvh == 1 ? (const void*)render_kernel<true, 1, false> : (const void*)render_kernel<true, 0, false>;
     else f = bvh == 2 ? (const void*)render_kernel<false, 2, false> : bvh == 1 ? (const void*)render_kernel<false, 1, false> : (const void*)render_kernel<false, 0, false>;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, f, 256, bvh == 1 ? kMeshTreeBytes : bvh ? kStackBytes + kStateBytesBvh : kStateBytes);

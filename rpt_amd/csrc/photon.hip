@@ -1544,8 +1544,12 @@ RPT_DEV void surface_gather_lane(QueryK q, const SceneView& sc_arg, const Gather
 // KIND: the PhotonRenderKind of the map (RPT_PHOTON_*).  One instantiation per kind: the three estimators share the
 // camera ray and the surface gather, but each drags its own register and scratch needs along (the point x point
 // volume gather keeps a 64-entry per-lane stack), which a run-time switch makes every kind pay.
-template <bool MEDIUM, bool BVH, bool GG, int KIND>
+// PHASE: 0 = the whole estimate in one launch; 1 / 2 = the volume estimate / the surface estimate alone, two launches over the
+// same work items whose partial sums go to two slabs that resolve_kernel adds (beam kinds in a medium, lists in LDS): each
+// kernel then keeps only its own estimate's wave-uniform state, and neither needs scratch memory.
+template <bool MEDIUM, bool BVH, bool GG, int KIND, int PHASE = 0>
 __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q) {
+    static_assert(PHASE == 0 || (MEDIUM && !GG && KIND != RPT_PHOTON_MAP), "the split camera pass: beam estimates in a medium, gather lists in LDS");
     extern __shared__ uint32_t dyn_lds[];
     const RenderArgs& a = q.r;
     const SceneView& sc = a.sc;
@@ -1591,7 +1595,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     // every test read a 48-byte staged record from LDS (the LDS pipe was as busy as the VALU) and the list was culled
     // and staged once per 64 samples instead of once per pixel.
     uint32_t* const cand = q.cand_cap ? q.cand + size_t(blockIdx.x * 4u + wave_) * q.cand_cap : nullptr;
-    const bool cand_mode = MEDIUM && KIND == RPT_PHOTON_POINT_BEAM && q.cand_cap != 0u && a.cam.aperture <= 0.f && !(q.skip & 1u);
+    const bool cand_mode = PHASE != 2 && MEDIUM && KIND == RPT_PHOTON_POINT_BEAM && q.cand_cap != 0u && a.cam.aperture <= 0.f && !(q.skip & 1u);
     uint32_t cand_n = 0;       // wave-uniform
     bool cand_valid = false;   // wave-uniform: the list describes the strip this wave is working on
     const uint32_t n_blocks64 = a.n_owned >> 6;  // 8x8 blocks owned by this rank
@@ -1681,8 +1685,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         // the surface gather can collect its candidates once for all the pixel's samples (below) when the estimator decides
         // "surface or not" by the hit alone
         // -- and when no beam walk of the trips below needs the list's LDS (it runs with the photons in the lanes, or not at all)
-        const bool pix_gather = !GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u && KIND != RPT_PHOTON_MAP && !(q.skip & 2u) &&
-                                (!MEDIUM || beam_lanes || (q.skip & 1u) != 0u);
+        const bool pix_gather = PHASE != 1 && !GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u && KIND != RPT_PHOTON_MAP && !(q.skip & 2u) &&
+                                (!MEDIUM || beam_lanes || (q.skip & 1u) != 0u || PHASE == 2);
         float far2 = 0.f, near2 = kInf;
         bool have_xc = false;      // wave-uniform
         V pxc = mk(0, 0, 0);       // wave-uniform: the first surface point among the pixel's samples
@@ -1737,7 +1741,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
         { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 2, t1 - tk); tk = t1; }   // [2] the pixel's candidate list (+ the first pass when there is no beam estimate)
         // ---- the pixel's samples, 64 per trip; lane = sample
         V pixel_sum = mk(0, 0, 0);
-        for (uint32_t sub = 0; sub < n_sub; sub++) {
+        // (PHASE 1 comes here only for the pixels of a strip without a candidate list: volume estimate with the samples in the lanes)
+        for (uint32_t sub = 0; sub < ((PHASE == 1 && beam_lanes) ? 0u : n_sub); sub++) {
         V ro, rd;
         float tmin, t;
         uint32_t code, inst;
@@ -1772,11 +1777,12 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     surface_scale = __expf(-sigma_t * t) * rcp(tr_d);   // transmittance(t) / (1 - cdf), 1 - cdf = T(d)
                 }
             }
-        } else if (MEDIUM && !(q.skip & 1u) && !beam_lanes) {  // beam estimates with the samples in the lanes
+        } else if (PHASE != 2 && MEDIUM && !(q.skip & 1u) && !beam_lanes) {  // beam estimates with the samples in the lanes
             const V vc = volume_estimate_sample_lanes<KIND>(q, active, ro, rd, hit, t, sigma_t, sc.medium_phase, wstack, stage);
             color = vc * mcol0;
         }
         if (active && !hit && !MEDIUM) color = env_color(sc_arg, rd);  // src/photon.rs:597
+        if constexpr (PHASE != 1) {
         // ---- surface estimate, src/photon.rs:327-375
         const bool surf = active && surface_on && !(q.skip & 2u);
         SurfaceSample s{ro, mk(0, 1, 0), wo, Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f}, mk(0, 0, 0), 0.f, surf};
@@ -1807,6 +1813,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             else if (MEDIUM) sc_col = __expf(-sigma_t * t) * sc_col;                  // :610-611
             color = color + sc_col;
         }
+        }   // PHASE != 1
         if (active) pixel_sum = pixel_sum + color;
         }   // trips of the pixel
         // the pixel's partial sum over this chunk: per lane its samples in trip order plus its photons' beam terms, then
@@ -1817,7 +1824,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             sum.y += __shfl_xor(sum.y, off);
             sum.z += __shfl_xor(sum.z, off);
         }
-        if (lane_ == 0) reinterpret_cast<float4*>(a.slab)[slab_idx] = make_float4(sum.x, sum.y, sum.z, 0.f);
+        if (lane_ == 0) reinterpret_cast<float4*>(PHASE == 2 ? a.slab2 : a.slab)[slab_idx] = make_float4(sum.x, sum.y, sum.z, 0.f);
         { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 6, t1 - tk); tk = t1; }   // [6] the pixel's sum
     }
     // Diagnostic counters (counters build; added where they occur, diag_add): [0] camera samples, [5] / [6] photon spheres visited /
@@ -1896,6 +1903,8 @@ struct PhotonMapDev {
     size_t cand_words = 0;
     uint32_t* d_gather = nullptr;  // per-wave k-nearest lists of gathers too large for LDS
     size_t gather_words = 0;
+    float* d_slab2 = nullptr;      // the surface term's partial sums of the split camera pass
+    size_t slab2_bytes = 0;
     std::shared_ptr<DevPool> pool = std::make_shared<DevPool>();   // handed on to the scene's next map (fresh_map)
     void release_raw() {
         pool->free(raw_s); pool->free(raw_v);
@@ -1909,6 +1918,9 @@ struct PhotonMapDev {
         pool->free(d_overflow);
         pool->free(d_cand);
         pool->free(d_gather);
+        pool->free(d_slab2);
+        d_slab2 = nullptr;
+        slab2_bytes = 0;
         release_raw();
         d_overflow = nullptr;
         d_cand = nullptr;
@@ -2027,9 +2039,22 @@ void rpti::photon_release(void* p) {
     }
 }
 
+// The split camera pass (PHASE 1, then 2): same grid, same work items; the work counter starts again in between.
+template <bool B>
+static void launch_query_split(const QueryArgs& q, int kind, int nb, size_t lds, hipStream_t st) {
+    const dim3 g(nb), b(256);
+    if (kind == RPT_PHOTON_BEAM_BEAM) hipLaunchKernelGGL((photon_query_kernel<true, B, false, RPT_PHOTON_BEAM_BEAM, 1>), g, b, lds, st, q);
+    else hipLaunchKernelGGL((photon_query_kernel<true, B, false, RPT_PHOTON_POINT_BEAM, 1>), g, b, lds, st, q);
+    (void)hipMemsetAsync(q.r.queue, 0, 8, st);
+    if (kind == RPT_PHOTON_BEAM_BEAM) hipLaunchKernelGGL((photon_query_kernel<true, B, false, RPT_PHOTON_BEAM_BEAM, 2>), g, b, lds, st, q);
+    else hipLaunchKernelGGL((photon_query_kernel<true, B, false, RPT_PHOTON_POINT_BEAM, 2>), g, b, lds, st, q);
+}
 template <bool M, bool B, bool G>
 static void launch_query_k(const QueryArgs& q, int kind, int nb, size_t lds, hipStream_t st) {
     const dim3 g(nb), b(256);
+    if constexpr (M && !G) {
+        if (q.r.slab2 && kind != RPT_PHOTON_MAP) return launch_query_split<B>(q, kind, nb, lds, st);
+    }
     if (kind == RPT_PHOTON_MAP) hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_MAP>), g, b, lds, st, q);
     else if (kind == RPT_PHOTON_BEAM_BEAM) hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_BEAM_BEAM>), g, b, lds, st, q);
     else hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_POINT_BEAM>), g, b, lds, st, q);
@@ -2339,6 +2364,20 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         }
         q.cand = pm->d_cand;
         q.cand_cap = kCandCap;
+    }
+    // the split camera pass (option "photon_split"; off by default -- two launches cannot overlap the two estimates the way
+    // one kernel's mix of waves does: 112 ms against 95 on C4): a second slab for the surface term
+    q.r.slab2 = nullptr;
+    if (medium && !gg && pm->kind != RPT_PHOTON_MAP && rpti::option_photon_split(s)) {
+        const size_t bytes = std::max<size_t>(size_t(q.r.n_chunks) * q.r.n_owned * 16u, 16u);
+        if (bytes > pm->slab2_bytes) {
+            pm->pool->free(pm->d_slab2);
+            pm->d_slab2 = nullptr;
+            pm->slab2_bytes = 0;
+            RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->d_slab2, bytes));
+            pm->slab2_bytes = bytes;
+        }
+        q.r.slab2 = pm->d_slab2;
     }
     rc = rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch, false, true);
     if (rc == RPT_OK && sync_counters) {

@@ -61,6 +61,8 @@ struct rpt_options {
     int64_t photon_skip = 0;
     int64_t photon_block_lists = 1;
     int64_t photon_coop_gather = 1; // surface gather of a pixel's samples by the wave together (0: one search per lane)
+    int64_t photon_split = 0;       // camera pass of the beam kinds in a medium: volume estimate and surface estimate as two launches (no scratch in
+                                    // either, but 112 ms instead of 95 on C4: in one kernel the LDS-bound and the VALU-bound estimate overlap)
     int64_t photon_parts = 4;       // work items per (8x8 pixel block, sample chunk) of the photon camera pass: the block's rows in strips
     int64_t instancing = 1;         // meshes shared by several shapes are stored once and instanced
     int64_t bvh_leaf_max = 4;       // triangles per leaf of a mesh tree (read by rpt_scene_commit)
@@ -76,6 +78,8 @@ struct rpt_options {
     int64_t detach_lanes = 44;      // ... parked primary + queued shadow queries per wave that trigger a walk session
     int64_t detach_trigger = 28;    // ... or this many queued shadow queries alone (the queue holds 32)
     int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built
+    int64_t scene_tree_meshes = 0;  // 1: meshes with trees of their own are leaves of the scene tree (every query walks to completion);
+                                    // 0: they stay outside it and their walks are parked as in scenes without a scene tree (read by rpt_scene_commit)
     int64_t epsilon_policy = 0;     // 1: the reference-epsilon mode (read by rpt_scene_commit): fp64, generic shapes, t_min = 1e-12, |hit - dist| < 1e-12
 };
 static rpt_options g_defaults;
@@ -91,6 +95,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "photon_skip") o.photon_skip = value;
     else if (s == "photon_block_lists") o.photon_block_lists = value;
     else if (s == "photon_parts") o.photon_parts = value;
+    else if (s == "photon_split") o.photon_split = value;
     else if (s == "photon_coop_gather") o.photon_coop_gather = value;
     else if (s == "instancing") o.instancing = value;
     else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); o.defer_lanes = value; }
@@ -105,6 +110,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "detach_trigger") { if (value < 1 || value > 32) return fail(RPT_ERR_INVALID, "detach_trigger must be 1..32"); o.detach_trigger = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
     else if (s == "epsilon_policy") { if (value < 0 || value > 1) return fail(RPT_ERR_INVALID, "epsilon_policy must be 0 or 1"); o.epsilon_policy = value; }
+    else if (s == "scene_tree_meshes") o.scene_tree_meshes = value;
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); o.scene_bvh_min = value; }
     else return fail(RPT_ERR_INVALID, "unknown option: " + s);
     return RPT_OK;
@@ -848,6 +854,7 @@ struct Flattener {
     std::vector<uint32_t> pleaf;
     uint32_t top_root = 0;
     bool scene_bvh = false;
+    bool mesh_deferred = false;   // the scene tree does not hold the meshes that have trees of their own
     std::vector<AabbScan> pbox;
 
     static PBox xf_box(const Xf& x, bool sphere) {  // unit sphere / unit cube under an affine map
@@ -1286,11 +1293,17 @@ struct Flattener {
             for (size_t i = 0; i < tri.size(); i++) add_item(box_tri[i].lo, box_tri[i].hi, (K_TRI << 28) | uint32_t(i));
             for (size_t i = 0; i < insts.size(); i++) add_item(box_inst[i].lo, box_inst[i].hi, (K_INST << 28) | uint32_t(i));
             std::vector<uint8_t> solo(items.size(), 0);
-            for (size_t i = 0; i < meshes.size(); i++) {
-                add_item(box_mesh[i].lo, box_mesh[i].hi, (K_BVHTRI << 28) | uint32_t(i));
-                solo.push_back(1);
-            }
-            if (items.size() >= size_t(std::max<int64_t>(2, s->opt.scene_bvh_min)) || !insts.empty()) {  // instances live in the tree only
+            // Meshes with trees of their own: leaves of the scene tree (option "scene_tree_meshes" = 1), or -- the default when
+            // the tree has anything else to hold -- left outside it: a query then walks the scene tree for the small things and
+            // the mesh trees separately, and the render kernel parks the mesh walks (kernels.hip, BVH = 3).
+            const size_t n_counted = items.size() + meshes.size();   // (whether a tree is built does not depend on the option)
+            mesh_deferred = !s->opt.scene_tree_meshes && !meshes.empty() && items.size() >= 2;
+            if (!mesh_deferred)
+                for (size_t i = 0; i < meshes.size(); i++) {
+                    add_item(box_mesh[i].lo, box_mesh[i].hi, (K_BVHTRI << 28) | uint32_t(i));
+                    solo.push_back(1);
+                }
+            if (n_counted >= size_t(std::max<int64_t>(2, s->opt.scene_bvh_min)) || !insts.empty()) {  // instances live in the tree only
                 scene_bvh = true;
                 std::vector<TmpNode> tmp;
                 tmp.reserve(2 * items.size());
@@ -1439,6 +1452,7 @@ struct Flattener {
         v.meshes = (const MeshRef*)(base + o_mesh); v.n_mesh = uint32_t(meshes.size());
         v.pleaf = (const uint32_t*)(base + o_pleaf); v.n_nodes = uint32_t(nodes.size());
         v.scene_bvh = scene_bvh ? 1u : 0u;          v.top_root = top_root;
+        v.mesh_deferred = (scene_bvh && mesh_deferred) ? 1u : 0u;
         v.inst = (const InstRec*)(base + o_inst);   v.n_inst = uint32_t(insts.size());
         v.mats = (const Material*)(base + o_mats);  v.n_obj = uint32_t(mats.size());
         v.lights = (const Light*)(base + o_lights); v.n_lights = uint32_t(lights.size());
@@ -1488,7 +1502,7 @@ struct Flattener {
         // scan-record bytes every closest-hit query walks (the uniform part of the algorithmic bytes)
         s->stats[8] = 48 * (sph.size() + cub.size() + tri.size()) + 16 * pln.size() + 32 * (aabb.size() + rect.size());
         s->stats[9] = off;
-        s->stats[10] = scene_bvh ? 1 : 0;
+        s->stats[10] = scene_bvh ? (mesh_deferred ? 2 : 1) : 0;
         s->stats[11] = pleaf.size();
         s->stats[14] = has_shell ? shell_sh.size() : 0;
         s->stats[15] = uint64_t(top_depth + mesh_depth);
@@ -1920,6 +1934,7 @@ extern "C++" void*& rpti::photon_slot(rpt_scene* s) { return s->photon; }
 extern "C++" int64_t rpti::option_photon_skip(rpt_scene* s) { return s->opt.photon_skip; }
 extern "C++" int64_t rpti::option_photon_block_lists(rpt_scene* s) { return s->opt.photon_block_lists; }
 extern "C++" int64_t rpti::option_photon_parts(rpt_scene* s) { return s->opt.photon_parts; }
+extern "C++" int64_t rpti::option_photon_split(rpt_scene* s) { return s->opt.photon_split; }
 extern "C++" int64_t rpti::option_photon_coop_gather(rpt_scene* s) { return s->opt.photon_coop_gather; }
 extern "C++" double* rpti::scratch_out(rpt_scene* s, size_t bytes) {
     if (bytes > s->out_cap) {

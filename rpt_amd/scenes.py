@@ -178,6 +178,28 @@ def mesh_in_fog(nu=224, nv=224, absorb=0.005, scat=0.045):
     return scene, camera, dict(width=2048, height=2048, spp=1024, max_bounces=2, filter=0)
 
 
+def mesh_among_spheres(nu=224, nv=224, n_spheres=64, absorb=0.005, scat=0.045):
+    """C5's scene with the mesh inside a `KdTree<Box<dyn Bounded>>` of n_spheres small spheres (src/kdtree.rs:103-146, the
+    shape of examples/fractal_teapots.rs:56 with one large mesh): >= 64 bounded primitives give the scene its scene-level
+    tree, and the mesh keeps a tree of its own whose walks are parked (kernels.hip, BVH = 3)."""
+    scene, camera, cfg = mesh_in_fog(nu, nv, absorb, scat)
+    mesh_obj = scene.objects[0]
+    kids = [mesh_obj.shape]
+    for i in range(n_spheres):   # a double ring of beads around and above the torus
+        a = 2 * math.pi * i / n_spheres
+        r, y = (1.75, 0.25) if i % 2 == 0 else (1.2, 0.75)
+        kids.append(sphere().scale(vec3(0.07, 0.07, 0.07)).translate(vec3(r * math.cos(a), y, r * math.sin(a))))
+    out = Scene()
+    out.add(Object(KdTree(kids)).material(mesh_obj.material_))
+    for o in scene.objects[1:]:
+        out.add(o)
+    for l in scene.lights:
+        out.add(l)
+    for m in scene.media:
+        out.add(m)
+    return out, camera, dict(cfg, spp=256)
+
+
 def lampshade_beamphoton():
     """C4: examples/volumetric_beamphoton_lampshade.rs:139-164 (photon_point_query_beam_render)."""
     watts = 200_000.0 / (130.0 * 105.0)
@@ -242,4 +264,5 @@ CONFIGS = {
     "C3": lampshade,
     "C4": lampshade_beamphoton,
     "C5": mesh_in_fog,
+    "C5G": mesh_among_spheres,   # not a BASELINE configuration: C5's mesh inside a kd-tree group (scene tree + parked mesh walks)
 }

@@ -267,3 +267,54 @@ def test_group_as_object_light_matches_oracle(fog):
         assert np.all(np.isfinite(got)) and exp.mean() > 0
         assert rel_rms(got, exp) < 2e-2
         assert abs(got.mean() - exp.mean()) / exp.mean() < 5e-3
+
+
+def test_large_mesh_in_a_group_is_walked_outside_the_scene_tree_with_parked_walks():
+    """A `KdTree<Box<dyn Bounded>>` of 64 spheres and one mesh large enough for a tree of its own (C5's mesh in fog,
+    scenes.mesh_among_spheres): the scene-level tree holds the spheres, the mesh keeps its tree and its walks are parked like
+    those of a scene without a scene tree (kernels.hip, BVH = 3).  Closest hits and the render match the oracle's kd-tree of
+    shapes; when the parked walks start and stop changes no bit; with the mesh as a leaf of the scene tree (option
+    "scene_tree_meshes" = 1, every query walked to completion) the same triangles are found."""
+    scene, cam, cfg = scenes.mesh_among_spheres(nu=48, nv=32, n_spheres=64)
+    w, h, spp, mb = 96, 72, 16, cfg["max_bounces"]
+
+    def render(lanes=32, stop=16, leaf_quarters=6, in_tree=0):
+        rpt_amd.set_option("scene_tree_meshes", in_tree)
+        rpt_amd.set_option("defer_lanes", lanes)
+        rpt_amd.set_option("defer_stop", stop)
+        rpt_amd.set_option("walk_leaf_quarters", leaf_quarters)
+        sc, cm, _ = scenes.mesh_among_spheres(nu=48, nv=32, n_spheres=64)
+        r = Renderer(sc, cm).width(w).height(h).max_bounces(mb).seed(4)
+        img = r.sample_array(spp)
+        st = r.scene_stats()
+        assert st["scene_bvh"] == (1 if in_tree else 2) and st["bvh_tris"] == 48 * 32 * 2   # the mesh: a leaf of the scene tree, or outside it
+        assert st["scene_bvh_prims"] == 65                           # 64 spheres + the lamp's rectangle
+        return img, r
+    try:
+        frames = [render(*v)[0] for v in ((32, 16), (1, 1), (64, 64), (64, 1), (8, 5), (32, 16, 0), (40, 8, 64))]
+        in_tree, _ = render(in_tree=1)
+        img, r = render()
+        rng = np.random.default_rng(12)
+        ro, rd = random_rays(rng, 20000, np.array([0.0, 0.0, 0.0]), 4.0)
+        t, obj, nrm = r.get_closest_hit(ro, rd)
+    finally:
+        rpt_amd.set_option("scene_tree_meshes", 0)
+        rpt_amd.set_option("defer_lanes", 32)
+        rpt_amd.set_option("defer_stop", 16)
+        rpt_amd.set_option("walk_leaf_quarters", 6)
+    for f in frames[1:]:
+        assert np.array_equal(frames[0], f)
+    assert rel_rms(in_tree, frames[0]) < 2e-4 and abs(in_tree.mean() - frames[0].mean()) < 1e-5 * frames[0].mean()
+    orc = _oracle(scene)
+    te, oe, ne = orc.intersect(ro.astype(np.float32), rd.astype(np.float32), robust=1)
+    hit = oe >= 0
+    assert hit.sum() > 2000
+    same = (obj >= 0) == hit
+    assert same.mean() > 0.9995                                        # (grazing rays may fall either way in fp32)
+    both = hit & (obj >= 0)
+    assert np.array_equal(obj[both], oe[both])
+    assert np.max(np.abs(t[both] - te[both]) / te[both]) < 2e-4
+    exp = orc.render(cam, w, h, spp, mb, seed=4, robust=1)
+    assert np.all(np.isfinite(frames[0])) and exp.mean() > 0
+    assert rel_rms(frames[0], exp) < 1e-2
+    assert abs(frames[0].mean() - exp.mean()) / exp.mean() < 5e-3
