@@ -259,6 +259,9 @@ def parse_args(argv):
     ap.add_argument("--exchange", default="gather", choices=("gather", "reduce"),
                     help="N > 1: how rank 0 gets the frame -- gather of the owned tiles through the library's own RCCL communicator "
                          "(rpt_gather_frame_device, default) or torch.distributed's sum-reduce of zero-padded full frames")
+    ap.add_argument("--chunk-spp", type=int, default=0, help="diagnostic: samples per work item (option chunk_spp; 0 = the automatic rule)")
+    ap.add_argument("--emulate-shard", type=int, default=0,
+                    help="diagnostic, one GPU: render only rank 0's tiles of an N-rank job (the step time of one rank of N, without the exchange)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl) and the frame exchange even with one rank, to rehearse the N > 1 code path")
     ap.add_argument("--dryrun-cpu", action="store_true",
@@ -320,8 +323,11 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
     spp = (args.spp if headline else 0) or cfg["spp"]
     rpt_amd.set_option("timing", 1)
     rpt_amd.set_option("counters", 0)
+    rpt_amd.set_option("chunk_spp", args.chunk_spp if headline else 0)
     r = Renderer(scene, cam).width(width).height(height).max_bounces(cfg["max_bounces"]).seed(0)
     r.device(local_rank).shard(rank, world)
+    if headline and args.emulate_shard > 1 and world == 1:
+        r.shard(0, args.emulate_shard)
     photon = "photons" in cfg   # C4: Renderer::photon_render = shoot + build the map + camera pass, every step
     n_photons = 0
     if photon:
@@ -577,7 +583,7 @@ def main(argv=None):
                "steps": head.pop("steps"), "warmup": head.pop("warmup"), "ms_per_step": head.pop("ms_per_step"),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": head.pop("dtype"), "data": "synthetic"}
         out.update(head)
-    default_run = args.workload == "C3" and not (args.width or args.height or args.spp)
+    default_run = args.workload == "C3" and not (args.width or args.height or args.spp or args.chunk_spp or args.emulate_shard)
     if world == 1 and dist is None and default_run and not args.no_secondary:
         secondary = []
         for wl in ("C2", "C4", "C5", "C5G"):

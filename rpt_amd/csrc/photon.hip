@@ -1531,6 +1531,14 @@ RPT_DEV void surface_gather_lane(QueryK q, const SceneView& sc_arg, const Gather
     bool touched = true;
     if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, true, s.x, __builtin_sqrtf(s.max_d2) * (1.f + 1e-4f) + 1e-6f, &touched);
     const bool lane_clear = !BVH && !touched && sc.n_pln == 0u && !(q.skip & 128u) && shell.holds(s.x);   // as in gather_serve
+    // The K nearest come out of the search in an order that depends on the walk (which other lanes were live, where the
+    // previous gather's radius let it start): the terms are summed in photon-index order instead, a function of the set alone.
+    for (uint32_t i = 1; i < found; i++) {
+        const uint32_t v = l.gi[i * 64u];
+        uint32_t j = i;
+        for (; j > 0u && l.gi[(j - 1u) * 64u] > v; j--) l.gi[j * 64u] = l.gi[(j - 1u) * 64u];
+        l.gi[j * 64u] = v;
+    }
     for (uint32_t k = 0; k < found; k++) {
         const PhotonRec ph = q.s_ph[l.gi[k * 64u]];
         const bool lane_free = lane_clear && shell.holds(xyz(ph.pos_r));
@@ -1628,6 +1636,13 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
             pi = __builtin_amdgcn_readfirstlane(part * per_part);
             pi_end = pi + per_part;
             cand_valid = false;
+            // What a lane carries from one pixel's surface gather to the next -- its last gather radius, the wave's anchor -- starts
+            // afresh with the work item: which item a wave had before depends on the work queue, and the radius decides in which
+            // round, hence in which order, a sample's photon terms are added.  (photon_skip bit 2048 keeps them: diagnostic.)
+            if (!(q.skip & 2048u)) {
+                prev_r2 = 0.f;
+                anc = Anchor{mk(0, 0, 0), 0.f, 0u};
+            }
             if (cand_mode) {
                 // the four corner directions of the strip (footprints included): every sample ray lies between them
                 const float e = a.inv_dim * 1.0001f;
@@ -1653,6 +1668,30 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     });
                     cand_n = n_list;
                     cand_valid = n_list <= q.cand_cap;  // an overfull list is dropped: those pixels walk the tree
+                    // The walk lists the strip's photons in the order its lanes happen to reach them.  A pixel's beam terms are
+                    // summed in list order, so the list is put into photon-index order (bitonic sort in the wave's LDS region,
+                    // free at this point): a pixel's sum then no longer depends on how the block was cut into strips.
+                    if (cand_valid && n_list > 1u && n_list <= q.region_dwords && !(q.skip & 1024u)) {
+                        uint32_t n2 = 2u;
+                        while (n2 < n_list) n2 <<= 1;
+                        if (n2 <= q.region_dwords) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the walk's stores, before other lanes read them
+                            for (uint32_t i = lane_; i < n2; i += 64u) region[i] = i < n_list ? cand[i] : 0xFFFFFFFFu;
+                            __builtin_amdgcn_wave_barrier();
+                            for (uint32_t k = 2u; k <= n2; k <<= 1)
+                                for (uint32_t j = k >> 1; j != 0u; j >>= 1) {
+                                    for (uint32_t t = lane_; t < (n2 >> 1); t += 64u) {
+                                        const uint32_t i = 2u * t - (t & (j - 1u)), ixj = i | j;
+                                        const uint32_t va = region[i], vb = region[ixj];
+                                        if ((va > vb) == ((i & k) == 0u)) { region[i] = vb; region[ixj] = va; }
+                                    }
+                                    __builtin_amdgcn_wave_barrier();
+                                }
+                            for (uint32_t i = lane_; i < n_list; i += 64u) cand[i] = region[i];
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
                 }
             }
         }
@@ -1778,6 +1817,9 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                 }
             }
         } else if (PHASE != 2 && MEDIUM && !(q.skip & 1u) && !beam_lanes) {  // beam estimates with the samples in the lanes
+            // (this walk's pending entries and staging slots lie where a pixel's candidate list would: `pix_gather` rules the list out
+            // for such pixels -- counted in the counters build should the two ever meet again)
+            if (a.counters && plist.valid) diag_add(a.counters, 23, 1ull);
             const V vc = volume_estimate_sample_lanes<KIND>(q, active, ro, rd, hit, t, sigma_t, sc.medium_phase, wstack, stage);
             color = vc * mcol0;
         }
@@ -1830,7 +1872,8 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
     // Diagnostic counters (counters build; added where they occur, diag_add): [0] camera samples, [5] / [6] photon spheres visited /
     // accepted; the wave-level surface gather: [8] trips with a gather, [9] photon terms without a visibility scan, [10] steps of
     // the ball walks, [11] candidates, [12] overfull walks, [13] / [14] selection steps / list updates, [15] / [16] candidates looked
-    // at / photon terms of the second pass, [17] new anchors, [18] / [19] trips / lanes that searched one by one; [24..33] clock
+    // at / photon terms of the second pass, [17] new anchors, [18] / [19] trips / lanes that searched one by one; [23] trips in which
+    // two layouts of the wave's LDS region were live at once (must stay 0); [24..33] clock
     // ticks (100 MHz) per part of a pixel, summed over the waves.
 }
 
@@ -2308,7 +2351,8 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     QueryArgs q{};
     // Work items of the camera pass are wave-level: (a strip of rows of an 8x8 pixel block, chunk of up to kSuper
     // samples); the chunking is fixed here (whatever the "chunk_spp" option says) and prepare_render sizes the slab
-    // [n_chunks][n_owned] for it.  How many strips a block is cut into changes no pixel's arithmetic.
+    // [n_chunks][n_owned] for it.  How many strips a block is cut into ("photon_parts") changes the order in which a pixel's beam
+    // terms are added (the strip's candidate list), i.e. the last bits of the image (1e-6), nothing else.
     int rc = rpti::prepare_render(s, st, cam, prm, num_samples, seed, sample_offset, q.r, 0, kSuper);
     if (rc) return rc;
     rc = rpti::serialize_with_other_streams(s, st);  // candidate lists and the overflow flag exist once per scene

@@ -112,6 +112,18 @@ def test_photon_beam_walk_without_a_common_ray_origin():
     exp = pm.render(lens, size, size, spp, seed=6)
     assert np.all(np.isfinite(got)) and exp.mean() > 0
     assert rel_rms(got, exp) < 1e-2 and abs(got.mean() - exp.mean()) / exp.mean() < 3e-3
+    # The wave-private LDS region of the camera pass serves three layouts in turn (photon.hip, photon_query_kernel): this
+    # camera once had a pixel's candidate list and the per-sample beam walk live in it together.  The counters build counts
+    # such trips.
+    import ctypes as C
+    from rpt_amd import _lib
+    scene.set_option("counters", 1)
+    r._sample_offset = 0
+    again = r.photon_sample_array(spp)
+    out = (C.c_uint64 * 56)()
+    _lib.check(_lib.load().rpt_debug_section_counters(r.scene._handle, out))
+    assert int(out[15]) == 0      # counters[23]: trips with two layouts live at once
+    assert np.allclose(again, got, rtol=1e-6, atol=1e-9)
 
 
 def test_timing_events_are_kept_per_launch_and_read_afterwards():

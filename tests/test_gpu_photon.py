@@ -306,10 +306,15 @@ def test_block_candidate_lists_equal_the_per_sample_walk(w, h, spp):
 @pytest.mark.parametrize("w,h,spp", [(64, 64, 70), (40, 24, 300)])
 def test_strips_per_block_of_the_camera_pass(w, h, spp):
     """A work item of the camera pass is a strip of rows of an 8x8 pixel block x up to 256 samples ("photon_parts"
-    strips per block).  How the blocks are cut decides which wave renders a pixel and in which order the strip's
-    candidate photons are listed -- i.e. the fp32 order of a pixel's beam sum, never which photons are in it: images
-    for different cuts agree to rounding, a repeated render with the same cut is bit-identical.  300 samples = two
-    chunks, the second one ragged."""
+    strips per block).  How the blocks are cut decides which wave renders a pixel and which photons its strip's candidate
+    list holds -- never which of them pass the pixel's own cull, and the list is kept in photon-index order (sorted in
+    the wave's LDS region: free, 97.7 against 98.5 ms on C4), so a pixel's BEAM sum does not depend on the cut.  Its
+    SURFACE terms still do, in the last bits: a sample's K nearest photons are collected around the pixel's first surface
+    point with a radius guessed from the lane's previous gather, and a sample that guess fails is served in a later round,
+    whose candidates are ordered around another point -- and the previous gather is the strip's previous pixel.  (Guessing
+    from nothing at every pixel sends its first 64 samples through one search per lane: the slow path that the guess exists
+    to avoid.)  So: bit-identical for a given cut, whatever the work queue hands a wave -- the guess starts afresh with every
+    work item --, equal to 1e-6 across cuts.  300 samples = two chunks, the second one ragged."""
     import rpt_amd
     scene, cam, cfg = scenes.CONFIGS["C4"]()
     n = 30000
