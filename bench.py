@@ -276,11 +276,25 @@ class Exchange:
 
     def __init__(self, torch, dist, mode, width, height, local_rank):
         self.torch, self.dist, self.mode, self.w, self.h = torch, dist, mode, width, height
-        self.comm, self.stream = None, None
+        self.comm, self.stream, self.fallback = None, None, None
         if mode == "gather":
             from rpt_amd.dist import FrameComm
-            self.comm = FrameComm.from_torch(dist, local_rank)
-            self.stream = torch.cuda.Stream()
+            try:
+                self.comm = FrameComm.from_torch(dist, local_rank)
+                ok = 1
+            except Exception as e:   # the library's communicator could not be formed on this rank
+                self.fallback, ok = f"{type(e).__name__}: {e}", 0
+            # every rank takes the same route: the gather only if all of them have a communicator
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if self.comm is not None:
+                    self.comm.close()
+                    self.comm = None
+                self.fallback = self.fallback or "another rank could not form the communicator"
+                self.mode = "reduce"
+            else:
+                self.stream = torch.cuda.Stream()
 
     def issue(self, frame, on):
         """Behind the render that `on` has just been given; returns what the next user of `frame` has to wait for."""
@@ -386,7 +400,7 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
 
     def drain():
         for fi in range(n_frames):
-            if last_use[fi] is not None and last_use[fi][0] == "xchg" and args.exchange == "reduce":
+            if last_use[fi] is not None and last_use[fi][0] == "xchg" and xchg.mode == "reduce":
                 last_use[fi][1].wait()
         torch.cuda.synchronize()
 
@@ -478,7 +492,9 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
     if host_elapsed is not None:
         out["value_host_resident"] = round(samples_per_step / host_elapsed / 1e6, 3)
         out["ms_per_step_host_resident"] = round(host_elapsed * 1e3, 3)
-    parallelism = f"tile-shard x{world}" + (f", frame {args.exchange} on rank 0" if dist is not None else "")
+    parallelism = f"tile-shard x{world}" + (f", frame {xchg.mode} on rank 0" if xchg is not None else "")
+    if xchg is not None and xchg.fallback:
+        out["exchange_fallback"] = f"rpt_gather_frame_device unavailable ({xchg.fallback}): torch.distributed sum-reduce used instead"
 
     # one extra, untimed pass with device counters on (rank-local work) for the algorithmic figures
     r.scene.set_option("timing", 0)

@@ -64,6 +64,10 @@ RPT_DEV T uload(const T* p) {
 // asserts next to each), so kernarg + 0 is the view.  Reading a field through this pointer -- constant address space,
 // behind an opaque copy of the pointer -- is a scalar load at the place of use; read as a plain kernel argument it is
 // hoisted to the kernel's entry and held in a scalar register for the kernel's whole life.
+// CONSEQUENCE: the `const SceneView&` parameter that scan_prims, closest_hit, finalize_hit, load_mat, env_color, ... still take
+// is NOT what they read -- it only keeps the call sites readable.  A kernel whose first argument is not the view, or a caller
+// that builds a modified copy of the view, would silently get the launch's own view: every kernel that calls these functions
+// carries a static_assert (or, for intersect_kernel, a comment) that its argument struct begins with the SceneView.
 typedef const __attribute__((address_space(4))) SceneView* KernargView;
 RPT_DEV KernargView kernarg_scene() {
     KernargView kv = (KernargView)__builtin_amdgcn_kernarg_segment_ptr();

@@ -55,6 +55,11 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 #ifndef RPT_MIN_WAVES_MESH
 #define RPT_MIN_WAVES_MESH 4  // per-mesh-tree instantiations (BVH = 1)
 #endif
+#ifndef RPT_MIN_WAVES_SCENE_MESH
+#define RPT_MIN_WAVES_SCENE_MESH 3  // scene tree + per-mesh trees (BVH = 3): at 4 (128 VGPRs) the walk of the scene tree inlined into the parked-walk
+                                    // machine costs 112 B/lane of scratch -- a footprint of 3.7 MB per XCD against 4 MB of L2: 647 GB of writes per
+                                    // C5G frame -- and 253.9 ms at 2048x2048x64; 3 (168 VGPRs, no scratch): 219.5
+#endif
 #ifndef RPT_MIN_WAVES_STREAM
 #define RPT_MIN_WAVES_STREAM 4  // per-mesh-tree instantiation with streamed walks (DETACH = 2); 3 (168 VGPRs) has no scratch
 #endif
@@ -209,7 +214,7 @@ RPT_DEV bool stage_bounce(const RenderArgs& a, float albedo_med, V rd, uint32_t 
 // DETACH (per-mesh-tree kernels in a medium): shadow queries that need a tree walk leave their path (see the loop body).
 // DETACH = 2: primary queries leave as well -- their paths wait in memory and the lane goes on with another one.
 template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false, int DETACH = 0>
-__global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : (BVH == 1 || BVH == 3) ? (DETACH == 2 ? RPT_MIN_WAVES_STREAM : RPT_MIN_WAVES_MESH) : RPT_MIN_WAVES)
+__global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : BVH == 3 ? RPT_MIN_WAVES_SCENE_MESH : BVH == 1 ? (DETACH == 2 ? RPT_MIN_WAVES_STREAM : RPT_MIN_WAVES_MESH) : RPT_MIN_WAVES)
 void render_kernel(const RenderArgs a) {
     static_assert(DETACH == 0 || (MEDIUM && BVH == 1 && !GROUPS), "detached tree walks: per-mesh-tree kernels in a medium only");
     extern __shared__ uint32_t dyn_lds[];
@@ -1362,6 +1367,8 @@ __global__ __launch_bounds__(256) void frame_tiles_kernel(const double* __restri
     else if (inside) dst[f] = src[e];
 }
 
+// (The SceneView MUST stay this kernel's first parameter: the device functions read the view from the kernel-argument segment at
+// offset 0 -- kernarg_scene() in device_core.h -- whatever reference they are handed.)
 template <int BVH>
 __global__ __launch_bounds__(256) void intersect_kernel(const SceneView sc, uint64_t n, const float* __restrict__ o,
                                                         const float* __restrict__ d, float* __restrict__ t_out,

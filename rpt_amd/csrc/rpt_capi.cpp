@@ -67,7 +67,7 @@ struct rpt_options {
     int64_t instancing = 1;         // meshes shared by several shapes are stored once and instanced
     int64_t bvh_leaf_max = 4;       // triangles per leaf of a mesh tree (read by rpt_scene_commit)
     int64_t bvh_max_depth = 20;     // a mesh tree deeper than this is rebuilt balanced (read by rpt_scene_commit)
-    int64_t bvh_sweep_below = 0;    // ranges of at most this many triangles are split by an exact SAH sweep instead of 16 bins (read by rpt_scene_commit; 0 = bins only)
+    int64_t bvh_sweep_below = 4096; // ranges of at most this many triangles are split by an exact SAH sweep instead of 16 bins (read by rpt_scene_commit; 0 = bins only)
     int64_t defer_stop = 16;        // still-walking lanes below which a wave leaves the walk (the rest resume later)
     int64_t walk_leaf_quarters = 6; // deferred walks: test the leaves when 4 x (lanes at a leaf) >= this x (lanes still descending); 0 = when all are there
     int64_t defer_lanes = 32;       // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)

@@ -24,7 +24,7 @@ i=0
 for group in "${GROUPS_ALL[@]}"; do
   i=$((i+1))
   if [ $QUICK = 1 ] && [ $i -gt 4 ]; then break; fi
-  rocprofv3 --kernel-trace --pmc $group -d "$OUT/pass$i" -o p --output-format csv -- python3 "$REPO/bench.py" --workload "$WL" --streams 1 --steps 1 --warmup 1 --no-cpu-baseline "$@" > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/pass$i.log"; }
+  rocprofv3 --kernel-trace --pmc $group -d "$OUT/pass$i" -o p --output-format csv -- python3 "$REPO/bench.py" --workload "$WL" --streams 1 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary "$@" > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/pass$i.log"; }
   echo "pass $i done"
 done
 cd "$REPO"
