@@ -86,7 +86,10 @@ static constexpr uint32_t kDetachDwords = kDetachQBase + 4u * kQWaveDwords;
 static_assert(kDetachAccBase % 2u == 0u, "the 64-bit accumulators are 8-byte aligned");
 // DETACH = 2 ("streamed walks"): per wave, in global memory (RenderArgs::stream_scratch; only this wave ever touches its
 // part), a FIFO ring of queries and kCtxMax parked path contexts per lane.
-static constexpr uint32_t kRingEntries = 512u;   // queries a wave can hold; a session is forced before the ring could overflow
+#ifndef RPT_STREAM_RING
+#define RPT_STREAM_RING 512
+#endif
+static constexpr uint32_t kRingEntries = RPT_STREAM_RING;   // queries a wave can hold; a session is forced before the ring could overflow
 static constexpr uint32_t kRingDwords = 12u;     // origin, direction | end of the interval, 3 words by kind | meta, pad (3 x 16 B)
 static constexpr uint32_t kCtxMax = 6u;          // parked paths per lane (RenderArgs::stream_contexts of them are used)
 static constexpr uint32_t kCtxFields = 20u;      // origin, direction, P, Q, RNG state, depth, medium distance, answer (t, code)

@@ -73,8 +73,9 @@ struct rpt_options {
     int64_t defer_lanes = 32;       // parked tree walks per wave that trigger a walk (per-mesh-tree kernels)
     int64_t detach_shadows = 1;     // per-mesh-tree kernels in a medium: 1 = shadow queries that need a tree walk leave their path (0: they park
                                     // the lane), 2 = every tree walk leaves its path ("streamed walks": ring + parked paths in memory)
-    int64_t stream_backlog = 64;    // detach_shadows = 2: queries in a wave's ring that trigger a walk session
-    int64_t stream_contexts = 4;    // detach_shadows = 2: paths a lane can have waiting in memory (1..6)
+    int64_t stream_backlog = 48;    // detach_shadows = 2: queries in a wave's ring that trigger a walk session
+    int64_t stream_contexts = 1;    // detach_shadows = 2: paths a lane can have waiting in memory (1..6; C5: 272 / 279 / 290 ms for 1 / 2 / 4 at
+                                    // 2048x2048x128 -- every parked path is a round trip to the fabric --, 234 with detach_shadows = 1)
     int64_t detach_lanes = 44;      // ... parked primary + queued shadow queries per wave that trigger a walk session
     int64_t detach_trigger = 28;    // ... or this many queued shadow queries alone (the queue holds 32)
     int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built

@@ -358,12 +358,14 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
         streamed = []
         if fog:
             rpt_amd.set_option("detach_shadows", 2)
-            for backlog, stop in ((128, 16), (1, 1), (256, 64), (64, 32), (200, 1)):
+            for backlog, stop, contexts in ((128, 16, 4), (1, 1, 1), (256, 64, 6), (64, 32, 2), (200, 1, 3), (48, 16, 1)):
                 rpt_amd.set_option("stream_backlog", backlog)
+                rpt_amd.set_option("stream_contexts", contexts)
                 streamed.append(render(32, stop))
     finally:
         rpt_amd.set_option("detach_shadows", 1)
-        rpt_amd.set_option("stream_backlog", 128)
+        rpt_amd.set_option("stream_backlog", 48)
+        rpt_amd.set_option("stream_contexts", 1)
         rpt_amd.set_option("defer_lanes", 32)
         rpt_amd.set_option("defer_stop", 16)
         rpt_amd.set_option("walk_leaf_quarters", 6)
