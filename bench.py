@@ -384,7 +384,7 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
             st = on.cuda_stream
             if photon:
                 if dist is not None:   # shooting sharded by photon index, records all-gathered over RCCL
-                    photon_map_build_sharded(r, n_photons, Renderer.PHOTON_POINT_BEAM, rank, world)
+                    photon_map_build_sharded(r, n_photons, Renderer.PHOTON_POINT_BEAM, rank, world, comm=xchg.comm)
                 else:
                     r.photon_map_build(n_photons, Renderer.PHOTON_POINT_BEAM)
                 r.photon_sample_device(spp, frames[fi].data_ptr(), st)
@@ -571,6 +571,12 @@ def main(argv=None):
         # not under a launcher: become the launcher.  Nothing below this line runs in this process.
         sys.exit(spawn_ranks(args.gpus, argv))
 
+    # Rank 0 prints ONE line on stdout.  Libraries write there too (RCCL prints a version banner when a communicator is formed), so
+    # file descriptor 1 points at stderr for the run and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch  # before the HIP library: one shared HIP runtime (rpt_amd/_lib.py)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -589,7 +595,7 @@ def main(argv=None):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()   # n_gpus in the line = the ranks the communicator actually formed
     if args.dryrun_cpu:
-        return dryrun_cpu(args, dist, rank, world)
+        return dryrun_cpu(args, dist, rank, world, json_fd)
     torch.cuda.set_device(local_rank)
 
     head = measure(args.workload, args, args.steps, args.warmup, args.streams, torch, dist, rank, local_rank, world, True)
@@ -611,13 +617,14 @@ def main(argv=None):
                                  "2048x2048x256), 2 timed steps each after 1 warm-up, strictly one stream (ms_per_step = wall_clock_s x 1000), "
                                  "same definitions as the headline")
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def dryrun_cpu(args, dist, rank, world):
+def dryrun_cpu(args, dist, rank, world, json_fd=1):
     """--dryrun-cpu: everything around the device work -- argument handling, rank launch, rendezvous, tile sharding,
     the per-step frame reduce to rank 0, max-over-ranks timing, the JSON line -- on the CPU with gloo.  Each rank
     writes 1.0 into the pixels of the tiles it owns; the reduced frame must be all ones."""
@@ -643,12 +650,13 @@ def dryrun_cpu(args, dist, rank, world):
         elapsed = float(t.item())
     if rank == 0:
         ok = bool(np.all(out.numpy() == 1.0))
-        print(json.dumps({"metric": "Msamples/sec", "value": 0.0, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps({"metric": "Msamples/sec", "value": 0.0, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "dryrun": True, "frame_assembled": ok,
                           "config": {"workload": f"dry run {width}x{height}: tile shards reduced to rank 0, no device work",
-                                     "parallelism": f"tile-shard x{world}"}}), flush=True)
+                                     "parallelism": f"tile-shard x{world}"}}) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -280,6 +280,14 @@ int rpt_comm_rank(const rpt_comm*, int* rank, int* n_ranks);
 #define RPT_GATHER_LOOPBACK 1u
 int rpt_gather_frame_device(rpt_comm*, uint32_t width, uint32_t height, const void* d_shard, void* d_frame,
                             uint32_t flags, void* hip_stream);
+/* The photon maps' exchange step: the shooting loop (src/photon.rs:656-690) is sharded by photon index (rpt_photon_shoot) and
+ * every rank builds the whole map, so the shot records (rpt_photon_records: RPT_PHOTON_RECORD_BYTES each) are all-gathered in
+ * rank order -- contiguous blocks in rank order ARE the single-GPU arrays.  Collective.  d_local / n_local: this rank's records
+ * (device); d_out: room for `capacity` records (device); n_per_rank (optional, n_ranks values) and n_total are filled on the host;
+ * the call synchronises hip_stream once (the second all-gather is sized by the counts of the first).  If `capacity` is too
+ * small the call fails with RPT_ERR_INVALID after filling n_total -- on every rank alike -- and can be repeated with room. */
+int rpt_allgather_records_device(rpt_comm*, const void* d_local, uint64_t n_local, void* d_out, uint64_t capacity,
+                                 uint64_t* n_per_rank, uint64_t* n_total, void* hip_stream);
 /* The packed layout (pure host function): tile_offsets[r] = first tile of rank r's block in the gathered buffer,
  * r = 0..n_ranks (tile_offsets[n_ranks] = tiles of the whole frame); a tile is 32*32*3 f64. */
 int rpt_frame_pack_layout(uint32_t width, uint32_t height, uint32_t n_ranks, uint64_t* tile_offsets);

@@ -122,6 +122,7 @@ SYMBOLS = [
     ("rpt_comm_destroy", None, [_P]),
     ("rpt_comm_rank", C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("rpt_gather_frame_device", C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, C.c_uint32, _P]),
+    ("rpt_allgather_records_device", C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _P]),
     ("rpt_frame_pack_layout", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     ("rpt_frame_pack_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
     ("rpt_frame_unpack_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),

@@ -54,7 +54,7 @@ uint64_t seed_mix(uint64_t seed) {
 // be driven from different host threads.
 struct rpt_options {
     int64_t counters = 0;
-    int64_t chunk_spp = 0;          // 0 = auto: ceil(iterations / 32) clamped to [2, 32]
+    int64_t chunk_spp = 0;          // 0 = auto: ceil(iterations / 16) clamped to [2, 32]
     int64_t blocks_per_cu = 0;      // 0 = occupancy query
     int64_t timing = 0;
     int64_t room_shell = 1;         // fold rectangles that are the faces of one box into a single slab test
@@ -1729,13 +1729,14 @@ extern "C" int64_t rpt_shard_tiles(uint32_t width, uint32_t height, uint32_t sha
 
 // Samples per work item.  Small items keep the persistent grid's tail short when a GPU owns only 1/8 of the
 // tiles; the value depends on `iterations` alone so that the fp32 partial sums, and hence the image bits, do not
-// change with the shard count.  At most 32 chunks per pixel (C3: 8 samples per item, 0.54 GB of partial sums per launch instead of the
+// change with the shard count.  At most 16 chunks per pixel (C3: 16 samples per item, 0.27 GB of partial sums per launch instead of the
 // 1.07 GB of 4-sample items; measured with consecutive steps on two streams (tools/chunk_pipelined.py): 25.46 / 25.26 / 25.02 / 24.86 ms per
-// step for 4 / 8 / 16 / 32 on the whole frame, 3.31 / 3.34 / 3.40 / 3.51 ms on one rank's shard of an 8-GPU job).
+// step for 4 / 8 / 16 / 32 on the whole frame, 3.31 / 3.34 / 3.40 / 3.51 ms on one rank's shard of an 8-GPU job: an item is also a trip
+// through the work-pull code for the whole wave, which some lane needs in 95 % of the trips with 8-sample items and 77 % with 16).
 static uint32_t chunk_rule(int64_t opt_chunk_spp, uint32_t iterations, uint32_t min_chunk, uint32_t fixed_chunk) {
     if (fixed_chunk) return fixed_chunk;
     const int64_t chunk = opt_chunk_spp > 0 ? opt_chunk_spp
-                                              : std::min<int64_t>(32, std::max<int64_t>(std::max<int64_t>(2, min_chunk), (int64_t(iterations) + 31) / 32));
+                                              : std::min<int64_t>(32, std::max<int64_t>(std::max<int64_t>(2, min_chunk), (int64_t(iterations) + 15) / 16));
     return uint32_t(std::min<int64_t>(chunk, iterations));
 }
 int rpt_render_chunking(uint32_t iterations, uint32_t* chunk_spp, uint32_t* n_chunks) {

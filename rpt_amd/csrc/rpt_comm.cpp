@@ -30,6 +30,7 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string error;
 };
@@ -57,6 +58,7 @@ void load_rccl() {
     g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
     g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(sym("ncclSend"));
     g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(sym("ncclAllGather"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
     if (g_rccl.error.empty()) g_rccl.handle = h;
 }
@@ -105,6 +107,10 @@ struct rpt_comm {
     uint32_t* d_tiles = nullptr;   // layout.all
     double* d_stage = nullptr;     // rank 0: every rank's block (whole frame worth of tiles); others: their own block
     size_t stage_cap = 0, tiles_cap = 0;
+    // photon records: counts of every rank, and the padded blocks of the all-gather
+    unsigned long long* d_counts = nullptr;
+    void* d_rec_stage = nullptr;
+    size_t rec_stage_cap = 0;
 };
 
 extern "C" {
@@ -139,6 +145,8 @@ void rpt_comm_destroy(rpt_comm* c) {
     (void)hipSetDevice(c->device);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_rec_stage) (void)hipFree(c->d_rec_stage);
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     delete c;
 }
@@ -266,6 +274,54 @@ int rpt_gather_frame_device(rpt_comm* c, uint32_t width, uint32_t height, const 
     if (!loop && frame != shard) {   // own tiles into a separate frame: pack + unpack on the device
         RPTI_HIP_TRY(rptg::launch_frame_pack(shard, c->d_stage, c->d_tiles, n_of(0), L.tiles_x, width, height, st));
         RPTI_HIP_TRY(rptg::launch_frame_unpack(c->d_stage, frame, c->d_tiles, n_of(0), L.tiles_x, width, height, st));
+    }
+    return RPT_OK;
+}
+
+// The photon maps' exchange step (src/photon.rs:656-690 sharded by photon index): every rank needs every rank's records, in
+// rank order.  Two ncclAllGathers -- the counts, then blocks padded to the largest count -- and one device copy per rank
+// that closes the gaps.  The counts come to the host in between (the second collective is sized by them).
+int rpt_allgather_records_device(rpt_comm* c, const void* d_local, uint64_t n_local, void* d_out, uint64_t capacity,
+                                 uint64_t* n_per_rank, uint64_t* n_total, void* hip_stream) {
+    if (!c || !n_total) return fail(RPT_ERR_INVALID, "null argument");
+    if (n_local && !d_local) return fail(RPT_ERR_INVALID, "null records");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    RPTI_HIP_TRY(hipSetDevice(c->device));
+    const size_t n = size_t(c->n_ranks);
+    if (!c->d_counts) RPTI_HIP_TRY(hipMalloc((void**)&c->d_counts, (n + 1) * sizeof(unsigned long long)));
+    // [n]: this rank's count (send buffer), [0, n): everybody's
+    unsigned long long mine = n_local;
+    RPTI_HIP_TRY(hipMemcpyAsync(c->d_counts + n, &mine, sizeof(mine), hipMemcpyHostToDevice, st));
+    RCCL_TRY(g_rccl.AllGather(c->d_counts + n, c->d_counts, 1, ncclUint64, c->comm, st));
+    std::vector<unsigned long long> counts(n);
+    RPTI_HIP_TRY(hipMemcpyAsync(counts.data(), c->d_counts, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    RPTI_HIP_TRY(hipStreamSynchronize(st));
+    uint64_t total = 0, largest = 0;
+    for (size_t r = 0; r < n; r++) {
+        if (n_per_rank) n_per_rank[r] = counts[r];
+        total += counts[r];
+        largest = std::max<uint64_t>(largest, counts[r]);
+    }
+    *n_total = total;
+    if (total > capacity) return fail(RPT_ERR_INVALID, "rpt_allgather_records_device: the output holds fewer records than the ranks have shot");
+    if (total == 0) return RPT_OK;
+    if (!d_out) return fail(RPT_ERR_INVALID, "null output");
+    const size_t block = size_t(largest) * RPT_PHOTON_RECORD_BYTES;
+    const size_t need = block * (n + 1);   // the padded copy of this rank's records + every rank's block
+    if (need > c->rec_stage_cap) {
+        if (c->d_rec_stage) RPTI_HIP_TRY(hipFree(c->d_rec_stage));
+        c->d_rec_stage = nullptr; c->rec_stage_cap = 0;
+        RPTI_HIP_TRY(hipMalloc(&c->d_rec_stage, need));
+        c->rec_stage_cap = need;
+    }
+    char* const send = static_cast<char*>(c->d_rec_stage), *const recv = send + block;
+    if (n_local) RPTI_HIP_TRY(hipMemcpyAsync(send, d_local, size_t(n_local) * RPT_PHOTON_RECORD_BYTES, hipMemcpyDeviceToDevice, st));
+    RCCL_TRY(g_rccl.AllGather(send, recv, block, ncclUint8, c->comm, st));
+    size_t at = 0;
+    for (size_t r = 0; r < n; r++) {
+        const size_t bytes = size_t(counts[r]) * RPT_PHOTON_RECORD_BYTES;
+        if (bytes) RPTI_HIP_TRY(hipMemcpyAsync(static_cast<char*>(d_out) + at, recv + r * block, bytes, hipMemcpyDeviceToDevice, st));
+        at += bytes;
     }
     return RPT_OK;
 }

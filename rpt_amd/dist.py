@@ -54,6 +54,15 @@ class FrameComm:
                                                        _C.c_void_p(d_frame) if d_frame else None,
                                                        GATHER_LOOPBACK if loopback else 0, _C.c_void_p(stream) if stream else None))
 
+    def allgather_records(self, d_local, n_local, d_out, capacity, stream=None):
+        """rpt_allgather_records_device: every rank's photon records in rank order -> (per-rank counts, total)."""
+        per = (_C.c_uint64 * self.world)()
+        tot = _C.c_uint64()
+        _lib.check(_lib.load().rpt_allgather_records_device(self._h, _C.c_void_p(d_local) if n_local else None, int(n_local),
+                                                            _C.c_void_p(d_out) if d_out else None, int(capacity), per, _C.byref(tot),
+                                                            _C.c_void_p(stream) if stream else None))
+        return [int(v) for v in per], int(tot.value)
+
     def close(self):
         if self._h:
             _lib.load().rpt_comm_destroy(self._h)
@@ -121,16 +130,24 @@ def _view(ptr, n, device):
     return torch.as_tensor(_DevicePtr(ptr, n * RECORD_BYTES), device=device).view(n, RECORD_BYTES)
 
 
-def photon_map_build_sharded(renderer, photon_count, kind, rank, world, group=None):
+def photon_map_build_sharded(renderer, photon_count, kind, rank, world, group=None, comm=None):
     """Renderer.photon_map_build across `world` ranks: each rank shoots its block of photons
-    (rpt_photon_shoot), the records are all-gathered over RCCL and every rank builds the full map
-    (rpt_photon_map_from_records).  Returns the stats dict of photon_map_build."""
+    (rpt_photon_shoot), the records are all-gathered over RCCL -- through the library's own communicator
+    (`comm`: a FrameComm, rpt_allgather_records_device) or through torch.distributed -- and every rank builds the
+    full map (rpt_photon_map_from_records).  Returns the stats dict of photon_map_build."""
     import torch
     device = torch.device("cuda", renderer.device_)
     renderer.photon_shoot(photon_count, kind, rank, world)
     gathered = []
     for which in (0, 1):
         ptr, n = renderer.photon_records(which)
+        if comm is not None:
+            st = torch.cuda.current_stream(device).cuda_stream
+            cap = max(1, 4 * photon_count)   # generous: repeated with the exact size should it ever be short
+            out = torch.empty((cap, RECORD_BYTES), dtype=torch.uint8, device=device)
+            _, total = comm.allgather_records(ptr, n, out.data_ptr(), cap, st)
+            gathered.append(out[:total])
+            continue
         gathered.append(gather_records(_view(ptr, n, device), group))
     torch.cuda.current_stream(device).synchronize()   # the library builds on the null stream
     return renderer.photon_map_from_records(photon_count, kind, gathered[0].data_ptr(), gathered[0].shape[0],

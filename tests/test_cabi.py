@@ -79,12 +79,12 @@ def test_argument_validation_needs_no_gpu():
         assert rc == -2 and b"commit" in lib.rpt_last_error()                         # render before commit
         assert lib.rpt_set_option(b"no_such_option", 1) == -1
         # options are per scene: same names, same validation, no effect on the process defaults
-        assert lib.rpt_scene_set_option(h, b"chunk_spp", 16) == 0 and lib.rpt_scene_set_option(h, b"defer_lanes", 16) == 0
+        assert lib.rpt_scene_set_option(h, b"chunk_spp", 8) == 0 and lib.rpt_scene_set_option(h, b"defer_lanes", 16) == 0
         assert lib.rpt_scene_set_option(h, b"defer_lanes", 65) == -1 and lib.rpt_scene_set_option(h, b"nope", 1) == -1
         assert lib.rpt_scene_set_option(None, b"chunk_spp", 8) == -1
         c, n = C.c_uint32(), C.c_uint32()
-        assert lib.rpt_render_chunking(256, C.byref(c), C.byref(n)) == 0 and (c.value, n.value) == (8, 32)   # the default rule
-        assert lib.rpt_scene_render_chunking(h, 256, C.byref(c), C.byref(n)) == 0 and (c.value, n.value) == (16, 16)   # this scene's option
+        assert lib.rpt_render_chunking(256, C.byref(c), C.byref(n)) == 0 and (c.value, n.value) == (16, 16)   # the default rule
+        assert lib.rpt_scene_render_chunking(h, 256, C.byref(c), C.byref(n)) == 0 and (c.value, n.value) == (8, 32)   # this scene's option
     finally:
         lib.rpt_scene_destroy(h)
 

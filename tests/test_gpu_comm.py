@@ -73,3 +73,23 @@ def test_one_rank_gather_through_rccl():
         assert torch.equal(src3, dst3)
     finally:
         comm.close()
+
+
+def test_one_rank_all_gather_of_photon_records():
+    """rpt_allgather_records_device with the one rank of a single-GPU box: counts, order and bytes of the records; an output
+    that is too small is refused with the total reported."""
+    import torch
+    from rpt_amd import RptError
+    comm = FrameComm(FrameComm.unique_id(), 0, 1, 0)
+    try:
+        rec = torch.randint(0, 256, (1234, 48), dtype=torch.uint8, device="cuda")
+        out = torch.zeros((2000, 48), dtype=torch.uint8, device="cuda")
+        per, total = comm.allgather_records(rec.data_ptr(), rec.shape[0], out.data_ptr(), out.shape[0])
+        torch.cuda.synchronize()
+        assert per == [1234] and total == 1234 and torch.equal(out[:1234], rec) and int(out[1234:].sum()) == 0
+        per, total = comm.allgather_records(0, 0, out.data_ptr(), out.shape[0])      # a rank that shot nothing
+        assert per == [0] and total == 0
+        with pytest.raises(RptError):
+            comm.allgather_records(rec.data_ptr(), rec.shape[0], out.data_ptr(), 10)
+    finally:
+        comm.close()
