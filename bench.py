@@ -500,7 +500,7 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
     r.scene.set_option("timing", 0)
     r.scene.set_option("counters", 1)
     r._sample_offset = 0
-    cspp = min(spp, 16)
+    cspp = 1 if photon else min(spp, 16)   # (the camera pass's counters build carries timers: one sample per pixel is enough for per-sample ratios)
     if photon:
         r.photon_sample_device(cspp, frames[0].data_ptr(), 0)
     else:

@@ -28,10 +28,14 @@ cfg = scenes.CONFIGS[args.workload]()[2]
 kernel = "photon_query_kernel" if "photons" in cfg else "render_kernel"
 tot, launches, durations = defaultdict(float), defaultdict(set), []
 for f in glob.glob(args.out + "/pass*/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
+    rows = [row for row in csv.DictReader(open(f)) if kernel in row.get("Kernel_Name", "")]
+    if kernel == "photon_query_kernel" and rows:
+        # the camera pass has no separate counters instantiation: the LAST launch of a bench.py run is its untimed counters pass
+        # (diagnostic timers and atomics: ten times slower) and does not belong in the means
+        last = max(int(row["Dispatch_Id"]) for row in rows)
+        rows = [row for row in rows if int(row["Dispatch_Id"]) != last]
+    for row in rows:
         name = row.get("Kernel_Name", "")
-        if kernel not in name:
-            continue
         if kernel == "render_kernel" and (re.search(r"render_kernel<\w+, \d, true[,>]", name) or re.search(r"render_kernelILb[01]ELi\dELb1E", name)):
             continue  # the timed launches only (the COUNT = true instantiation is bench.py's untimed counter pass)
         tot[row["Counter_Name"]] += float(row["Counter_Value"])
