@@ -187,6 +187,13 @@ def issue_view(pmc, current):
     return rnd(issue), rnd(lanes), rnd(wait)
 
 
+def mirror_issue_figures(out):
+    """The figures that say what binds the kernel, once more INSIDE the roofline object (a reader that keeps only the
+    contract's objects still gets them): fp32 VALU view of the same launch."""
+    out["roofline"]["valu"] = {k: out.get(k) for k in ("valu_frac", "valu_tflops", "valu_peak_tflops", "valu_issue_frac", "active_lanes",
+                                                      "lane_slot_utilisation", "s_waitcnt_share", "path_lanes", "pmc_source") if k in out}
+
+
 def cpu_baseline(scene, cam, cfg, width, height, target_seconds=15.0):
     """The fp64 oracle (C++ restatement of rpt's CPU algorithm, literal reference semantics,
     one task per image row like the rayon loop) on the host CPUs this process may use, on a bounded sample."""
@@ -540,6 +547,7 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
                     "valu_issue_frac": issue, "active_lanes": lanes, "s_waitcnt_share": wait, "pmc_source": pmc_path if pmc_current else None})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, r.watts_)
+        mirror_issue_figures(out)
         return out
 
     bytes_ps, flops_ps, rays_ps = algorithmic_work(stats, len(scene.objects), cnt, samples_c)
@@ -561,6 +569,7 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, cam, cfg, width, height, 15.0 if headline else 8.0)
         out["config"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    mirror_issue_figures(out)
     return out
 
 
