@@ -31,6 +31,9 @@ RPT_DEV V fma3(float s, V a, V b) { return V{fmaf(s, a.x, b.x), fmaf(s, a.y, b.y
 RPT_DEV V fma3(V s, V a, V b) { return V{fmaf(s.x, a.x, b.x), fmaf(s.y, a.y, b.y), fmaf(s.z, a.z, b.z)}; }
 RPT_DEV float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 RPT_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// v_sqrt_f32 as it is (1 ulp, like rcp / rsq above).  sqrtf() is correctly rounded by default under hipcc: one v_sqrt_f32
+// plus ~17 instructions of scaling and refinement around it, per call, in the sphere test and the direction samplers.
+RPT_DEV float sqrt1(float x) { return __builtin_amdgcn_sqrtf(x); }
 RPT_DEV V normalize(V a) { return rsq(dot(a, a)) * a; }
 RPT_DEV V vmin(V a, V b) { return V{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
 RPT_DEV float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
@@ -150,23 +153,52 @@ struct Rng {
 
 // Unit sphere, src/shape/sphere.rs:14-46.  Same roots as the reference's (-b -/+ sqrt(b^2-ac))/a,
 // evaluated through the closest-approach vector so fp32 keeps the discriminant's digits.
+RPT_DEV bool sphere_closer(V ol, V dl, float tmin, float tbest, float& t);
 RPT_DEV float hit_sphere(V ol, V dl, float tmin) {
+    float t;
+    return sphere_closer(ol, dl, tmin, __builtin_inff(), t) ? t : -1.f;
+}
+// The scans' form of the three bounded primitives: "is there an accepted root closer than tbest", one chain of compares
+// (a negative discriminant leaves NaN in t, which fails them).  hit_sphere / hit_cube<false> / hit_aabb<false> are these
+// with tbest = inf, and the bodies are compiled without fp contraction (their fmas are written out): a scan and a tree
+// walk that reach the same primitive then get the same bits for t wherever the body is inlined.
+RPT_DEV bool sphere_closer(V ol, V dl, float tmin, float tbest, float& t) {
+#pragma clang fp contract(off)
     float a = dot(dl, dl);
     float inv_a = rcp(a);
     float bb = dot(dl, ol) * inv_a;
     V l = fma3(-bb, dl, ol);
-    float disc = 1.f - dot(l, l);
-    if (disc < 0.f) return -1.f;
-    float sq = __builtin_sqrtf(disc * inv_a);
+    float sq = sqrt1((1.f - dot(l, l)) * inv_a);
     float t0 = -bb - sq;
-    float t1 = -bb + sq;
-    float t = (t0 < tmin) ? t1 : t0;
-    return (t < tmin) ? -1.f : t;
+    t = (t0 < tmin) ? -bb + sq : t0;
+    return t >= tmin && t < tbest;
+}
+RPT_DEV bool slabs_closer(float x1, float x2, float y1, float y2, float z1, float z2, float tmin, float tbest, float& t) {
+#pragma clang fp contract(off)
+    const float start = max3(fminf(x1, x2), fminf(y1, y2), fminf(z1, z2));
+    const float end = min3(fmaxf(x1, x2), fmaxf(y1, y2), fmaxf(z1, z2));
+    t = start < tmin ? end : start;
+    return !(start > end) && !(end < tmin) && t < tbest;
+}
+RPT_DEV bool cube_closer(V ol, V dl, float tmin, float tbest, float& t) {
+#pragma clang fp contract(off)
+    float ix = rcp(dl.x), iy = rcp(dl.y), iz = rcp(dl.z);
+    return slabs_closer((-0.5f - ol.x) * ix, (0.5f - ol.x) * ix, (-0.5f - ol.y) * iy, (0.5f - ol.y) * iy, (-0.5f - ol.z) * iz,
+                        (0.5f - ol.z) * iz, tmin, tbest, t);
+}
+RPT_DEV bool aabb_closer(const F4& lo, const F4& hi, V o, V inv, float tmin, float tbest, float& t) {
+#pragma clang fp contract(off)
+    return slabs_closer((lo.x - o.x) * inv.x, (hi.x - o.x) * inv.x, (lo.y - o.y) * inv.y, (hi.y - o.y) * inv.y,
+                        (lo.z - o.z) * inv.z, (hi.z - o.z) * inv.z, tmin, tbest, t);
 }
 // Unit cube [-1/2,1/2]^3, src/shape/cube.rs:22-74.  Returns t; `axis_sign` (optional) gets the
 // face: axis | (positive ? 4 : 0).
 template <bool WANT_FACE>
 RPT_DEV float hit_cube(V ol, V dl, float tmin, uint32_t& face) {
+    if constexpr (!WANT_FACE) {   // t alone: the same entry / exit parameters through min / max instead of compare + select
+        float t;
+        return cube_closer(ol, dl, tmin, __builtin_inff(), t) ? t : -1.f;
+    }
     float ix = rcp(dl.x), iy = rcp(dl.y), iz = rcp(dl.z);
     float x1 = (-0.5f - ol.x) * ix, x2 = (0.5f - ol.x) * ix;
     float y1 = (-0.5f - ol.y) * iy, y2 = (0.5f - ol.y) * iy;
@@ -214,6 +246,10 @@ RPT_DEV float hit_tri(const F4& pn, const F4& A, const F4& B, V o, V d, float tm
 // same entry/exit parameters because t is shared between the two spaces.  `inv` = 1/d.
 template <bool WANT_FACE>
 RPT_DEV float hit_aabb(const F4& lo, const F4& hi, V o, V inv, float tmin, uint32_t& face) {
+    if constexpr (!WANT_FACE) {   // (as in hit_cube)
+        float t;
+        return aabb_closer(lo, hi, o, inv, tmin, __builtin_inff(), t) ? t : -1.f;
+    }
     float x1 = (lo.x - o.x) * inv.x, x2 = (hi.x - o.x) * inv.x;
     float y1 = (lo.y - o.y) * inv.y, y2 = (hi.y - o.y) * inv.y;
     float z1 = (lo.z - o.z) * inv.z, z2 = (hi.z - o.z) * inv.z;
@@ -424,8 +460,8 @@ RPT_DEV void scan_prims(const SceneView& scene, V o, V d, float tmin, float& tbe
         const XfScan x = uload(&sc.sph[i]);
         V ol, dl;
         to_local(x, o, d, ol, dl);
-        float t = hit_sphere(ol, dl, tmin);
-        if (t >= 0.f && t < tbest) { tbest = t; code = (K_SPHERE << 28) | i; }
+        float t;
+        if (sphere_closer(ol, dl, tmin, tbest, t)) { tbest = t; code = (K_SPHERE << 28) | i; }
     }
     bit += sc.n_sph;
     {   // two records per iteration: independent instruction streams for the scheduler (unmasked scans)
@@ -436,19 +472,17 @@ RPT_DEV void scan_prims(const SceneView& scene, V o, V d, float tmin, float& tbe
                 V ol0, dl0, ol1, dl1;
                 to_local(x0, o, d, ol0, dl0);
                 to_local(x1, o, d, ol1, dl1);
-                uint32_t f;
-                const float t0 = hit_cube<false>(ol0, dl0, tmin, f), t1 = hit_cube<false>(ol1, dl1, tmin, f);
-                if (t0 >= 0.f && t0 < tbest) { tbest = t0; code = (K_CUBE << 28) | i; }
-                if (t1 >= 0.f && t1 < tbest) { tbest = t1; code = (K_CUBE << 28) | (i + 1u); }
+                float t0, t1;
+                if (cube_closer(ol0, dl0, tmin, tbest, t0)) { tbest = t0; code = (K_CUBE << 28) | i; }
+                if (cube_closer(ol1, dl1, tmin, tbest, t1)) { tbest = t1; code = (K_CUBE << 28) | (i + 1u); }
             }
         for (; i < sc.n_cub; i++) {
             if (!on(i)) continue;
             const XfScan x = uload(&sc.cub[i]);
             V ol, dl;
             to_local(x, o, d, ol, dl);
-            uint32_t f;
-            float t = hit_cube<false>(ol, dl, tmin, f);
-            if (t >= 0.f && t < tbest) { tbest = t; code = (K_CUBE << 28) | i; }
+            float t;
+            if (cube_closer(ol, dl, tmin, tbest, t)) { tbest = t; code = (K_CUBE << 28) | i; }
         }
     }
     bit += sc.n_cub;
@@ -466,17 +500,15 @@ RPT_DEV void scan_prims(const SceneView& scene, V o, V d, float tmin, float& tbe
             if (!MASKED)
                 for (; i + 1u < sc.n_aabb; i += 2u) {
                     const AabbScan b0 = uload(&sc.aabb[i]), b1 = uload(&sc.aabb[i + 1u]);
-                    uint32_t f;
-                    const float t0 = hit_aabb<false>(b0.lo, b0.hi, o, inv, tmin, f), t1 = hit_aabb<false>(b1.lo, b1.hi, o, inv, tmin, f);
-                    if (t0 >= 0.f && t0 < tbest) { tbest = t0; code = (K_AABB << 28) | i; }
-                    if (t1 >= 0.f && t1 < tbest) { tbest = t1; code = (K_AABB << 28) | (i + 1u); }
+                    float t0, t1;
+                    if (aabb_closer(b0.lo, b0.hi, o, inv, tmin, tbest, t0)) { tbest = t0; code = (K_AABB << 28) | i; }
+                    if (aabb_closer(b1.lo, b1.hi, o, inv, tmin, tbest, t1)) { tbest = t1; code = (K_AABB << 28) | (i + 1u); }
                 }
             for (; i < sc.n_aabb; i++) {
                 if (!on(i)) continue;
                 const AabbScan b = uload(&sc.aabb[i]);
-                uint32_t f;
-                float t = hit_aabb<false>(b.lo, b.hi, o, inv, tmin, f);
-                if (t >= 0.f && t < tbest) { tbest = t; code = (K_AABB << 28) | i; }
+                float t;
+                if (aabb_closer(b.lo, b.hi, o, inv, tmin, tbest, t)) { tbest = t; code = (K_AABB << 28) | i; }
             }
         }
         bit += sc.n_aabb;
@@ -830,8 +862,8 @@ RPT_DEV V reflect_neg(V w, V n) { return fma3(2.f * dot(n, w), n, -w); }  // -gl
 RPT_DEV bool sample_f(const Mat& m, V n, V wo, Rng& rng, V& wi, float& pdf) {
     if (m.kind == M_LAMBERTIAN) {
         float r1 = rng.uniform(), r2 = rng.uniform();
-        float ct = __builtin_sqrtf(r2);             // cos(acos(sqrt(r2)))
-        float st = __builtin_sqrtf(1.f - r2);
+        float ct = sqrt1(r2);             // cos(acos(sqrt(r2)))
+        float st = sqrt1(1.f - r2);
         pdf = ct * kInvPi;
         V dir = mk(st * __builtin_amdgcn_cosf(r1), ct, st * __builtin_amdgcn_sinf(r1));  // phi = 2 pi r1
         wi = normalize(rotate_from_y(n, dir, true));
@@ -839,7 +871,7 @@ RPT_DEV bool sample_f(const Mat& m, V n, V wo, Rng& rng, V& wi, float& pdf) {
     } else if (m.kind == M_PHONG) {
         float r1 = rng.uniform(), r2 = rng.uniform();
         float ct = __powf(r2, rcp(m.shin + 1.f));
-        float st = __builtin_sqrtf(fmaxf(1.f - ct * ct, 0.f));
+        float st = sqrt1(fmaxf(1.f - ct * ct, 0.f));
         pdf = (m.shin + 1.f) * (0.5f * kInvPi) * __powf(ct, m.shin);
         V dir = mk(st * __builtin_amdgcn_cosf(r1), ct, st * __builtin_amdgcn_sinf(r1));
         V refl = reflect_neg(wo, n);
@@ -867,7 +899,7 @@ RPT_DEV bool sample_f(const Mat& m, V n, V wo, Rng& rng, V& wi, float& pdf) {
         float eta = ni * rcp(nt);
         float k = 1.f - eta * eta * (1.f - ci * ci);
         if (k < 0.f) return false;  // sqrt -> NaN -> None
-        float cost = __builtin_sqrtf(k);
+        float cost = sqrt1(k);
         wi = fma3(eta * ci - cost, nn, -eta * wo);
         return true;
     }
@@ -947,7 +979,7 @@ RPT_DEV void sample_light_leaf(const SceneView& scene_, uint32_t shape, uint32_t
         V tl = xf ? mk(dot3w(x.inv(0), pos), dot3w(x.inv(1), pos), dot3w(x.inv(2), pos)) : pos;
         float dx, dy;
         rng.unit_disc(dx, dy);
-        float z = __builtin_sqrtf(fmaxf(1.f - dx * dx - dy * dy, 0.f));
+        float z = sqrt1(fmaxf(1.f - dx * dx - dy * dy, 0.f));
         V nn = normalize(tl);
         bool normal_x = fabsf(nn.x) >= 1.17549435e-38f && fabsf(nn.x) < kInf;
         V n1 = normal_x ? normalize(mk(nn.y, -nn.x, 0.f)) : normalize(mk(0.f, -nn.z, nn.y));

@@ -64,11 +64,13 @@ RPT_DEV void item_pixel(const RenderArgs& a, uint32_t p, uint32_t& x, uint32_t& 
 #define RPT_MIN_WAVES_STREAM 4  // per-mesh-tree instantiation with streamed walks (DETACH = 2); 3 (168 VGPRs) has no scratch
 #endif
 #ifndef RPT_MIN_WAVES_SCAN
-#define RPT_MIN_WAVES_SCAN 5  // linear-scan instantiations (BVH = 0) without a medium: 96 VGPRs
+#define RPT_MIN_WAVES_SCAN 6  // linear-scan instantiations (BVH = 0): 80 VGPRs.  Without a medium no scratch; in a medium 24 B/lane (9 MB over
+                              // the chip: it stays in L2).  C3 21.4 ms against 22.6 at 5 waves (96 VGPRs), C2 1.11 against 1.17; 7 waves
+                              // (72 VGPRs, 52 / 28 B of scratch) 21.5 / 1.09: no further gain.  (Before the build dropped SLP vectorisation
+                              // the medium flavour spilled 84 B/lane at 6 waves -- 32 GB of HBM writes per C3 launch -- and 5 was the setting.)
 #endif
-#ifndef RPT_MIN_WAVES_SCAN_MEDIUM
-#define RPT_MIN_WAVES_SCAN_MEDIUM 5  // ... in a medium.  6 (80 VGPRs) renders C3 in 25.3 instead of 26.0 ms but spills 84 B/lane, a scratch
-                                     // footprint just over the XCD's L2: 32 GB of HBM writes per launch instead of 1.1 -- not taken
+#ifndef RPT_MIN_WAVES_SCAN_GROUPS
+#define RPT_MIN_WAVES_SCAN_GROUPS 5  // ... with group lights or counters (GROUPS / COUNT): 64 / 48 B of scratch at 6 waves, none at 5
 #endif
 // LDS of the per-mesh-tree kernel with detached shadow queries (render_kernel<true, 1, *, false, true>), in dwords per block
 // of 256 lanes: [stack rows][5 state rows][staged tables][pend: 256][acc: 3 x 256 u64][4 wave queues].  40,320 B: four
@@ -217,7 +219,7 @@ RPT_DEV bool stage_bounce(const RenderArgs& a, float albedo_med, V rd, uint32_t 
 // DETACH (per-mesh-tree kernels in a medium): shadow queries that need a tree walk leave their path (see the loop body).
 // DETACH = 2: primary queries leave as well -- their paths wait in memory and the lane goes on with another one.
 template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false, int DETACH = 0>
-__global__ __launch_bounds__(256, BVH == 0 ? (MEDIUM ? RPT_MIN_WAVES_SCAN_MEDIUM : RPT_MIN_WAVES_SCAN) : BVH == 3 ? RPT_MIN_WAVES_SCENE_MESH : BVH == 1 ? (DETACH == 2 ? RPT_MIN_WAVES_STREAM : RPT_MIN_WAVES_MESH) : RPT_MIN_WAVES)
+__global__ __launch_bounds__(256, BVH == 0 ? ((GROUPS || COUNT) ? RPT_MIN_WAVES_SCAN_GROUPS : RPT_MIN_WAVES_SCAN) : BVH == 3 ? RPT_MIN_WAVES_SCENE_MESH : BVH == 1 ? (DETACH == 2 ? RPT_MIN_WAVES_STREAM : RPT_MIN_WAVES_MESH) : RPT_MIN_WAVES)
 void render_kernel(const RenderArgs a) {
     static_assert(DETACH == 0 || (MEDIUM && BVH == 1 && !GROUPS), "detached tree walks: per-mesh-tree kernels in a medium only");
     extern __shared__ uint32_t dyn_lds[];

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void photon_shoot_kernel(const ShootArgs a) {
         sample_light_shape<true>(sc, L, mk(0.f, 0.f, 0.f), rng, ro, n0, p0);  // :733-734 (target is a dummy)
         float u1 = rng.uniform(), u2 = rng.uniform();
         float ct = 1.f - u2;                                           // theta = acos(1 - u), :738
-        float st = __builtin_sqrtf(fmaxf(1.f - ct * ct, 0.f));
+        float st = sqrt1(fmaxf(1.f - ct * ct, 0.f));
         V rd = rotate_from_y(n0, mk(st * __builtin_amdgcn_cosf(u1), ct, st * __builtin_amdgcn_sinf(u1)), true);
         V power = a.power * xyz(L.albedo);
         uint32_t ns = 0, nv = 0, c0 = 0, c1 = 0;
@@ -995,7 +995,7 @@ RPT_DEV V volume_estimate_sample_lanes(QueryK q, bool active, V ro, V rd, bool h
     const float t2 = hit ? t * t : kInf;
     auto prep_packet = [&](PhotonRec ph, const V& o0) {
         const V c = xyz(ph.pos_r) - o0;
-        const float r2 = ph.pos_r.w * ph.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = __builtin_sqrtf(c2);
+        const float r2 = ph.pos_r.w * ph.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = sqrt1(c2);
         const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
         ph.pos_r = F4{c.x, c.y, c.z, r2};
         ph.dir = F4{c2, len, ir2, 0.f};
@@ -1028,7 +1028,7 @@ RPT_DEV V volume_estimate_sample_lanes(QueryK q, bool active, V ro, V rd, bool h
         const V bstart = xyz(ph.dir), bend = xyz(ph.pos_r);
         const float radius = ph.pos_r.w;
         const V bvec = bend - bstart;
-        const float beam_len = __builtin_sqrtf(dot(bvec, bvec));
+        const float beam_len = sqrt1(dot(bvec, bvec));
         const V bdir = rcp(beam_len) * bvec;
         const V l = bstart - ro;
         const V u = normalize(cross(l, bdir));
@@ -1039,7 +1039,7 @@ RPT_DEV V volume_estimate_sample_lanes(QueryK q, bool active, V ro, V rd, bool h
         const float beam_t = dot(bdir, qc - bstart);
         const V bc = fma3(beam_t, bdir, bstart);
         const V dq = qc - bc;
-        const float dist = __builtin_sqrtf(dot(dq, dq));
+        const float dist = sqrt1(dot(dq, dq));
         const bool ok = !(hit && tq >= t) && beam_t >= 0.f && beam_t <= beam_len && dist < radius;
         if (ok) {
             c_acc++;
@@ -1091,7 +1091,7 @@ RPT_DEV V beam_estimate_photon_lanes(QueryK q, const uint32_t* cand, uint32_t ca
         if (lane_ < nb) {
             const PhotonRec raw = q.v_ph[list[lane_]];
             const V c = xyz(raw.pos_r) - eye0;
-            const float r2 = raw.pos_r.w * raw.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = __builtin_sqrtf(c2);
+            const float r2 = raw.pos_r.w * raw.pos_r.w, ir2 = rcp(r2), c2 = dot(c, c), len = sqrt1(c2);
             const float kk = (3.f * kInvPi) * phase * ir2 * __expf(-sigma_t * len);
             const V pw = kk * xyz(raw.pow);
             const float one_plus = fmaf(sigma_t, len, 1.f);
@@ -1547,6 +1547,9 @@ RPT_DEV void surface_gather_lane(QueryK q, const SceneView& sc_arg, const Gather
     s.todo = false;
 }
 
+#ifndef RPT_MIN_WAVES_QUERY
+#define RPT_MIN_WAVES_QUERY 4   // waves per SIMD the camera-pass kernels are compiled for (128 VGPRs)
+#endif
 // get_color_with_photon_map / PhotonMap::estimate_indirect for the point-beam map
 // (src/photon.rs:950-985, 316-375, 439-502, 595-628).  LDS: per lane gather_size (d2, index) pairs.
 // KIND: the PhotonRenderKind of the map (RPT_PHOTON_*).  One instantiation per kind: the three estimators share the
@@ -1556,7 +1559,7 @@ RPT_DEV void surface_gather_lane(QueryK q, const SceneView& sc_arg, const Gather
 // same work items whose partial sums go to two slabs that resolve_kernel adds (beam kinds in a medium, lists in LDS): each
 // kernel then keeps only its own estimate's wave-uniform state, and neither needs scratch memory.
 template <bool MEDIUM, bool BVH, bool GG, int KIND, int PHASE = 0>
-__global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q) {
+__global__ __launch_bounds__(256, RPT_MIN_WAVES_QUERY) void photon_query_kernel(const QueryArgs q) {
     static_assert(PHASE == 0 || (MEDIUM && !GG && KIND != RPT_PHOTON_MAP), "the split camera pass: beam estimates in a medium, gather lists in LDS");
     extern __shared__ uint32_t dyn_lds[];
     const RenderArgs& a = q.r;
@@ -1809,7 +1812,7 @@ __global__ __launch_bounds__(256, 4) void photon_query_kernel(const QueryArgs q)
                     V sum = mk(0, 0, 0);
                     for (uint32_t k = 0; k < found; k++) sum = sum + xyz(q.v_ph[gi[k * 64u]].pow);
                     // / (4/3 pi r^3) / extinction * transmittance / pdf, pdf = sigma_t * transmittance
-                    const float r3 = max_d2 * __builtin_sqrtf(max_d2);
+                    const float r3 = max_d2 * sqrt1(max_d2);
                     const float scale = sc.medium_phase * rcp((4.f / 3.f) * kPi * r3) * rcp(sigma_t) * tr_d * rcp(sigma_t * tr_d);
                     color = scale * (sum * mcol);
                 } else {
