@@ -32,6 +32,7 @@ struct RenderArgs {
     uint32_t walk_leaf_quarters;  // ... and the descent of a walk pauses for the leaves when 4 x (lanes at a leaf) >= this x (lanes descending); 0: never
     uint32_t detach;              // per-mesh-tree kernels in a medium: 1 = shadow queries that need a tree walk leave their path (wave queue
                                   // in LDS); 2 = every tree walk leaves its path (ring + parked path contexts in stream_scratch)
+    uint32_t pull_batch;          // lanes that must wait for a new work item before the wave runs the item bookkeeping (it also runs when no lane has anything else to do)
     uint32_t detach_trigger;      // detach = 1: a walk session is due as soon as the queue holds this many (1..32)
     uint32_t stream_backlog;      // detach = 2: ... as soon as the ring holds this many queries
     uint32_t stream_contexts;     // detach = 2: parked paths per lane (1..6)

@@ -118,6 +118,9 @@ RPT_DEV float from_fixed(unsigned long long x) { return float(double(x) * 0x1p-3
 #else
 #define RPT_MARK(k)
 #endif
+#ifdef RPT_SECT_CLOCKS
+#define SECT(k) do { } while (0)   // (the clocks build keeps its counts per wave in LDS: global atomics would be what it measures)
+#else
 #define SECT(k)                                                                                  \
     do {                                                                                         \
         RPT_MARK(k);                                                                             \
@@ -129,6 +132,26 @@ RPT_DEV float from_fixed(unsigned long long x) { return float(double(x) * 0x1p-3
             }                                                                                    \
         }                                                                                        \
     } while (0)
+#endif
+// SECTK: the same inside render_kernel's body.  -DRPT_SECT_CLOCKS (a diagnostic build of its own, tools/sect_clocks.py): the
+// lanes slot of a section then holds wave clock ticks (s_memtime) instead -- the time from reaching that section until the
+// wave reaches the next section point, stalls included.
+#ifdef RPT_SECT_CLOCKS
+#define SECTK(k)                                                                                 \
+    do {                                                                                         \
+        if (COUNT) {                                                                             \
+            const uint64_t now_ = __builtin_amdgcn_s_memtime();                                  \
+            if (mbcnt64(__ballot(true)) == 0) {                                                  \
+                sect_lds_[threadIdx.x >> 6][2 * (k)] += 1ull;                                    \
+                sect_lds_[threadIdx.x >> 6][2 * sect_prev_ + 1] += now_ - sect_clk_;             \
+            }                                                                                    \
+            sect_prev_ = (k);                                                                    \
+            sect_clk_ = now_;                                                                    \
+        }                                                                                        \
+    } while (0)
+#else
+#define SECTK(k) SECT(k)
+#endif
 // ---- The stages of a path vertex, shared by the two loop bodies of render_kernel (the parked-walk state machine of the
 // per-mesh-tree flavour and the lock-step body of the others): what they compute is one thing, when they run another.
 // Distance sample of a new vertex and the interval its closest-hit query has to search (Medium::sample_d,
@@ -221,6 +244,12 @@ RPT_DEV bool stage_bounce(const RenderArgs& a, float albedo_med, V rd, uint32_t 
 template <bool MEDIUM, int BVH, bool COUNT, bool GROUPS = false, int DETACH = 0>
 __global__ __launch_bounds__(256, BVH == 0 ? ((GROUPS || COUNT) ? RPT_MIN_WAVES_SCAN_GROUPS : RPT_MIN_WAVES_SCAN) : BVH == 3 ? RPT_MIN_WAVES_SCENE_MESH : BVH == 1 ? (DETACH == 2 ? RPT_MIN_WAVES_STREAM : RPT_MIN_WAVES_MESH) : RPT_MIN_WAVES)
 void render_kernel(const RenderArgs a) {
+#ifdef RPT_SECT_CLOCKS
+    __shared__ unsigned long long sect_lds_[4][56];   // per wave: [2k] visits of section k, [2k + 1] its ticks
+    if ((threadIdx.x & 63u) < 56u) sect_lds_[threadIdx.x >> 6][threadIdx.x & 63u] = 0ull;
+    uint64_t sect_clk_ = __builtin_amdgcn_s_memtime();
+    uint32_t sect_prev_ = 27u;   // (time before the first section point)
+#endif
     static_assert(DETACH == 0 || (MEDIUM && BVH == 1 && !GROUPS), "detached tree walks: per-mesh-tree kernels in a medium only");
     extern __shared__ uint32_t dyn_lds[];
     const SceneView& sc = a.sc;
@@ -367,9 +396,15 @@ void render_kernel(const RenderArgs a) {
             // (a lane that has just taken a path back is not looking for an item, whatever it was a moment ago)
             want = want && need_path && parked_mask == 0u;
         }
-        if (__any(want)) {
+        // The bookkeeping below costs the wave the same whether one lane or sixty-four want an item, so lanes wait until
+        // `pull_batch` of them do -- or until no lane of the wave has anything else to do.  Which lane renders an item does
+        // not change the item's sum (same frame bits for every setting).  Measured (tools/pull_batch_sweep.py): C3 21.78 ms
+        // at 1, 21.49 at 2, 21.51 at 4, 21.9 at 8, 24.7 at 24; C5 flat up to 2, then slower -- waiting lanes cost more than
+        // the saved visits beyond 2, which is the default.
+        const uint32_t n_want = uint32_t(__popcll(__ballot(want)));
+        if (n_want != 0u && (n_want >= a.pull_batch || __ballot(alive && !want) == 0ull)) {
             const auto& ka = *kernarg_args<RenderArgs>();   // item bookkeeping reads its arguments here, not from registers held since kernel entry
-            SECT(0);
+            SECTK(0);
             if (want && have_item) {
                 if constexpr (DETACH) {
                     const volatile unsigned long long* av = acc64;
@@ -450,12 +485,12 @@ void render_kernel(const RenderArgs a) {
                 }
             }
         }
-        // (DETACH: a lane whose finished item still waits for shadow answers has no sample to start; DETACH = 2: nor has a
-        // lane with every context parked)
-        if (need_path && alive && !(DETACH != 0 && item_done) && !(DETACH == 2 && uint32_t(__popc(parked_mask)) >= a.stream_contexts)) {
+        // (a lane whose item is finished has no sample to start: it waits for the wave's next item hand-out, or -- DETACH -- for
+        // the item's last shadow answers; DETACH = 2: nor has a lane with every context parked)
+        if (need_path && alive && !item_done && !(DETACH == 2 && uint32_t(__popc(parked_mask)) >= a.stream_contexts)) {
             if (alive) {  // src/renderer.rs:179-181
                 const auto& ka = *kernarg_args<RenderArgs>();
-                SECT(1);
+                SECTK(1);
                 const uint32_t s = ldu(S_S, s_r);
                 rng.seed(ka.seed_mixed, ldu(S_PIX, pix_r), ka.sample_offset + s);
                 float dx = rng.range(-ka.inv_dim, ka.inv_dim);
@@ -494,7 +529,7 @@ void render_kernel(const RenderArgs a) {
             // ---- A: a new path vertex: distance sample, scan, do the trees matter?
             if (alive && !need_path && phase == PH_NEW) {
                 if (COUNT) c_vertices++;
-                SECT(2);
+                SECTK(2);
                 did_work = true;
                 stage_distance<MEDIUM>(rng, inv_sigma_t, v_dmed, q_t);
                 const float tmin = ray_tmin(ro);
@@ -503,7 +538,7 @@ void render_kernel(const RenderArgs a) {
                 if (COUNT) c_rays++;
                 phase = PH_HAVEP;
                 if (mesh_roots_hit(sc, ro, rd, tmin, q_t)) {
-                    SECT(21);
+                    SECTK(21);
                     const uint32_t lane = threadIdx.x & 63u;
                     const uint32_t c = uint32_t(__builtin_ctz(~parked_mask));   // a free context (the caller of this stage had one)
                     // the query
@@ -531,13 +566,13 @@ void render_kernel(const RenderArgs a) {
             }
             // ---- B, L, C: event, next-event estimation, continue or end
             if (alive && !need_path && phase == PH_HAVEP) {
-                SECT(3);
+                SECTK(3);
                 did_work = true;
                 const bool hit = q_code != CODE_MISS;
                 const bool ev_medium = v_dmed < (hit ? q_t : 400.f);
                 phase = PH_NEW;
                 if (!ev_medium && !hit) {
-                    SECT(4);
+                    SECTK(4);
                     acc_add(fma3(Q, env_color(sc, rd), P));
                     need_path = true;
                 } else {
@@ -551,10 +586,10 @@ void render_kernel(const RenderArgs a) {
                         } else if (L.kind == L_OBJECT) {
                             V I, wi;
                             float dist;
-                            SECT(7);
+                            SECTK(7);
                             illuminate_object<false>(sc, L, x, rng, I, wi, dist, tab);
                             if (L.twin_object >= 0) {
-                                SECT(8);
+                                SECTK(8);
                                 const float tm = ray_tmin(x);
                                 float ts = dist * (1.f + 1e-3f);
                                 uint32_t cs = CODE_MISS;
@@ -563,7 +598,7 @@ void render_kernel(const RenderArgs a) {
                                 const bool twin = (L.twin_lo <= L.twin_hi) ? (cs >= L.twin_lo && cs <= L.twin_hi)
                                                                            : (cs != CODE_MISS && code_object(sc, cs, 0u) == uint32_t(L.twin_object));
                                 if (cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) && twin) {   // (see DETACH = 1)
-                                    SECT(9);
+                                    SECTK(9);
                                     V T;
                                     if (ev_medium) {
                                         T = (albedo_med * sc.medium_phase) * (I * mcol);
@@ -574,7 +609,7 @@ void render_kernel(const RenderArgs a) {
                                     if (!mesh_roots_hit(sc, x, wi, tm, ts)) {
                                         E = E + T;
                                     } else {
-                                        SECT(22);
+                                        SECTK(22);
                                         const V cand = Q * T;
                                         const uint64_t m = __ballot(true);
                                         uint32_t base = 0u;
@@ -592,7 +627,7 @@ void render_kernel(const RenderArgs a) {
                     }
                     V wi = mk(0, 0, 1), k = mk(0, 0, 0);
                     const bool cont = stage_bounce<MEDIUM, COUNT>(a, albedo_med, rd, depth, ev_medium, n, mcol, mat, rng, wi, k);
-                    SECT(14);
+                    SECTK(14);
                     P = fma3(Q, E, P);
                     if (cont) {
                         Q = Q * k;
@@ -623,7 +658,7 @@ void render_kernel(const RenderArgs a) {
                     if (!worked && alive && need_path && have_item) { ls_pend[threadIdx.x] = 0u; parked_mask = 0u; }
                 } else if (head - tail >= a.stream_backlog || tight || !worked) {
                     if (COUNT) c_wave[0] = c_wave[1] = 0;
-                    SECT(15);
+                    SECTK(15);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this trip's entries are in memory before any lane reads them
                     const uint32_t min_active = (tight || !worked) ? 1u : a.defer_stop;
                     const BvhNode* const nodes = sc.nodes;
@@ -727,7 +762,7 @@ void render_kernel(const RenderArgs a) {
                         if (cur == kWalkDone && h_e != kNoEntry) {   // answered
                             const uint32_t owner = meta & 63u;
                             if ((meta >> 12) == 0u) {   // shadow: visible iff no tree holds a triangle in its interval
-                                if (COUNT) { SECT(18); }
+                                if (COUNT) { SECTK(18); }
                                 if (wc == CODE_MISS) {
                                     const uint32_t ol = (threadIdx.x & ~63u) | owner;
                                     atomicAdd(&acc64[ol], to_fixed(__uint_as_float(aux0)));
@@ -736,8 +771,8 @@ void render_kernel(const RenderArgs a) {
                                 }
                                 atomicSub(const_cast<uint32_t*>(ls_pend) + ((threadIdx.x & ~63u) | owner), 1u);
                             } else {   // primary: the closest hit goes to the parked path, which becomes ready
-                                SECT(16);
-                                if ((wc >> 28) == K_BVHTRI) { SECT(17); }
+                                SECTK(16);
+                                if ((wc >> 28) == K_BVHTRI) { SECTK(17); }
                                 const uint32_t c = (meta >> 6) & 15u;
                                 uint32_t* const cx = ctx_base + c * kCtxFields * 64u + owner;
                                 cx[18 * 64] = __float_as_uint(wt);
@@ -786,7 +821,7 @@ void render_kernel(const RenderArgs a) {
             // ---- A: a new path vertex: distance sample, scan, do the trees matter?
             if (alive && !need_path && phase == PH_NEW) {
                 if (COUNT) c_vertices++;
-                SECT(2);
+                SECTK(2);
                 stage_distance<MEDIUM>(rng, inv_sigma_t, v_dmed, q_t);
                 const float tmin = ray_tmin(ro);
                 q_code = CODE_MISS;
@@ -797,12 +832,12 @@ void render_kernel(const RenderArgs a) {
             }
             // ---- B, L, C: event, next-event estimation, continue or end -- in one go, nothing waits in between
             if (alive && phase == PH_HAVEP) {
-                SECT(3);
+                SECTK(3);
                 const bool hit = q_code != CODE_MISS;
                 const bool ev_medium = v_dmed < (hit ? q_t : 400.f);
                 phase = PH_NEW;
                 if (!ev_medium && !hit) {
-                    SECT(4);
+                    SECTK(4);
                     acc_add(fma3(Q, env_color(sc, rd), P));
                     need_path = true;
                 } else {
@@ -816,10 +851,10 @@ void render_kernel(const RenderArgs a) {
                         } else if (L.kind == L_OBJECT) {
                             V I, wi;
                             float dist;
-                            SECT(7);
+                            SECTK(7);
                             illuminate_object<false>(sc, L, x, rng, I, wi, dist, tab);
                             if (L.twin_object >= 0) {
-                                SECT(8);
+                                SECTK(8);
                                 const float tm = ray_tmin(x);
                                 float ts = dist * (1.f + 1e-3f);
                                 uint32_t cs = CODE_MISS;
@@ -831,7 +866,7 @@ void render_kernel(const RenderArgs a) {
                                 const bool twin = (L.twin_lo <= L.twin_hi) ? (cs >= L.twin_lo && cs <= L.twin_hi)
                                                                            : (cs != CODE_MISS && code_object(sc, cs, 0u) == uint32_t(L.twin_object));
                                 if (cs != CODE_MISS && ts >= dist * (1.f - 1e-3f) && twin) {
-                                    SECT(9);
+                                    SECTK(9);
                                     V T;
                                     if (ev_medium) {
                                         T = (albedo_med * sc.medium_phase) * (I * mcol);
@@ -842,7 +877,7 @@ void render_kernel(const RenderArgs a) {
                                     if (!mesh_roots_hit(sc, x, wi, tm, ts)) {
                                         E = E + T;
                                     } else {
-                                        SECT(21);
+                                        SECTK(21);
                                         const V cand = Q * T;
                                         const uint64_t m = __ballot(true);   // the lanes that detach a query now
                                         uint32_t fr = ~wq[0];                // free slots (every lane reads before any lane claims)
@@ -858,7 +893,7 @@ void render_kernel(const RenderArgs a) {
                                             atomicOr(const_cast<uint32_t*>(wq), 1u << e);
                                             ls_pend[threadIdx.x] = ls_pend[threadIdx.x] + 1u;
                                         } else {   // every slot is taken (a session is due as soon as detach_trigger entries wait): walk here
-                                            SECT(22);
+                                            SECTK(22);
                                             if (h_e != kNoEntry) {   // this lane's stack column holds a suspended shadow walk: that one starts again later, from the root
                                                 atomicAnd(const_cast<uint32_t*>(wq) + 1, ~(1u << h_e));
                                                 h_e = kNoEntry;
@@ -874,7 +909,7 @@ void render_kernel(const RenderArgs a) {
                     }
                     V wi = mk(0, 0, 1), k = mk(0, 0, 0);
                     const bool cont = stage_bounce<MEDIUM, COUNT>(a, albedo_med, rd, depth, ev_medium, n, mcol, mat, rng, wi, k);
-                    SECT(14);
+                    SECTK(14);
                     P = fma3(Q, E, P);
                     if (cont) {
                         Q = Q * k;
@@ -900,14 +935,16 @@ void render_kernel(const RenderArgs a) {
                 const uint32_t n_new = uint32_t(__popc(avail));
                 const uint32_t n_work = uint32_t(__popcll(__ballot(waitp || susp))) + n_new;
                 const bool stalled = alive && need_path && item_done && have_item && ls_pend[threadIdx.x] != 0u;
-                const bool idle = __ballot(alive && !waitp && !stalled) == 0ull;   // nothing else this wave could do
+                // (a lane whose item is finished can do nothing either: it waits for answers -- stalled -- or for the wave's next
+                // item hand-out, which in turn waits for the stalled lanes when fewer than pull_batch lanes want an item)
+                const bool idle = __ballot(alive && !waitp && !(need_path && item_done)) == 0ull;   // nothing else this wave could do
                 if (n_work == 0u) {
                     // nothing to walk.  (A lane can only be stalled while the queue holds a query of its item; should the
                     // bookkeeping ever disagree, the lane writes its item out rather than spin.)
                     if (idle && stalled) ls_pend[threadIdx.x] = 0u;
                 } else if (n_work >= a.defer_lanes || n_new >= a.detach_trigger || idle) {
                     if (COUNT) c_wave[0] = c_wave[1] = 0;
-                    SECT(15);
+                    SECTK(15);
                     const uint32_t min_active = idle ? 1u : a.defer_stop;
                     const BvhNode* const nodes = sc.nodes;
                     const uint32_t root0 = uload(&sc.meshes[0]).root;
@@ -1014,7 +1051,7 @@ void render_kernel(const RenderArgs a) {
                             if (mode == 2u) {   // a shadow query is answered: visible iff no tree holds a triangle in its interval
                                 const volatile uint32_t* const q = wq + 16u + h_e;
                                 const uint32_t owner = q[10u * kQCap];
-                                if (COUNT) { SECT(18); }
+                                if (COUNT) { SECTK(18); }
                                 if (wc == CODE_MISS) {
                                     atomicAdd(&acc64[owner], to_fixed(__uint_as_float(q[7u * kQCap])));
                                     atomicAdd(&acc64[256u + owner], to_fixed(__uint_as_float(q[8u * kQCap])));
@@ -1033,8 +1070,8 @@ void render_kernel(const RenderArgs a) {
                                     mode = 1u;
                                 }
                             } else if (mode == 1u) {
-                                SECT(16);
-                                if ((wc >> 28) == K_BVHTRI) { SECT(17); }
+                                SECTK(16);
+                                if ((wc >> 28) == K_BVHTRI) { SECTK(17); }
                                 mode = 0u;
                                 phase = PH_HAVEP;
                                 q_t = wt;
@@ -1058,9 +1095,10 @@ void render_kernel(const RenderArgs a) {
         }
         if constexpr (BVH == 1 || BVH == 3) {
             // ---- A: a new path vertex: distance sample, scan (BVH = 3: walk of the scene tree), do the mesh trees matter?
-            if (alive && phase == PH_NEW) {
+            // (a lane without a path waits for the wave's next item hand-out)
+            if (alive && !need_path && phase == PH_NEW) {
                 if (COUNT) c_vertices++;
-                SECT(2);
+                SECTK(2);
                 stage_distance<MEDIUM>(rng, inv_sigma_t, v_dmed, q_t);
                 const float tmin = ray_tmin(ro);
                 q_code = CODE_MISS;
@@ -1072,11 +1110,11 @@ void render_kernel(const RenderArgs a) {
             }
             // ---- B: the event (src/renderer.rs:197-243, 288-299)
             if (alive && phase == PH_HAVEP) {
-                SECT(3);
+                SECTK(3);
                 const bool hit = q_code != CODE_MISS;
                 v_medium = MEDIUM && (v_dmed < (hit ? q_t : 400.f));
                 if (!v_medium && !hit) {
-                    SECT(4);
+                    SECTK(4);
                     acc_add(vmin(fma3(Q, env_color(sc, rd), P), Rc));
                     need_path = true;
                     phase = PH_NEW;
@@ -1096,10 +1134,10 @@ void render_kernel(const RenderArgs a) {
                     if (L.kind == L_AMBIENT) {
                         v_E = fma3(xyz(L.color), v_medium ? v_mcol : mat_color(v_mat), v_E);
                     } else if (L.kind == L_OBJECT) {
-                        SECT(7);
+                        SECTK(7);
                         illuminate_object<GROUPS>(sc, L, v_x, rng, v_I, v_wi, v_dist, tab);
                         if (L.twin_object >= 0) {  // the shadow query (see the undeferred body)
-                            SECT(8);
+                            SECTK(8);
                             const float tm = ray_tmin(v_x);
                             q_t = v_dist * (1.f + 1e-3f);
                             q_code = CODE_MISS;
@@ -1116,7 +1154,7 @@ void render_kernel(const RenderArgs a) {
                     if (next) v_li = l + 1u;
                 }
                 if (alive && phase == PH_HAVES && v_li == l) {
-                    SECT(9);
+                    SECTK(9);
                     stage_light_term(sc, L, albedo_med, rd, v_medium, q_t, q_code, q_inst, v_dist, v_I, v_wi, v_n, v_mcol, v_mat, v_E);
                     v_li = l + 1u;
                     phase = PH_LIGHT;
@@ -1126,7 +1164,7 @@ void render_kernel(const RenderArgs a) {
             if (alive && phase == PH_LIGHT && v_li >= sc.n_lights) {
                 V wi = mk(0, 0, 1), k = mk(0, 0, 0);
                 const bool cont = stage_bounce<MEDIUM, COUNT>(a, albedo_med, rd, depth, v_medium, v_n, v_mcol, v_mat, rng, wi, k);
-                SECT(14);
+                SECTK(14);
                 P = fma3(Q, v_E, P);
                 if (cont) {
                     if (!MEDIUM) Rc = vmin(Rc, fma3(100.f, Q, P));
@@ -1143,11 +1181,11 @@ void render_kernel(const RenderArgs a) {
             // ---- the parked walks: start when enough lanes wait, stop when most of them are through
             const bool waiting = alive && phase >= PH_WAITP;
             const uint64_t wm = __ballot(waiting);
-            const bool idle = __ballot(alive && !waiting) == 0;  // nothing else this wave could do
+            const bool idle = __ballot(alive && !waiting && !(need_path && item_done)) == 0;  // nothing else this wave could do (lanes between items wait for the hand-out)
             if (wm != 0 && (uint32_t(__popcll(wm)) >= a.defer_lanes || idle)) {
                 if (COUNT) c_wave[0] = c_wave[1] = 0;
                 if (waiting) {
-                    SECT(15);
+                    SECTK(15);
                     const bool shadow = phase == PH_WAITS;
                     const V qo = shadow ? v_x : ro, qd = shadow ? v_wi : rd;
                     AnyHit any{-kInf, 1u, 0u};  // a primary query: nothing blocks
@@ -1159,9 +1197,9 @@ void render_kernel(const RenderArgs a) {
                                                  idle ? 1u : a.defer_stop, any, c_nodes, c_btris, kStackRows, a.walk_leaf_quarters, c_wave);
                     if (walk.cur == kWalkDone) {
                         phase = shadow ? PH_HAVES : PH_HAVEP;
-                        SECT(16);
-                        if ((q_code >> 28) == K_BVHTRI) { SECT(17); }
-                        if (shadow) { SECT(18); }
+                        SECTK(16);
+                        if ((q_code >> 28) == K_BVHTRI) { SECTK(17); }
+                        if (shadow) { SECTK(18); }
                     }
                 }
                 if (COUNT) {   // every lane that walked counted the same steps
@@ -1174,24 +1212,24 @@ void render_kernel(const RenderArgs a) {
             }
             continue;
         }
-        if (!alive) continue;
+        if (!alive || need_path) continue;   // (a lane without a path waits for the wave's next item hand-out)
 
         // ---- one path vertex (one trace_ray invocation, src/renderer.rs:187-322)
         if (COUNT) c_vertices++;
-        SECT(2);
+        SECTK(2);
         float dmed, t;
         stage_distance<MEDIUM>(rng, inv_sigma_t, dmed, t);
         const float tmin = ray_tmin(ro);
         uint32_t code = CODE_MISS, inst = 0;
         closest_hit<BVH, COUNT>(sc, ro, rd, tmin, t, code, inst, stk, stride, c_nodes, c_btris);
         if (COUNT) c_rays++;
-        SECT(3);
+        SECTK(3);
         const bool hit = code != CODE_MISS;
 
         const bool ev_medium = MEDIUM && (dmed < (hit ? t : 400.f));  // src/renderer.rs:197-243
         const bool ev_surface = !ev_medium && hit;
         if (!ev_medium && !ev_surface) {  // miss: environment (src/renderer.rs:198-206, 288)
-            SECT(4);
+            SECTK(4);
             if constexpr (BVH == 0) {
                 const V v = fma3(ldv(S_Q, Q), env_color(sc, rd), ldv(S_P, P));
                 acc_add(MEDIUM ? v : vmin(v, ldv(S_RC, Rc)));   // in a medium Rc stays +inf (no firefly clamp, src/renderer.rs:229-232)
@@ -1215,10 +1253,10 @@ void render_kernel(const RenderArgs a) {
             } else if (L.kind == L_OBJECT) {
                 V I, wi;
                 float dist;
-                SECT(7);
+                SECTK(7);
                 illuminate_object<GROUPS>(sc, L, x, rng, I, wi, dist, tab);
                 if (L.twin_object >= 0) {
-                    SECT(8);
+                    SECTK(8);
                     float ts = dist * (1.f + 1e-3f);
                     uint32_t cs = CODE_MISS, is = 0;
                     // tree-walking scenes: any hit in front of the light on something other than its twin settles the test
@@ -1226,7 +1264,7 @@ void render_kernel(const RenderArgs a) {
                     closest_hit<BVH, COUNT, BVH != 0>(sc, x, wi, ray_tmin(x), ts, cs, is, stk, stride, c_nodes, c_btris,
                                                      AnyHit{range ? dist * (1.f - 1e-3f) : -kInf, L.twin_lo, L.twin_hi});
                     if (COUNT) c_rays++;
-                    SECT(9);
+                    SECTK(9);
                     stage_light_term(sc, L, albedo_med, rd, ev_medium, ts, cs, is, dist, I, wi, n, mcol, mat, E);
                 }
             }
@@ -1237,7 +1275,7 @@ void render_kernel(const RenderArgs a) {
         // ---- continue or end the path
         V wi = mk(0, 0, 1), k = mk(0, 0, 0);
         const bool cont = stage_bounce<MEDIUM, COUNT>(a, albedo_med, rd, depth, ev_medium, n, mcol, mat, rng, wi, k);
-        SECT(14);
+        SECTK(14);
         if constexpr (BVH == 0) {
             const V q = ldv(S_Q, Q);
             const V pn = fma3(q, E, ldv(S_P, P));
@@ -1268,6 +1306,9 @@ void render_kernel(const RenderArgs a) {
     }
 
     if (COUNT) {
+#ifdef RPT_SECT_CLOCKS
+        if ((threadIdx.x & 63u) < 56u) atomicAdd(&a.counters[8 + (threadIdx.x & 63u)], sect_lds_[threadIdx.x >> 6][threadIdx.x & 63u]);
+#endif
         atomicAdd(&a.counters[0], (unsigned long long)c_samples);
         atomicAdd(&a.counters[1], (unsigned long long)c_rays);
         atomicAdd(&a.counters[2], (unsigned long long)c_vertices);

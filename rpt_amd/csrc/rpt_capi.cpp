@@ -77,6 +77,7 @@ struct rpt_options {
     int64_t stream_contexts = 1;    // detach_shadows = 2: paths a lane can have waiting in memory (1..6; C5: 272 / 279 / 290 ms for 1 / 2 / 4 at
                                     // 2048x2048x128 -- every parked path is a round trip to the fabric --, 234 with detach_shadows = 1)
     int64_t detach_lanes = 44;      // ... parked primary + queued shadow queries per wave that trigger a walk session
+    int64_t pull_batch = 2;         // lanes waiting for a new work item before a wave runs its item bookkeeping (1..64)
     int64_t detach_trigger = 28;    // ... or this many queued shadow queries alone (the queue holds 32)
     int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built
     int64_t scene_tree_meshes = 0;  // 1: meshes with trees of their own are leaves of the scene tree (every query walks to completion);
@@ -108,6 +109,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "stream_contexts") { if (value < 1 || value > 6) return fail(RPT_ERR_INVALID, "stream_contexts must be 1..6"); o.stream_contexts = value; }
     else if (s == "stream_backlog") { if (value < 1 || value > 256) return fail(RPT_ERR_INVALID, "stream_backlog must be 1..256"); o.stream_backlog = value; }
     else if (s == "detach_lanes") { if (value < 1 || value > 96) return fail(RPT_ERR_INVALID, "detach_lanes must be 1..96"); o.detach_lanes = value; }
+    else if (s == "pull_batch") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "pull_batch must be 1..64"); o.pull_batch = value; }
     else if (s == "detach_trigger") { if (value < 1 || value > 32) return fail(RPT_ERR_INVALID, "detach_trigger must be 1..32"); o.detach_trigger = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
     else if (s == "epsilon_policy") { if (value < 0 || value > 1) return fail(RPT_ERR_INVALID, "epsilon_policy must be 0 or 1"); o.epsilon_policy = value; }
@@ -1847,6 +1849,7 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     a.stream_contexts = uint32_t(s->opt.stream_contexts);
     a.n_twin_lights = s->n_twin_lights;
     a.stream_scratch = nullptr;   // (run_render sizes it for the grid)
+    a.pull_batch = uint32_t(s->opt.pull_batch);
     a.detach_trigger = uint32_t(s->opt.detach_trigger);
     if (a.detach) {
         a.defer_lanes = uint32_t(s->opt.detach_lanes);
