@@ -159,7 +159,7 @@ RPT_DEV float hit_sphere(V ol, V dl, float tmin) {
     return sphere_closer(ol, dl, tmin, __builtin_inff(), t) ? t : -1.f;
 }
 // The scans' form of the three bounded primitives: "is there an accepted root closer than tbest", one chain of compares
-// (a negative discriminant leaves NaN in t, which fails them).  hit_sphere / hit_cube<false> / hit_aabb<false> are these
+// (a negative discriminant leaves NaN in t, which fails them).  hit_sphere / hit_cube / hit_aabb are these
 // with tbest = inf, and the bodies are compiled without fp contraction (their fmas are written out): a scan and a tree
 // walk that reach the same primitive then get the same bits for t wherever the body is inlined.
 RPT_DEV bool sphere_closer(V ol, V dl, float tmin, float tbest, float& t) {
@@ -191,37 +191,10 @@ RPT_DEV bool aabb_closer(const F4& lo, const F4& hi, V o, V inv, float tmin, flo
     return slabs_closer((lo.x - o.x) * inv.x, (hi.x - o.x) * inv.x, (lo.y - o.y) * inv.y, (hi.y - o.y) * inv.y,
                         (lo.z - o.z) * inv.z, (hi.z - o.z) * inv.z, tmin, tbest, t);
 }
-// Unit cube [-1/2,1/2]^3, src/shape/cube.rs:22-74.  Returns t; `axis_sign` (optional) gets the
-// face: axis | (positive ? 4 : 0).
-template <bool WANT_FACE>
-RPT_DEV float hit_cube(V ol, V dl, float tmin, uint32_t& face) {
-    if constexpr (!WANT_FACE) {   // t alone: the same entry / exit parameters through min / max instead of compare + select
-        float t;
-        return cube_closer(ol, dl, tmin, __builtin_inff(), t) ? t : -1.f;
-    }
-    float ix = rcp(dl.x), iy = rcp(dl.y), iz = rcp(dl.z);
-    float x1 = (-0.5f - ol.x) * ix, x2 = (0.5f - ol.x) * ix;
-    float y1 = (-0.5f - ol.y) * iy, y2 = (0.5f - ol.y) * iy;
-    float z1 = (-0.5f - ol.z) * iz, z2 = (0.5f - ol.z) * iz;
-    bool sx = x1 > x2, sy = y1 > y2, sz = z1 > z2;
-    float xl = sx ? x2 : x1, xh = sx ? x1 : x2;
-    float yl = sy ? y2 : y1, yh = sy ? y1 : y2;
-    float zl = sz ? z2 : z1, zh = sz ? z1 : z2;
-    float start = max3(xl, yl, zl);
-    float end = min3(xh, yh, zh);
-    if (start > end || end < tmin) return -1.f;
-    bool use_end = start < tmin;
-    if (WANT_FACE) {
-        // start face: entering through the low side (normal -1) unless swapped; end face: +1 unless swapped
-        uint32_t as, ae;
-        if (xl > yl && xl > zl) as = 0; else if (yl > zl) as = 1; else as = 2;
-        if (xh < yh && xh < zh) ae = 0; else if (yh < zh) ae = 1; else ae = 2;
-        uint32_t ax = use_end ? ae : as;
-        bool swapped = ax == 0 ? sx : (ax == 1 ? sy : sz);
-        bool positive = use_end ? !swapped : swapped;
-        face = ax | (positive ? 4u : 0u);
-    }
-    return use_end ? end : start;
+// Unit cube [-1/2,1/2]^3, src/shape/cube.rs:22-74: t of the accepted root (the face is found from the hit point: box_face_normal).
+RPT_DEV float hit_cube(V ol, V dl, float tmin) {
+    float t;
+    return cube_closer(ol, dl, tmin, __builtin_inff(), t) ? t : -1.f;
 }
 // Plane, src/shape/plane.rs:17-32 (world-space (n, value)).
 RPT_DEV float hit_plane(const F4& nv, V o, V d, float tmin) {
@@ -244,33 +217,9 @@ RPT_DEV float hit_tri(const F4& pn, const F4& A, const F4& B, V o, V d, float tm
 // Axis-aligned box in world space (a cube under positive scale + translation): the reference's
 // local slab test (src/shape/cube.rs:22-74) evaluated in world coordinates, where it yields the
 // same entry/exit parameters because t is shared between the two spaces.  `inv` = 1/d.
-template <bool WANT_FACE>
-RPT_DEV float hit_aabb(const F4& lo, const F4& hi, V o, V inv, float tmin, uint32_t& face) {
-    if constexpr (!WANT_FACE) {   // (as in hit_cube)
-        float t;
-        return aabb_closer(lo, hi, o, inv, tmin, __builtin_inff(), t) ? t : -1.f;
-    }
-    float x1 = (lo.x - o.x) * inv.x, x2 = (hi.x - o.x) * inv.x;
-    float y1 = (lo.y - o.y) * inv.y, y2 = (hi.y - o.y) * inv.y;
-    float z1 = (lo.z - o.z) * inv.z, z2 = (hi.z - o.z) * inv.z;
-    bool sx = x1 > x2, sy = y1 > y2, sz = z1 > z2;
-    float xl = sx ? x2 : x1, xh = sx ? x1 : x2;
-    float yl = sy ? y2 : y1, yh = sy ? y1 : y2;
-    float zl = sz ? z2 : z1, zh = sz ? z1 : z2;
-    float start = max3(xl, yl, zl);
-    float end = min3(xh, yh, zh);
-    const bool miss = start > end || end < tmin;
-    bool use_end = start < tmin;
-    if (WANT_FACE) {
-        uint32_t as, ae;
-        if (xl > yl && xl > zl) as = 0; else if (yl > zl) as = 1; else as = 2;
-        if (xh < yh && xh < zh) ae = 0; else if (yh < zh) ae = 1; else ae = 2;
-        uint32_t ax = use_end ? ae : as;
-        bool swapped = ax == 0 ? sx : (ax == 1 ? sy : sz);
-        bool positive = use_end ? !swapped : swapped;
-        face = ax | (positive ? 4u : 0u);
-    }
-    return miss ? -1.f : (use_end ? end : start);
+RPT_DEV float hit_aabb(const F4& lo, const F4& hi, V o, V inv, float tmin) {
+    float t;
+    return aabb_closer(lo, hi, o, inv, tmin, __builtin_inff(), t) ? t : -1.f;
 }
 // Axis-aligned rectangle = two coplanar triangles of src/shape/mesh.rs:50-83 (u,v,w >= 0 on one
 // of them <=> the point lies in the closed rectangle).  oa/da/ia: origin, direction and 1/direction
@@ -364,12 +313,10 @@ RPT_DEV void hit_prim(const SceneView& scene_, uint32_t pc, V o, V d, V inv, flo
         const XfScan x = sc.cub[i];
         V ol, dl;
         to_local(x, o, d, ol, dl);
-        uint32_t f;
-        t = hit_cube<false>(ol, dl, tmin, f);
+        t = hit_cube(ol, dl, tmin);
     } else if (kind == K_AABB) {
         const AabbScan b = sc.aabb[i];
-        uint32_t f;
-        t = hit_aabb<false>(b.lo, b.hi, o, inv, tmin, f);
+        t = hit_aabb(b.lo, b.hi, o, inv, tmin);
     } else if (kind == K_RECT) {
         const RectScan r = sc.rect[i];
         if (i < sc.n_rect_x) t = hit_rect(r.a, r.b.x, o.x, inv.x, o.y, d.y, o.z, d.z, tmin, tbest);
@@ -724,6 +671,15 @@ RPT_DEV void scan_or_tree(const SceneView& scene_, V o, V d, float tmin, float& 
     }
 }
 
+// Outward normal of the face of the axis-aligned box [lo, hi] that the surface point p lies on: the axis whose nearer face
+// plane is closest to p.
+RPT_DEV V box_face_normal(V p, V lo, V hi) {
+    const float xl = fabsf(p.x - lo.x), xh = fabsf(p.x - hi.x), yl = fabsf(p.y - lo.y), yh = fabsf(p.y - hi.y);
+    const float zl = fabsf(p.z - lo.z), zh = fabsf(p.z - hi.z);
+    const float ex = fminf(xl, xh), ey = fminf(yl, yh), ez = fminf(zl, zh);
+    const bool ax0 = ex <= ey && ex <= ez, ax1 = !ax0 && ey <= ez;
+    return mk(ax0 ? (xh < xl ? 1.f : -1.f) : 0.f, ax1 ? (yh < yl ? 1.f : -1.f) : 0.f, (!ax0 && !ax1) ? (zh < zl ? 1.f : -1.f) : 0.f);
+}
 // Normal and object of the winning primitive (per lane).
 RPT_DEV void finalize_hit(const SceneView& scene_, V o, V d, float tmin, float t, uint32_t code, uint32_t inst, V& n,
                           uint32_t& obj) {
@@ -761,21 +717,14 @@ RPT_DEV void finalize_hit(const SceneView& scene_, V o, V d, float tmin, float t
         const XfShade s = sc.cub_sh[idx];
         V ol, dl;
         to_local(x, o, d, ol, dl);
-        uint32_t face = 0;
-        // same slab arithmetic and tmin as the scan, so the same root/face is selected
-        (void)hit_cube<true>(ol, dl, tmin, face);
-        float sg = (face & 4u) ? 1.f : -1.f;
-        uint32_t ax = face & 3u;
-        V nl = mk(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f);
+        // the face the hit point lies on (src/shape/cube.rs:37-55 picks the slab that bounds the root: the same face except
+        // within rounding of an edge), from the point instead of a second run of the slab test
+        const V nl = box_face_normal(fma3(t, dl, ol), mk(-0.5f, -0.5f, -0.5f), mk(0.5f, 0.5f, 0.5f));
         n = (s.r1.w != 0.f) ? normalize(mk(dot3(s.r0, nl), dot3(s.r1, nl), dot3(s.r2, nl))) : nl;
         obj = __float_as_uint(s.r0.w);
     } else if (kind == K_AABB) {
         const AabbScan b = sc.aabb[idx];
-        uint32_t face = 0;
-        (void)hit_aabb<true>(b.lo, b.hi, o, mk(rcp(d.x), rcp(d.y), rcp(d.z)), tmin, face);
-        float sg = (face & 4u) ? 1.f : -1.f;
-        uint32_t ax = face & 3u;
-        n = mk(ax == 0 ? sg : 0.f, ax == 1 ? sg : 0.f, ax == 2 ? sg : 0.f);
+        n = box_face_normal(fma3(t, d, o), xyz(b.lo), xyz(b.hi));   // (as for the cube)
         obj = __float_as_uint(b.lo.w);
     } else if (kind == K_RECT) {
         const F4 s = sc.rect_sh[idx].n_obj;

@@ -350,10 +350,20 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
         # (in fog the lamps' shadow queries leave their paths by default: here the parked form, the detached one below)
         rpt_amd.set_option("detach_shadows", 0)
         frames = [render(*v) for v in ((32, 16), (1, 1), (64, 64), (64, 1), (8, 5), (32, 16, 0), (32, 16, 1), (40, 8, 64))]
+        # how many lanes wait for a new work item before the wave hands items out ("pull_batch"): lanes between items idle
+        for pb in (1, 7, 64):
+            rpt_amd.set_option("pull_batch", pb)
+            frames.append(render(32, 16))
+        rpt_amd.set_option("pull_batch", 2)
         rpt_amd.set_option("detach_shadows", 1)
         # detached shadow queries (kernels.hip, DETACH): when a walk session starts (waiting + queued queries, queued alone), when
         # it is left, a queue that overflows at every vertex (trigger 32 with sessions that start late) -- not one bit
         detached = [render_detached(*v) for v in ((48, 20, 16), (1, 1, 1), (96, 32, 32), (64, 32, 1), (8, 3, 5), (48, 20, 16, 0), (96, 32, 8, 64))] if fog else []
+        if fog:   # stalled lanes (answers outstanding), lanes waiting for the hand-out and the session trigger must not wait for each other
+            for pb in (1, 9, 64):
+                rpt_amd.set_option("pull_batch", pb)
+                detached.append(render_detached(48, 20, 16))
+            rpt_amd.set_option("pull_batch", 2)
         # streamed walks (DETACH = 2): primary queries leave as well, their paths wait in memory; session threshold and exit rule
         streamed = []
         if fog:
@@ -362,7 +372,10 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
                 rpt_amd.set_option("stream_backlog", backlog)
                 rpt_amd.set_option("stream_contexts", contexts)
                 streamed.append(render(32, stop))
+            rpt_amd.set_option("pull_batch", 16)
+            streamed.append(render(32, 16))
     finally:
+        rpt_amd.set_option("pull_batch", 2)
         rpt_amd.set_option("detach_shadows", 1)
         rpt_amd.set_option("stream_backlog", 48)
         rpt_amd.set_option("stream_contexts", 1)
@@ -530,3 +543,22 @@ def test_hdri_environment_matches_oracle():
     top = Renderer(sc, cam).width(size).height(size).max_bounces(0).seed(1).sample_array(4)
     exp_top = _oracle(sc).render(cam, size, size, 4, 0, seed=1, robust=1)
     assert np.allclose(top[:size], exp_top[:size], rtol=2e-4, atol=1e-6)       # first image row sees only sky
+
+
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_item_hand_out_batches_do_not_change_the_frame(name):
+    """Scan kernels: a wave hands out work items when "pull_batch" lanes wait for one (or nothing else is left to do);
+    lanes between items take no part in a trip.  Which lane renders an item, and when, must not change one bit."""
+    import rpt_amd
+    scene, cam, cfg = scenes.CONFIGS[name]()
+    frames = []
+    try:
+        for pb in (1, 2, 5, 33, 64):
+            rpt_amd.set_option("pull_batch", pb)
+            r = Renderer(scene, cam).width(80).height(72).max_bounces(cfg["max_bounces"]).seed(3)
+            frames.append(r.sample_array(40))
+    finally:
+        rpt_amd.set_option("pull_batch", 2)
+    assert np.all(np.isfinite(frames[0])) and frames[0].mean() > 0
+    for f in frames[1:]:
+        assert np.array_equal(frames[0], f)
