@@ -189,6 +189,17 @@ int rpt_scene_render_chunking(rpt_scene*, uint32_t iterations, uint32_t* chunk_s
  * "photon_skip" (diagnostic bit mask that switches parts of the photon camera pass off), "defer_lanes" / "defer_stop" (scenes whose meshes
  * have their own trees: a wave starts its parked tree walks when this many lanes wait, default 32, and leaves
  * them when fewer than this many are still walking, default 16; the image does not depend on either),
+ * "detach_shadows" 0/1/2 (scenes whose meshes have their own trees, in a medium: 1, the default: a shadow query that needs a tree walk
+ * leaves its path and is answered from a queue of its wave, "detach_lanes" (default 44) waiting + queued queries or "detach_trigger"
+ * (default 28) queued ones start a walk session; 0: shadow queries park like primary ones; 2: primary queries leave as well, their
+ * paths wait in memory, "stream_backlog" (default 48) queued queries start a session and a lane may have "stream_contexts" (1..6,
+ * default 1) paths waiting -- slower, kept for measurement; the image depends on none of the thresholds),
+ * "scene_tree_meshes" 0/1 (read by rpt_scene_commit: in a scene that has a scene-level tree, 1 makes the meshes with trees of their own
+ * leaves of it; default 0: their walks are parked beside it), "bvh_sweep_below" (read by rpt_scene_commit: ranges of at most this many
+ * triangles are split by an exact SAH sweep instead of 16 bins, default 4096, 0 = bins only),
+ * "photon_split" 0/1 (camera pass of the beam kinds in a medium: volume and surface estimate as two launches, default 0 -- slower),
+ * "pull_batch" (path tracer: a wave hands out new work items when this many of its lanes wait for one, or when none of its lanes
+ * has anything else to do; 1..64, default 2; no effect on the image),
  * "walk_leaf_quarters" (same scenes: the descent of such a walk pauses for the triangle tests as soon as 4 x the lanes
  * waiting at a leaf >= this x the lanes still descending, default 6, 0 = when every lane is at a leaf; no effect on the image),
  * "bvh_leaf_max" (read by rpt_scene_commit: triangles per leaf of a mesh tree, default 4 -- C5: 49.8 / 43.1 / 41.1 /
