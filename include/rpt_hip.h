@@ -321,8 +321,10 @@ int rpt_frame_unpack_device(uint32_t width, uint32_t height, uint32_t rank, uint
  * photon mapping.
  * rpt_debug_epsilon_counters (option "counters" = 1): [0] closest-hit queries, [1] accepted hits, [2] accepted hits with
  * t < 1e-9 (1 + |origin|) -- a ray hitting the surface it starts on --, [3] shadow tests, [4] passed, [5] failed although
- * |hit - dist| < 1e-6 dist -- the light's own surface missed by rounding --, [6] camera samples, [7] path vertices. */
-int rpt_debug_epsilon_counters(rpt_scene*, uint64_t out[8]);
+ * |hit - dist| < 1e-6 dist -- the light's own surface missed by rounding --, [6] camera samples, [7] path vertices; the
+ * schedule: [8] objects evaluated in fp64 (all lanes), [9] wave-level evaluation rounds, [10] wave-level loop trips, [11] lanes
+ * holding a path summed over the trips. */
+int rpt_debug_epsilon_counters(rpt_scene*, uint64_t out[12]);
 
 /* ---- device self-test hooks (each runs the device function in a one-block kernel) ---- */
 int rpt_debug_rng_u32(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, uint32_t* out);

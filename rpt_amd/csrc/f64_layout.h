@@ -3,8 +3,15 @@
 // The fp32 path replaces rpt's 1e-12 epsilons (src/renderer.rs:17, 348, 396, 420) by tolerances fp32 can resolve and
 // specialises primitives at flatten time.  This mode does neither: every object is the reference's generic shape under
 // its own `Transformed` matrices, in fp64, tested in scene order with t_min = 1e-12, and the shadow test is
-// |hit - dist| < 1e-12.  It exists for callers who need rpt's own numbers (its self-hits and false shadow rejections
-// included), not its speed.
+// |hit - dist| < 1e-12: a caller gets rpt's own numbers, its self-hits and false shadow rejections included.
+//
+// What is MI355X about it (round 4): the fp64 arithmetic of an object is the reference's, but it is only run for the
+// objects a ray can reach.  Every object carries a padded world-space box in fp32 (`CullBox`, read through the scalar
+// cache); a lane first tests its ray against all of them at the full fp32 rate and keeps a bit mask of candidates, then
+// evaluates its own candidates -- a different object in every lane -- in scene order from per-lane records (`ObjRec`,
+// `TriRec`, staged in LDS when the scene is small).  An object the box test rejects cannot change the reference's
+// HitRecord (its literal test would miss, or hit no closer than what is already known to decide the event), so the
+// closest hit, its time and its normal are bit for bit those of the full scan (tests: culling on = off).
 #pragma once
 #include <stdint.h>
 
@@ -13,7 +20,8 @@ namespace rpt64 {
 enum : int32_t { SH_SPHERE = 0, SH_CUBE = 1, SH_PLANE = 2, SH_MESH = 3 };
 enum : int32_t { LT_POINT = 0, LT_AMBIENT = 1, LT_DIRECTIONAL = 2, LT_OBJECT = 3 };
 
-// One `Box<dyn Shape>`: unit primitive / plane / mesh, optionally under Transformed<T> (src/shape.rs:102-152).
+// One `Box<dyn Shape>`: unit primitive / plane / mesh, optionally under Transformed<T> (src/shape.rs:102-152).  The full
+// record: what Shape::sample of a light needs (wave-uniform, scalar loads).
 struct Shape {
     int32_t kind, has_xf;
     uint32_t tri_first, tri_count;   // SH_MESH: triangles in the mesh's own (local) space, in the order they were given
@@ -32,20 +40,54 @@ struct Mat {   // src/material.rs:8-23
     int32_t kind, _pad;
     double albedo[3], emittance, shininess, ior;
 };
-struct Object {
-    Shape shape;
-    Mat mat;
-};
 struct Light {   // src/light.rs:7-19
     int32_t kind, _pad;
     double color[3];   // Ambient / Point / Directional colour
-    Object obj;        // Light::Object
+    Shape shape;       // Light::Object
+    Mat mat;
 };
+
+// ---- what a closest-hit query reads
+// Padded world-space bounds of one object in fp32 (planes: unbounded).  32 bytes, wave-uniform: one s_load_dwordx8.
+struct CullBox {
+    float lo[3];
+    uint32_t unbounded;
+    float hi[3];
+    uint32_t _pad;
+};
+// What Shape::intersect of one object needs, read per lane (every lane may hold a different object): 160 bytes.
+struct ObjRec {
+    int32_t kind, has_xf;
+    uint32_t tri_first, tri_count;
+    double inv[12];   // rows of M^-1 (3 x 4)
+    double b[6];      // SH_MESH: KdTree::bounds min, max; SH_CUBE: -0.5 x 3, 0.5 x 3 (src/shape/cube.rs:25-26); SH_PLANE: normal, value
+};
+// Triangle::intersect (src/shape/mesh.rs:50-83) with everything that depends on the triangle alone evaluated once, on
+// the host, by the same IEEE operations in the same order (no contraction): the plane normal normalize(cross(d0, d1)),
+// d00, d01, d11 and denom are bit for bit what the reference recomputes per call.  128 bytes.
+struct TriRec {
+    double v1[3], pn[3], d0[3], d1[3];
+    double d00, d01, d11, denom;
+};
+// ... and what shading the winning object needs (per lane, once per query)
+struct ObjShade {
+    double nrm[9];   // (linear)^-T
+    Mat mat;
+};
+struct TriShade {
+    double n1[3], n2[3], n3[3];
+};
+
 struct Scene {
-    const Object* objects;
-    const Tri* tris;
+    const CullBox* cull;        // [n_objects]
+    const ObjRec* recs;         // [n_objects]
+    const ObjShade* shade;      // [n_objects]
+    const TriRec* trecs;        // [n_obj_tris]: the triangles of scene.objects' meshes
+    const TriShade* tshade;     // [n_obj_tris]
+    const Tri* tris;            // [n_tris]: vertices and normals as given -- the objects' triangles, then those of the lights' meshes (Triangle::sample)
+    const double* tri_pdf;      // [n_tris]: (1 / area) / triangles of the mesh (src/shape/mesh.rs:96-98, src/kdtree.rs:141-146)
     const Light* lights;
-    uint32_t n_objects, n_lights;
+    uint32_t n_objects, n_lights, n_tris, n_obj_tris;
     int32_t has_medium, medium_kind;
     double absorption, scattering;
     double env[3];
@@ -54,18 +96,21 @@ struct Camera {   // src/camera.rs:9-27, with `d` and `right` of cast_ray (:67-6
     double eye[3], direction[3], up[3], right[3];
     double d, aperture, focal_distance;
 };
+static constexpr uint32_t kLdsObjs = 32u, kLdsTris = 32u;   // tables staged in LDS when the scene has at most this many
 struct Args {
     Scene sc;
     Camera cam;
     uint32_t width, height, iterations, sample_offset, max_bounces;
-    uint32_t n_owned, tiles_x, _pad;
+    uint32_t n_owned, tiles_x, n_items;
+    uint32_t chunk_spp, n_chunks, pull_batch, cull;   // cull: 0 = every object is evaluated for every ray (the plain reference scan)
     const uint32_t* tiles;
     uint64_t seed_mixed;
     double medium_color[3], medium_color_hi[3];   // Medium::color: hex_color(0xD2B48C), or blue (y <= 250) / red for the glowing fog
     double dim;       // max(width, height) as f64 (src/renderer.rs:174)
-    double scale;     // 2^exposure_value
-    double* out;      // width * height * 3
-    unsigned long long* counters;   // [0] rays [1] accepted hits [2] self hits [3] shadow tests [4] passed [5] near misses [6] samples [7] vertices; or null
+    unsigned long long* queue;      // work counter of the launch
+    double* slab;                   // [n_chunks][n_owned][4]: partial sums of (pixel, chunk) items
+    unsigned long long* counters;   // [0] rays [1] accepted hits [2] self hits [3] shadow tests [4] passed [5] near misses [6] samples [7] vertices
+                                    // [8] objects evaluated [9] evaluation rounds (wave-level) [10] trips (wave-level) [11] live lanes summed over trips; or null
 };
 
 }  // namespace rpt64

@@ -28,12 +28,14 @@ void photon_release(void* p);      // defined in photon.hip
 // (the photon camera pass: 64); option and automatic rule are ignored, so the slab [n_chunks][n_owned] this
 // function sizes is the one that kernel and resolve_kernel index.
 int prepare_render(rpt_scene* s, hipStream_t st, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations, uint64_t seed,
-                   uint32_t sample_offset, rptg::RenderArgs& a, uint32_t min_chunk = 0, uint32_t fixed_chunk = 0);
+                   uint32_t sample_offset, rptg::RenderArgs& a, uint32_t min_chunk = 0, uint32_t fixed_chunk = 0,
+                   uint32_t slab_item_bytes = 16);   // 32: the reference-epsilon mode's partial sums are fp64
 // Zeroes the queue / sharded frame, calls `launch(args, n_blocks, stream)` with a persistent grid of
 // blocks_per_cu blocks per CU, then resolves the slab into d_out.
 int run_persistent(rpt_scene* s, const rpt_render_params* prm, const rptg::RenderArgs& a, double* d_out, hipStream_t st,
                    int blocks_per_cu, const std::function<hipError_t(const rptg::RenderArgs&, int, hipStream_t)>& launch,
-                   bool indexed_start = false, bool wave_items = false);  // wave_items: n_items counts one item per wave, not per lane
+                   bool indexed_start = false, bool wave_items = false,   // wave_items: n_items counts one item per wave, not per lane
+                   const std::function<hipError_t(double, double*, hipStream_t)>& resolve = nullptr);   // (scale, d_out, stream): instead of resolve_kernel
 int serialize_with_other_streams(rpt_scene* s, hipStream_t st);  // for launches with per-scene scratch outside the launch set
 int fetch_counters(rpt_scene* s, const rptg::RenderArgs& a);  // after the stream has been synchronised
 double* scratch_out(rpt_scene* s, size_t bytes);  // cached device frame for the host-buffer entry points

@@ -79,6 +79,8 @@ hipError_t launch_debug_camera(const CameraG& cam, uint32_t w, uint32_t h, uint6
 }  // namespace rptg
 namespace rpt64 { struct Args; }
 namespace rptg {
-// Reference-epsilon mode (kernels_f64.hip): one thread per owned pixel, frame written directly.
-hipError_t launch_render_f64(const rpt64::Args& a, hipStream_t stream);
+// Reference-epsilon mode (kernels_f64.hip): persistent grid over (pixel, chunk) items with an fp64 slab, then its resolve.
+hipError_t launch_render_f64(const rpt64::Args& a, int n_blocks, hipStream_t stream);
+hipError_t launch_resolve_f64(const rpt64::Args& a, double scale, double* d_out, hipStream_t stream);
+hipError_t render_f64_occupancy(bool medium, int* blocks_per_cu);
 }  // namespace rptg

@@ -1,16 +1,20 @@
 // kernels_f64.hip — the reference-epsilon mode (option "epsilon_policy" = 1): rpt's sampling path in fp64 with rpt's
-// own epsilons, for callers who need the reference's numbers rather than the fp32 path's speed.
+// own epsilons, on the fp32 path's machinery (persistent grid, wave-batched work queue, path regeneration, slab).
 //
-// Everything here follows the cited reference lines literally: every object of scene.objects is tested per ray, in
-// scene order, as the generic shape it is under its own `Transformed` matrices (no flatten-time specialisation, no
-// tree: `Mesh` objects are scanned triangle by triangle behind the kd-tree's root box test), t_min = EPSILON = 1e-12
-// (src/renderer.rs:17, 420), the light is visible iff |closest hit - distance to the sample| < 1e-12 (:348, :396),
-// colours and path state are f64, and the compiler may not contract a*b+c (the self-intersections at t ~ 1e-11 and the
-// near-miss shadow rejections that make rpt's images slightly darker are rounding noise of exactly these formulas).
-// What is NOT the reference's: the RNG (per-(seed, pixel, sample) xoshiro128+ stream of the fp32 path, DESIGN.md
-// section 2, deviation 1 -- the reference seeds from entropy) and the evaluation of the recursion as a loop with the
-// carrier min(P + Q x, R) (exact algebra of src/renderer.rs:229-232, 271-280, 308-313; rounding-level differences only).
-// One lane = one pixel: its samples are summed in order, as get_color does (:173-184); no partial-sum slab.
+// The ARITHMETIC is the cited reference lines, literally: generic shapes under their own `Transformed` matrices, scene
+// order, t_min = EPSILON = 1e-12 (src/renderer.rs:17, 420), the light is visible iff |closest hit - distance to the
+// sample| < 1e-12 (:348, :396), colours and path state in f64, no contraction of a*b+c (the self-intersections at
+// t ~ 1e-11 and the near-miss shadow rejections that make rpt's images slightly darker are rounding noise of exactly
+// these formulas).  What is NOT the reference's: the RNG (per-(seed, pixel, sample) xoshiro128+ stream of the fp32
+// path, DESIGN.md section 2, deviation 1), the recursion evaluated as a loop with the carrier min(P + Q x, R) (exact
+// algebra of src/renderer.rs:229-232, 271-280, 308-313), and the order of the additions that form a pixel's mean
+// (chunks of samples summed separately, then in chunk order: 1e-16 relative).
+//
+// The SCHEDULE is this file's own (f64_layout.h): a closest-hit query first tests the ray against every object's
+// padded world box in fp32 (wave-uniform records from the scalar cache, full rate), then each lane evaluates only its
+// own candidates in fp64, in scene order, a different object in every lane, from per-lane records in LDS.  Objects the
+// box test drops cannot change the reference's HitRecord, so hit, time and normal are those of the full scan bit for
+// bit (`cull` = 0 runs the full scan; tests/test_gpu_epsilon.py compares the two frames for equality).
 #include <hip/hip_runtime.h>
 
 #include "device_core.h"   // Rng (the fp32 path's stream, bit for bit)
@@ -22,6 +26,15 @@
 namespace rpt64 {
 
 #define R64_DEV __device__ __forceinline__
+#define R64_CONST __attribute__((address_space(4)))
+// The kernel's arguments, read from the kernel-argument segment where they are used (scalar loads through the constant
+// address space) instead of being held in scalar registers from the kernel's entry: ~100 dwords of arguments would
+// otherwise live in VGPR lanes (kernels.hip, "kernel arguments are read where they are used").  Valid in
+// render_f64_kernel and what it inlines: `Args` is that kernel's one argument.
+#define KA (*rptg::kernarg_args<Args>())
+#ifndef R64_WAVES
+#define R64_WAVES 3   // waves per SIMD the kernel is compiled for (168 VGPRs)
+#endif
 
 static constexpr double kEps = 1e-12;            // src/renderer.rs:17
 static constexpr double kFireflyClamp = 100.0;   // src/renderer.rs:18
@@ -32,7 +45,7 @@ struct D {
     double x, y, z;
 };
 R64_DEV D mk(double x, double y, double z) { return D{x, y, z}; }
-R64_DEV D ld(const double* p) { return D{p[0], p[1], p[2]}; }
+template <class P> R64_DEV D ld(P p) { return D{p[0], p[1], p[2]}; }
 R64_DEV D operator+(D a, D b) { return D{a.x + b.x, a.y + b.y, a.z + b.z}; }
 R64_DEV D operator-(D a, D b) { return D{a.x - b.x, a.y - b.y, a.z - b.z}; }
 R64_DEV D operator-(D a) { return D{-a.x, -a.y, -a.z}; }
@@ -45,16 +58,21 @@ R64_DEV D cross(D a, D b) { return D{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.
 R64_DEV double length(D a) { return sqrt(dot(a, a)); }
 R64_DEV D normalize(D a) { return a / length(a); }
 R64_DEV D vmin(D a, D b) { return D{fmin(a.x, b.x), fmin(a.y, b.y), fmin(a.z, b.z)}; }
-R64_DEV bool is_zero(D a) { return a.x == 0.0 && a.y == 0.0 && a.z == 0.0; }
-R64_DEV D mul3(const double* m, D v) {   // 3 x 3, row-major
+template <class P> R64_DEV D mul3(P m, D v) {   // 3 x 3, row-major
     return D{m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z, m[6] * v.x + m[7] * v.y + m[8] * v.z};
 }
-R64_DEV D xf_point(const double* m, D p) {   // rows of a 3 x 4: M * (p, 1)
+template <class P> R64_DEV D xf_point(P m, D p) {   // rows of a 3 x 4: M * (p, 1)
     return D{m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]};
 }
-R64_DEV D xf_dir(const double* m, D d) {     // M * (d, 0)
+template <class P> R64_DEV D xf_dir(P m, D d) {     // M * (d, 0)
     return D{m[0] * d.x + m[1] * d.y + m[2] * d.z, m[4] * d.x + m[5] * d.y + m[6] * d.z, m[8] * d.x + m[9] * d.y + m[10] * d.z};
+}
+// A wave-uniform record read through the constant address space (scalar loads, SGPR operands of the fp64 instructions)
+template <class T> R64_DEV const R64_CONST T& uniform_ref(const T* p) { return *(const R64_CONST T*)(uintptr_t)p; }
+
+RPT_DEV uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
 }
 
 // The fp32 path's RNG stream read as f64: u = (2k+1) 2^-24 is the same number in both precisions.
@@ -72,143 +90,191 @@ struct Rng64 {
     }
 };
 
-struct Hit {   // HitRecord, src/shape.rs:76-99
-    double time;
-    D normal;
+// ---------------------------------------------------------------------------- the closest-hit query
+// HitRecord (src/shape.rs:76-99) of a query in progress.  The normal is formed once, for the winner (`hit_normal`):
+// until then the record keeps what the winning primitive's normal is computed from.
+struct Query {
+    double t;        // HitRecord::time
+    int32_t obj;     // index into scene.objects, -1: none
+    uint32_t aux;    // cube: axis | negative << 2; plane: sign of the cosine; mesh: triangle (index into trecs)
+    D p;             // sphere: o + t d in the sphere's space; mesh: barycentric (u, v, w)
 };
 
-// ---------------------------------------------------------------------------- shapes
-// Sphere::intersect, src/shape/sphere.rs:14-46
-R64_DEV bool hit_sphere(D o, D d, double t_min, Hit& rec) {
-    const double a = dot(d, d), b = dot(d, o), c = dot(o, o) - 1.0;
-    double disc = b * b - a * c;
-    if (__builtin_signbit(disc)) return false;
-    disc = sqrt(disc);
-    double t = (-b - disc) / a;
-    if (t < t_min) {
-        t = (-b + disc) / a;
-        if (t < t_min) return false;
-    }
-    if (t < rec.time) {
-        rec.time = t;
-        rec.normal = normalize(o + t * d);
-        return true;
-    }
-    return false;
-}
-// Cube::intersect, src/shape/cube.rs:22-74
-R64_DEV bool hit_cube(D o, D d, double t_min, Hit& rec) {
-    double lo[3], hi[3], sg_lo[3], sg_hi[3];
-    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        double x1 = (-0.5 - oo[k]) / dd[k], x2 = (0.5 - oo[k]) / dd[k];
-        double n1 = -1.0, n2 = 1.0;
-        if (x1 > x2) { const double t = x1; x1 = x2; x2 = t; n1 = 1.0; n2 = -1.0; }
-        lo[k] = x1; hi[k] = x2; sg_lo[k] = n1; sg_hi[k] = n2;
-    }
-    int as, ae;
-    if (lo[0] > lo[1] && lo[0] > lo[2]) as = 0; else if (lo[1] > lo[2]) as = 1; else as = 2;
-    if (hi[0] < hi[1] && hi[0] < hi[2]) ae = 0; else if (hi[1] < hi[2]) ae = 1; else ae = 2;
-    const double start = as == 0 ? lo[0] : (as == 1 ? lo[1] : lo[2]), end = ae == 0 ? hi[0] : (ae == 1 ? hi[1] : hi[2]);
-    if (start > end || end < t_min) return false;
-    const bool use_end = start < t_min;
-    const double time = use_end ? end : start;
-    if (time < rec.time) {
-        const int ax = use_end ? ae : as;
-        const double sg = use_end ? (ae == 0 ? sg_hi[0] : (ae == 1 ? sg_hi[1] : sg_hi[2])) : (as == 0 ? sg_lo[0] : (as == 1 ? sg_lo[1] : sg_lo[2]));
-        rec.time = time;
-        rec.normal = mk(ax == 0 ? sg : 0.0, ax == 1 ? sg : 0.0, ax == 2 ? sg : 0.0);
-        return true;
-    }
-    return false;
-}
-// Plane::intersect, src/shape/plane.rs:17-32
-R64_DEV bool hit_plane(const double* pl, D o, D d, double t_min, Hit& rec) {
-    const D n = ld(pl);
-    const double cosine = dot(n, d);
-    if (fabs(cosine) < 1e-8) return false;
-    const double time = (pl[3] - dot(n, o)) / cosine;
-    if (time >= t_min && time < rec.time) {
-        rec.time = time;
-        const double sg = cosine > 0.0 ? 1.0 : (cosine < 0.0 ? -1.0 : (__builtin_signbit(cosine) ? -1.0 : 1.0));   // f64::signum
-        rec.normal = -(normalize(n)) * sg;
-        return true;
-    }
-    return false;
-}
-// Triangle::intersect, src/shape/mesh.rs:50-83
-R64_DEV bool hit_tri(const Tri& tr, D o, D d, double t_min, Hit& rec) {
-    const D v1 = ld(tr.v1);
-    const D d0 = ld(tr.v2) - v1, d1 = ld(tr.v3) - v1;
-    const D pn = normalize(cross(d0, d1));
-    const double cosine = dot(pn, d);
-    if (fabs(cosine) < 1e-8) return false;
-    const double time = dot(pn, v1 - o) / cosine;
-    if (time < t_min || time >= rec.time) return false;
-    const D d2 = (o + time * d) - v1;
-    const double d00 = dot(d0, d0), d01 = dot(d0, d1), d11 = dot(d1, d1), d20 = dot(d2, d0), d21 = dot(d2, d1);
-    const double denom = d00 * d11 - d01 * d01;
-    const double v = (d11 * d20 - d01 * d21) / denom, w = (d00 * d21 - d01 * d20) / denom, u = 1.0 - v - w;
-    if (u >= 0.0 && v >= 0.0 && w >= 0.0) {
-        rec.time = time;
-        rec.normal = normalize(u * ld(tr.n1) + v * ld(tr.n2) + w * ld(tr.n3));
-        return true;
-    }
-    return false;
-}
-// `Mesh = KdTree<Triangle>` (src/shape/mesh.rs:106): KdTree::intersect rejects the ray against the tree's bounds
-// (src/kdtree.rs:132-139, BoundingBox::intersect :56-71; f64::min / max ignore a NaN operand like fmin / fmax), then
-// finds the closest triangle.  The kd-tree below the root is an acceleration structure: every triangle is tested here.
-R64_DEV bool hit_mesh(const Scene& sc, const Shape& s, D o, D d, double t_min, Hit& rec) {
-    const double x1 = (s.bmin[0] - o.x) / d.x, x2 = (s.bmax[0] - o.x) / d.x;
-    const double y1 = (s.bmin[1] - o.y) / d.y, y2 = (s.bmax[1] - o.y) / d.y;
-    const double z1 = (s.bmin[2] - o.z) / d.z, z2 = (s.bmax[2] - o.z) / d.z;
-    const double b_min = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmin(z1, z2));
-    const double b_max = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
-    if (fmax(b_min, t_min) > fmin(b_max, rec.time)) return false;
-    bool any = false;
-    for (uint32_t i = 0; i < s.tri_count; i++)
-        if (hit_tri(sc.tris[s.tri_first + i], o, d, t_min, rec)) any = true;
-    return any;
-}
-// Shape::intersect of one object, Transformed::intersect (src/shape.rs:128-138) around it when has_xf
-R64_DEV bool hit_shape(const Scene& sc, const Shape& s, D o, D d, double t_min, Hit& rec) {
+// Shape::intersect of object i (Transformed::intersect around it when has_xf, src/shape.rs:128-138; Ray::apply_transform
+// does not renormalise the direction, so t is shared), updating the record as the reference does: a hit replaces it iff
+// its time is smaller.
+template <class RP, class TP>
+R64_DEV void eval_object(RP recs, TP trecs, uint32_t i, D o, D d, Query& q) {
+    const auto& r = recs[i];
+    const int32_t kind = r.kind;
     D ol = o, dl = d;
-    if (s.has_xf) {   // Ray::apply_transform, src/shape.rs:65-72 (direction not renormalised: t is shared)
-        ol = xf_point(s.inv, o);
-        dl = xf_dir(s.inv, d);
+    if (r.has_xf) {
+        ol = xf_point(r.inv, o);
+        dl = xf_dir(r.inv, d);
     }
-    bool h;
-    if (s.kind == SH_SPHERE) h = hit_sphere(ol, dl, t_min, rec);
-    else if (s.kind == SH_CUBE) h = hit_cube(ol, dl, t_min, rec);
-    else if (s.kind == SH_PLANE) h = hit_plane(s.plane, ol, dl, t_min, rec);
-    else h = hit_mesh(sc, s, ol, dl, t_min, rec);
-    if (h && s.has_xf) rec.normal = normalize(mul3(s.nrm, rec.normal));
-    return h;
-}
-// Renderer::get_closest_hit, src/renderer.rs:416-425
-R64_DEV int closest_hit(const Args& a, D o, D d, Hit& rec) {
-    const Scene& sc = a.sc;
-    rec.time = kInf;
-    rec.normal = mk(0, 0, 0);
-    int obj = -1;
-    for (uint32_t i = 0; i < sc.n_objects; i++)
-        if (hit_shape(sc, sc.objects[i].shape, o, d, kEps, rec)) obj = int(i);
-    if (a.counters) {
-        atomicAdd(&a.counters[0], 1ull);
-        if (obj >= 0) {
-            atomicAdd(&a.counters[1], 1ull);
-            const double m = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z));
-            if (rec.time < 1e-9 * (1.0 + m)) atomicAdd(&a.counters[2], 1ull);   // diagnostic: a hit on the surface the ray starts on
+    if (kind == SH_PLANE) {   // Plane::intersect, src/shape/plane.rs:17-32
+        const D n = ld(r.b);
+        const double cosine = dot(n, dl);
+        if (!(fabs(cosine) < 1e-8)) {
+            const double time = (r.b[3] - dot(n, ol)) / cosine;
+            if (time >= kEps && time < q.t) {
+                q.t = time;
+                q.obj = int32_t(i);
+                q.aux = (cosine > 0.0 || (cosine == 0.0 && !__builtin_signbit(cosine))) ? 0u : 1u;   // f64::signum of the cosine
+            }
+        }
+    } else if (kind == SH_SPHERE) {   // Sphere::intersect, src/shape/sphere.rs:14-46
+        const double a = dot(dl, dl), b = dot(dl, ol), c = dot(ol, ol) - 1.0;
+        double disc = b * b - a * c;
+        if (!__builtin_signbit(disc)) {
+            disc = sqrt(disc);
+            double t = (-b - disc) / a;
+            bool ok = true;
+            if (t < kEps) {
+                t = (-b + disc) / a;
+                ok = !(t < kEps);
+            }
+            if (ok && t < q.t) {
+                q.t = t;
+                q.obj = int32_t(i);
+                q.p = ol + t * dl;
+            }
+        }
+    } else {
+        // the six slab roots: Cube::intersect (src/shape/cube.rs:23-35, planes at -0.5 / 0.5) and BoundingBox::intersect of
+        // a mesh's bounds (src/kdtree.rs:56-71) are the same (plane - o) / d
+        const double x1 = (r.b[0] - ol.x) / dl.x, x2 = (r.b[3] - ol.x) / dl.x;
+        const double y1 = (r.b[1] - ol.y) / dl.y, y2 = (r.b[4] - ol.y) / dl.y;
+        const double z1 = (r.b[2] - ol.z) / dl.z, z2 = (r.b[5] - ol.z) / dl.z;
+        if (kind == SH_CUBE) {   // src/shape/cube.rs:36-74
+            const bool sx = x1 > x2, sy = y1 > y2, sz = z1 > z2;
+            const double lo0 = sx ? x2 : x1, hi0 = sx ? x1 : x2;
+            const double lo1 = sy ? y2 : y1, hi1 = sy ? y1 : y2;
+            const double lo2 = sz ? z2 : z1, hi2 = sz ? z1 : z2;
+            // the normal of an interval end: -1 along the axis for the -0.5 plane, +1 for the 0.5 plane (swapped with the roots)
+            const int as = (lo0 > lo1 && lo0 > lo2) ? 0 : (lo1 > lo2 ? 1 : 2);
+            const int ae = (hi0 < hi1 && hi0 < hi2) ? 0 : (hi1 < hi2 ? 1 : 2);
+            const double start = as == 0 ? lo0 : (as == 1 ? lo1 : lo2), end = ae == 0 ? hi0 : (ae == 1 ? hi1 : hi2);
+            if (!(start > end || end < kEps)) {
+                const bool use_end = start < kEps;
+                const double time = use_end ? end : start;
+                if (time < q.t) {
+                    const int ax = use_end ? ae : as;
+                    const bool swapped = ax == 0 ? sx : (ax == 1 ? sy : sz);
+                    const bool negative = use_end ? swapped : !swapped;   // start carries the lower root's normal (-1 unless swapped)
+                    q.t = time;
+                    q.obj = int32_t(i);
+                    q.aux = uint32_t(ax) | (negative ? 4u : 0u);
+                }
+            }
+        } else {
+            // `Mesh = KdTree<Triangle>` (src/shape/mesh.rs:106): KdTree::intersect rejects the ray against the tree's bounds
+            // (src/kdtree.rs:132-139; f64::min / max ignore a NaN operand like fmin / fmax), then finds the closest triangle.
+            // The kd-tree below the root is an acceleration structure: every triangle is tested here.
+            const double b_min = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmin(z1, z2));
+            const double b_max = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
+            if (!(fmax(b_min, kEps) > fmin(b_max, q.t))) {
+                for (uint32_t j = 0; j < r.tri_count; j++) {   // Triangle::intersect, src/shape/mesh.rs:50-83
+                    const auto& tr = trecs[r.tri_first + j];
+                    const D pn = ld(tr.pn), v1 = ld(tr.v1);
+                    const double cosine = dot(pn, dl);
+                    if (fabs(cosine) < 1e-8) continue;
+                    const double time = dot(pn, v1 - ol) / cosine;
+                    if (time < kEps || time >= q.t) continue;
+                    const D d2 = (ol + time * dl) - v1;
+                    const double d20 = dot(d2, ld(tr.d0)), d21 = dot(d2, ld(tr.d1));
+                    const double v = (tr.d11 * d20 - tr.d01 * d21) / tr.denom, w = (tr.d00 * d21 - tr.d01 * d20) / tr.denom;
+                    const double u = 1.0 - v - w;
+                    if (u >= 0.0 && v >= 0.0 && w >= 0.0) {
+                        q.t = time;
+                        q.obj = int32_t(i);
+                        q.aux = r.tri_first + j;
+                        q.p = mk(u, v, w);
+                    }
+                }
+            }
         }
     }
-    return obj;
+}
+
+// The fp32 box test that decides which objects a lane evaluates.  Conservative: boxes are padded at commit (1e-5 of
+// their extent and of their coordinates), the ray's origin error is covered by `eo`, and the slab interval is widened
+// by 4e-6 relative before it is compared -- three orders of magnitude above what fp32 rounding of the fp64 ray and of
+// the slab arithmetic can move it.  A NaN (0 * inf) compares false and keeps the object.
+R64_DEV uint32_t cull32(const CullBox* boxes, uint32_t base, uint32_t nb, float ox, float oy, float oz, float ix, float iy, float iz,
+                        float eo, float tlim) {
+    uint32_t mask = 0u;
+    for (uint32_t j = 0; j < nb; j++) {
+        const rptg::F4 lo = rptg::uload(reinterpret_cast<const rptg::F4*>(boxes + base + j));
+        const rptg::F4 hi = rptg::uload(reinterpret_cast<const rptg::F4*>(boxes + base + j) + 1);
+        if (__float_as_uint(lo.w) != 0u) {   // unbounded (a plane): always evaluated
+            mask |= 1u << j;
+            continue;
+        }
+        const float x1 = (lo.x - eo - ox) * ix, x2 = (hi.x + eo - ox) * ix;
+        const float y1 = (lo.y - eo - oy) * iy, y2 = (hi.y + eo - oy) * iy;
+        const float z1 = (lo.z - eo - oz) * iz, z2 = (hi.z + eo - oz) * iz;
+        const float tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+        const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+        const float tn_lo = tn - 4e-6f * fabsf(tn), tf_hi = tf + 4e-6f * fabsf(tf);
+        const bool out = tn_lo > tf_hi || tf_hi < 0.f || tn_lo > tlim;
+        if (!out) mask |= 1u << j;
+    }
+    return mask;
+}
+
+// Renderer::get_closest_hit, src/renderer.rs:416-425, into a record the caller has reset.  `tlim`: hits beyond it do not
+// matter to the caller (+inf: all do).
+template <bool COUNT, class RP, class TP>
+R64_DEV void closest_hit(RP recs, TP trecs, D o, D d, double tlim, Query& q, uint32_t& c_evals, uint32_t& c_rounds) {
+    const uint32_t n = KA.sc.n_objects;
+    const bool cull = KA.cull != 0u;
+    const float ox = float(o.x), oy = float(o.y), oz = float(o.z);
+    const float ix = __builtin_amdgcn_rcpf(float(d.x)), iy = __builtin_amdgcn_rcpf(float(d.y)), iz = __builtin_amdgcn_rcpf(float(d.z));
+    const float eo = 1e-6f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+    const float tl = float(tlim) * 1.00001f;
+    for (uint32_t base = 0; base < n; base += 32u) {
+        const uint32_t nb = min(32u, n - base);
+        uint32_t mask = nb == 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+        if (cull) mask = cull32(KA.sc.cull, base, nb, ox, oy, oz, ix, iy, iz, eo, tl);
+        while (__ballot(mask != 0u) != 0ull) {
+            if (COUNT && mbcnt64(__ballot(true)) == 0u) c_rounds++;
+            if (mask != 0u) {
+                const uint32_t j = uint32_t(__builtin_ctz(mask));
+                mask &= mask - 1u;
+                if (COUNT) c_evals++;
+                eval_object(recs, trecs, base + j, o, d, q);
+            }
+        }
+    }
+}
+
+// The winner's world-space normal: what each Shape::intersect stores in the record, then Transformed::intersect's
+// normalize(normal_transform * n) (src/shape.rs:135-136).
+template <class RP>
+R64_DEV D hit_normal(RP recs, const Query& q) {
+    const auto& r = recs[q.obj];
+    D n;
+    if (r.kind == SH_CUBE) {
+        const double sg = (q.aux & 4u) ? -1.0 : 1.0;
+        const uint32_t ax = q.aux & 3u;
+        n = mk(ax == 0u ? sg : 0.0, ax == 1u ? sg : 0.0, ax == 2u ? sg : 0.0);
+    } else if (r.kind == SH_SPHERE) {
+        n = normalize(q.p);
+    } else if (r.kind == SH_PLANE) {
+        n = -(normalize(ld(r.b))) * (q.aux ? -1.0 : 1.0);
+    } else {
+        const TriShade& ts = KA.sc.tshade[q.aux];
+        n = normalize(q.p.x * ld(ts.n1) + q.p.y * ld(ts.n2) + q.p.z * ld(ts.n3));
+    }
+    if (r.has_xf) n = normalize(mul3(KA.sc.shade[q.obj].nrm, n));
+    return n;
 }
 
 // ---------------------------------------------------------------------------- Shape::sample
-// of the unit shapes / a mesh in the shape's own space: point v, normal n, pdf p
-R64_DEV void sample_local(const Scene& sc, const Shape& s, D target, Rng64& rng, D& v, D& n, double& p) {
+// of the unit shapes / a mesh in the shape's own space: point v, normal n, pdf p.  `s` is a light's shape: wave-uniform.
+template <class S>
+R64_DEV void sample_local(const S& s, D target, Rng64& rng, D& v, D& n, double& p) {
     if (s.kind == SH_SPHERE) {   // src/shape/sphere.rs:53-65
         double x, y;
         rng.unit_disc(x, y);
@@ -233,27 +299,29 @@ R64_DEV void sample_local(const Scene& sc, const Shape& s, D target, Rng64& rng,
         }
         p = 1.0 / 6.0;
     } else {   // KdTree::sample, src/kdtree.rs:141-146, over Triangle::sample, src/shape/mesh.rs:85-99
-        const uint32_t idx = rng.index(s.tri_count);
-        const Tri& tr = sc.tris[s.tri_first + idx];
-        double u = rng.uniform(), vv = rng.uniform();
-        while (u + vv > 1.0) {
-            u = rng.uniform();
-            vv = rng.uniform();
+        const uint32_t idx = s.tri_first + rng.index(s.tri_count);
+        // `while u + v > 1 { redraw }`: with u = (2k+1) 2^-24 the sum is exact and u + v > 1 <=> ku + kv >= 2^23, so a
+        // rejected pair is never converted (same draws)
+        uint32_t ku = rng.r.next() >> 9, kv = rng.r.next() >> 9;
+        while (ku + kv >= (1u << 23)) {
+            ku = rng.r.next() >> 9;
+            kv = rng.r.next() >> 9;
         }
+        const double u = double((ku << 1) | 1u) * 0x1p-24, vv = double((kv << 1) | 1u) * 0x1p-24;
         const double w = 1.0 - u - vv;
-        const D v1 = ld(tr.v1), v2 = ld(tr.v2), v3 = ld(tr.v3);
-        const double area = 0.5 * length(cross(v2 - v1, v3 - v1));
-        v = u * v1 + vv * v2 + w * v3;
+        const Tri& tr = KA.sc.tris[idx];
+        v = u * ld(tr.v1) + vv * ld(tr.v2) + w * ld(tr.v3);
         n = normalize(u * ld(tr.n1) + vv * ld(tr.n2) + w * ld(tr.n3));
-        p = (1.0 / area) / double(s.tri_count);
+        p = KA.sc.tri_pdf[idx];   // (1 / area) / len, area = 0.5 |(v2 - v1) x (v3 - v1)|: the triangle's alone, evaluated at commit
     }
 }
-R64_DEV void sample_shape(const Scene& sc, const Shape& s, D target, Rng64& rng, D& v, D& n, double& p) {
-    if (!s.has_xf) return sample_local(sc, s, target, rng, v, n, p);
+template <class S>
+R64_DEV void sample_shape(const S& s, D target, Rng64& rng, D& v, D& n, double& p) {
+    if (!s.has_xf) return sample_local(s, target, rng, v, n, p);
     // Transformed::sample, src/shape.rs:140-151
     D vl, nl;
     double pl;
-    sample_local(sc, s, xf_point(s.inv, target), rng, vl, nl, pl);
+    sample_local(s, xf_point(s.inv, target), rng, vl, nl, pl);
     const D new_normal = normalize(mul3(s.nrm, nl));
     const double height = dot(mul3(s.lin, nl), new_normal);
     const double base = s.det / height;
@@ -262,18 +330,18 @@ R64_DEV void sample_shape(const Scene& sc, const Shape& s, D target, Rng64& rng,
     p = pl / base;
 }
 // Light::illuminate for Light::Object, src/light.rs:34-45
-R64_DEV void illuminate_object(const Scene& sc, const Light& L, D pos, Rng64& rng, D& intensity, D& wi, double& dist) {
+template <class LT>
+R64_DEV void illuminate_object(const LT& L, D pos, Rng64& rng, D& intensity, D& wi, double& dist) {
     D v, n;
     double p;
-    sample_shape(sc, L.obj.shape, pos, rng, v, n, p);
+    sample_shape(L.shape, pos, rng, v, n, p);
     const D disp = v - pos;
     const double len = length(disp);
     const double cosine = fmax(-dot(disp, n), 0.0) / len;
     const double surface_area = fmax(cosine, 0.0) / (len * len);
-    const Mat& m = L.obj.mat;
-    const bool has_color = m.kind <= 1;   // Material::color / emittance, src/material.rs:99-113
-    const D col = has_color ? ld(m.albedo) : mk(0, 0, 0);
-    const double emit = has_color ? m.emittance : 0.0;
+    const bool has_color = L.mat.kind <= 1;   // Material::color / emittance, src/material.rs:99-113
+    const D col = has_color ? ld(L.mat.albedo) : mk(0, 0, 0);
+    const double emit = has_color ? L.mat.emittance : 0.0;
     intensity = ((col * emit) * surface_area) / p;
     wi = disp / len;
     dist = len;
@@ -356,8 +424,14 @@ R64_DEV D bsdf(const Mat& m, D n, D wo, D wi) {
 }
 
 // ---------------------------------------------------------------------------- the path
+// Medium::color (src/medium.rs:80-122): hex_color(0xD2B48C) for homogeneous_isotropic; blue below / red above y = 250 for
+// colored_glowing_fog (the host passes the colours, src/color.rs:10-15 evaluated in fp64)
+R64_DEV D medium_color(D pos) {
+    return (KA.sc.medium_kind == 1 && pos.y > 250.0) ? ld(KA.medium_color_hi) : ld(KA.medium_color);
+}
 // Camera::cast_ray, src/camera.rs:65-82
-R64_DEV void cast_ray(const Camera& c, double x, double y, Rng64& rng, D& o, D& d) {
+template <class CP>
+R64_DEV void cast_ray(const CP& c, double x, double y, Rng64& rng, D& o, D& d) {
     const D right = ld(c.right), up = ld(c.up);
     o = ld(c.eye);
     D nd = c.d * ld(c.direction) + x * right + y * up;
@@ -370,146 +444,340 @@ R64_DEV void cast_ray(const Camera& c, double x, double y, Rng64& rng, D& o, D& 
     }
     d = normalize(nd);
 }
-// The shadow test of sample_lights / sample_lights_for_media (src/renderer.rs:339-348, 386-396)
-R64_DEV bool light_visible(const Args& a, D pos, D wi, double dist) {
-    Hit h;
-    const int obj = closest_hit(a, pos, wi, h);
-    if (a.counters) atomicAdd(&a.counters[3], 1ull);
-    if (obj < 0) return false;
-    const double miss = fabs(h.time - dist);
-    if (a.counters) {
-        if (miss < kEps) atomicAdd(&a.counters[4], 1ull);
-        else if (miss < 1e-6 * dist) atomicAdd(&a.counters[5], 1ull);   // diagnostic: the light's own surface, missed by rounding
+
+// LDS of a block, in doubles: [kColsD columns of 256: acc, P, Q, R][kColsU / 2 columns' worth of dword columns: slab slot,
+// sample, end, pixel][ObjRec x kLdsObjs][TriRec x kLdsTris]
+static constexpr uint32_t kColsD = 12u, kColsU = 4u;
+static constexpr uint32_t kTabBase = (kColsD + kColsU / 2u) * 256u;
+static constexpr uint32_t kObjDoubles = sizeof(ObjRec) / 8u, kTriDoubles = sizeof(TriRec) / 8u;
+static constexpr uint32_t kLdsDoubles = kTabBase + kLdsObjs * kObjDoubles + kLdsTris * kTriDoubles;
+static_assert(sizeof(ObjRec) == 160 && sizeof(TriRec) == 128 && sizeof(CullBox) == 32, "record sizes");
+static_assert(kLdsDoubles * 8u * 4u <= 160u * 1024u, "four blocks per CU");
+
+template <bool MEDIUM, bool COUNT, bool LDSTAB>
+__global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a_by_value) {
+    (void)a_by_value;   // (read through KA)
+    extern __shared__ double lds64[];
+    double* const cd = lds64 + threadIdx.x;                                                    // [column * 256]
+    uint32_t* const cu = reinterpret_cast<uint32_t*>(lds64 + kColsD * 256u) + threadIdx.x;    // [column * 256]
+    enum { C_ACC = 0, C_P = 3, C_Q = 6, C_R = 9 };
+    enum { U_SLAB = 0, U_S = 1, U_END = 2, U_XY = 3 };
+    const ObjRec* recs = KA.sc.recs;
+    const TriRec* trecs = KA.sc.trecs;
+    if constexpr (LDSTAB) {
+        double* const t0 = lds64 + kTabBase;
+        const double* const g0 = reinterpret_cast<const double*>(KA.sc.recs);
+        const double* const g1 = reinterpret_cast<const double*>(KA.sc.trecs);
+        const uint32_t n0 = KA.sc.n_objects * kObjDoubles, n1 = KA.sc.n_obj_tris * kTriDoubles;
+        for (uint32_t i = threadIdx.x; i < n0; i += 256u) t0[i] = g0[i];
+        for (uint32_t i = threadIdx.x; i < n1; i += 256u) t0[kLdsObjs * kObjDoubles + i] = g1[i];
+        __syncthreads();
+        recs = reinterpret_cast<const ObjRec*>(t0);
+        trecs = reinterpret_cast<const TriRec*>(t0 + kLdsObjs * kObjDoubles);
     }
-    return miss < kEps;
-}
+    auto ldD = [&](int c) { return mk(cd[c * 256], cd[(c + 1) * 256], cd[(c + 2) * 256]); };
+    auto stD = [&](int c, D v) { cd[c * 256] = v.x; cd[(c + 1) * 256] = v.y; cd[(c + 2) * 256] = v.z; };
 
-// Medium::color (src/medium.rs:80-122): hex_color(0xD2B48C) for homogeneous_isotropic; blue below / red above y = 250 for
-// colored_glowing_fog.  The host passes the two colours (color.rs:10-15 evaluated in fp64).
-R64_DEV D medium_color(const Args& a, D pos) {
-    return (a.sc.medium_kind == 1 && pos.y > 250.0) ? ld(a.medium_color_hi) : ld(a.medium_color);
-}
+    Rng64 rng;
+    rng.r.s0 = rng.r.s1 = rng.r.s2 = rng.r.s3 = 0;
+    D ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+    uint32_t depth = 0;
+    bool alive = true, have_item = false, need_path = true, item_done = true;
+    bool drained = false, first_batch = true;                                   // wave-uniform
+    uint32_t pool_next = 0, pool_end = 0, pool_chunk = 0, pool_x0 = 0, pool_y0 = 0;   // wave-uniform: the batch of work items at hand
+    uint32_t c_rays = 0, c_hits = 0, c_self = 0, c_shadow = 0, c_pass = 0, c_near = 0, c_samples = 0, c_vertices = 0, c_evals = 0,
+             c_rounds = 0, c_trips = 0, c_live = 0;
 
-__global__ __launch_bounds__(256) void render_f64_kernel(const Args a) {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= a.n_owned) return;
-    const uint32_t tile = a.tiles[p >> 10], within = p & 1023u;
-    const uint32_t ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const uint32_t x = tx * 32u + (within & 31u), y = ty * 32u + (within >> 5);
-    if (x >= a.width || y >= a.height) return;
-    const Scene& sc = a.sc;
-    const bool medium = sc.has_medium != 0;
-    // src/renderer.rs:174-176 (2 * x + 1 and 2 * (h - y) - 1 in u32, like the reference)
-    const double xn = (double(2u * x + 1u) - double(a.width)) / a.dim;
-    const double yn = (double(2u * (a.height - y) - 1u) - double(a.height)) / a.dim;
-    D color = mk(0, 0, 0);
-    for (uint32_t s = 0; s < a.iterations; s++) {
-        Rng64 rng;
-        rng.r.seed(a.seed_mixed, y * a.width + x, a.sample_offset + s);
-        const double dx = rng.range(-1.0 / a.dim, 1.0 / a.dim);
-        const double dy = rng.range(-1.0 / a.dim, 1.0 / a.dim);
-        D ro, rd;
-        cast_ray(a.cam, xn + dx, yn + dy, rng, ro, rd);
-        if (a.counters) atomicAdd(&a.counters[6], 1ull);
-        // trace_ray (src/renderer.rs:187-322) as a loop: the radiance of the path = min(P + Q x, R) per channel, x = what the
-        // rest of the path returns (closed under x -> E + min(k x, 100), :308-313; in a medium there is no clamp, R = inf)
-        D P = mk(0, 0, 0), Q = mk(1, 1, 1), R = mk(kInf, kInf, kInf);
-        uint32_t depth = 0;
-        for (;;) {
-            if (a.counters) atomicAdd(&a.counters[7], 1ull);
-            double dmed = kInf;
-            if (medium) dmed = -log(rng.range(0.0, 1.0)) / (sc.absorption + sc.scattering);   // Medium::sample_d, src/medium.rs:133-146
-            const D wo = -normalize(rd);
-            Hit h;
-            const int obj = closest_hit(a, ro, rd, h);
-            const bool hit = obj >= 0;
-            const bool ev_medium = medium && dmed < (hit ? h.time : 400.0);   // :197-243 (`d >= h.time` is a surface event)
-            if (!ev_medium && !hit) {   // :198-206 (in a medium the background counts only beyond 400), :288
-                const D env = (!medium || dmed >= 400.0) ? ld(sc.env) : mk(0, 0, 0);
-                color = color + vmin(P + Q * env, R);
-                break;
+    for (;;) {
+        // ---- work distribution (wave-convergent), as in the fp32 megakernel: a wave draws batches of 64 items -- one 8 x 8
+        // pixel block of one chunk -- from the global counter with one atomic and hands them to the lanes that finished
+        // theirs through a ballot / mbcnt prefix
+        bool want = alive && need_path && item_done;
+        const uint32_t n_want = uint32_t(__popcll(__ballot(want)));
+        if (n_want != 0u && (n_want >= KA.pull_batch || __ballot(alive && !want) == 0ull)) {
+            const auto& ka = KA;
+            if (want && have_item) {
+                double* const sl = ka.slab + size_t(cu[U_SLAB * 256]) * 4u;
+                const D acc = ldD(C_ACC);
+                reinterpret_cast<double2*>(sl)[0] = make_double2(acc.x, acc.y);
+                reinterpret_cast<double2*>(sl)[1] = make_double2(acc.z, 0.0);
+                have_item = false;
             }
-            D E, k = mk(0, 0, 0), pos, wi_next = mk(0, 0, 1);
-            bool cont = false;
-            if (ev_medium) {   // :243-283
-                pos = ro + dmed * rd;
-                const D mcol = medium_color(a, pos);
-                const double scat = sc.scattering, extinction = sc.absorption + sc.scattering;
-                const double emm = sc.medium_kind == 1 ? 10.0 : 0.0;
-                const double phase = sc.medium_kind == 1 ? 1.0 / 4.0 * kPi : 1.0 / (4.0 * kPi);   // (sic, src/medium.rs:113)
-                E = depth == 0 ? emm * mcol : mk(0, 0, 0);
-                // sample_lights_for_media, :325-359
-                for (uint32_t li = 0; li < sc.n_lights; li++) {
-                    const Light& L = sc.lights[li];
-                    if (L.kind == LT_AMBIENT) {
-                        E = E + ld(L.color) * mcol;
-                    } else if (L.kind == LT_OBJECT) {
-                        D I, wi;
-                        double dist;
-                        illuminate_object(sc, L, pos, rng, I, wi, dist);
-                        if (light_visible(a, pos, wi, dist)) E = E + ((scat / extinction) * (I * mcol)) * phase;
+            for (;;) {
+                const uint64_t m = __ballot(want);
+                if (m == 0) break;
+                if (pool_next == pool_end) {
+                    unsigned long long base = ~0ull;
+                    if (first_batch) {   // a wave's first batch is its own index (the host starts the counter behind them)
+                        base = (unsigned long long)(blockIdx.x * 4u + (threadIdx.x >> 6)) * 64ull;
+                        first_batch = false;
+                    } else if (!drained && (threadIdx.x & 63u) == 0) {
+                        base = atomicAdd(ka.queue, 64ull);
                     }
-                    // Point / Directional: illuminate draws nothing and the test |hit - dist| < 1e-12 can never pass
-                    // (dist = the light's position / +inf, src/light.rs:26-33)
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(base));
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(base >> 32));
+                    if (hi != 0 || lo >= ka.n_items) {
+                        drained = true;   // queue exhausted: the waiting lanes retire
+                        if (want) alive = false;
+                        break;
+                    }
+                    pool_next = lo;
+                    pool_end = min(lo + 64u, ka.n_items);
+                    pool_chunk = lo / ka.n_owned;
+                    const uint32_t p0 = lo - pool_chunk * ka.n_owned;
+                    const uint32_t tile = ka.tiles[p0 >> 10], sb = (p0 & 1023u) >> 6;
+                    const uint32_t ty = tile / ka.tiles_x, tx = tile - ty * ka.tiles_x;
+                    pool_x0 = __builtin_amdgcn_readfirstlane(tx * 32u + (sb & 3u) * 8u);
+                    pool_y0 = __builtin_amdgcn_readfirstlane(ty * 32u + (sb >> 2) * 8u);
+                    pool_chunk = __builtin_amdgcn_readfirstlane(pool_chunk);
                 }
-                if (rng.uniform() < 0.8) {   // :262-281
-                    const double ax = rng.range(-1.0, 1.0), ay = rng.range(-1.0, 1.0), az = rng.range(-1.0, 1.0);
-                    wi_next = normalize(mk(ax, ay, az));   // Medium::sample_ph, src/medium.rs:87-93
-                    k = ((((scat / extinction) / phase) * mcol) * phase) / 0.8;   // (scat/ext) x / ph_p . color * phase / rr_p, ph_p == phase
+                const uint32_t take = min(uint32_t(__popcll(m)), pool_end - pool_next);
+                const uint32_t rank = mbcnt64(m);
+                const uint32_t item = pool_next + rank;
+                const bool got = want && rank < take;
+                pool_next += take;
+                if (got) {
+                    const uint32_t l = item & 63u;
+                    const uint32_t x = pool_x0 + (l & 7u), y = pool_y0 + (l >> 3);
+                    if (x < ka.width && y < ka.height) {   // slots of clipped tiles lie outside the image
+                        want = false;
+                        have_item = true;
+                        item_done = false;
+                        cu[U_SLAB * 256] = item;
+                        stD(C_ACC, mk(0, 0, 0));
+                        const uint32_t s0 = pool_chunk * ka.chunk_spp;
+                        cu[U_S * 256] = s0;
+                        cu[U_END * 256] = min(s0 + ka.chunk_spp, ka.iterations);
+                        cu[U_XY * 256] = x | (y << 16);
+                    }
+                }
+            }
+        }
+        if (need_path && alive && !item_done) {   // the item's next sample: src/renderer.rs:174-181
+            const auto& ka = KA;
+            const uint32_t s = cu[U_S * 256], xy = cu[U_XY * 256], x = xy & 0xFFFFu, y = xy >> 16;
+            rng.r.seed(ka.seed_mixed, y * ka.width + x, ka.sample_offset + s);
+            // (2 * x + 1 and 2 * (h - y) - 1 in u32, like the reference)
+            const double dim = ka.dim;
+            const double xn = (double(2u * x + 1u) - double(ka.width)) / dim;
+            const double yn = (double(2u * (ka.height - y) - 1u) - double(ka.height)) / dim;
+            const double dx = rng.range(-1.0 / dim, 1.0 / dim);
+            const double dy = rng.range(-1.0 / dim, 1.0 / dim);
+            cast_ray(ka.cam, xn + dx, yn + dy, rng, ro, rd);
+            depth = 0;
+            stD(C_P, mk(0, 0, 0));
+            stD(C_Q, mk(1, 1, 1));
+            if (!MEDIUM) stD(C_R, mk(kInf, kInf, kInf));
+            cu[U_S * 256] = s + 1u;
+            item_done = s + 1u >= cu[U_END * 256];
+            need_path = false;
+            if (COUNT) c_samples++;
+        }
+        if (__ballot(alive) == 0ull) break;
+        if (COUNT) {
+            if (mbcnt64(__ballot(true)) == 0u) c_trips++;
+            if (alive && !need_path) c_live++;
+        }
+        if (!alive || need_path) continue;   // (a lane without a path waits for the wave's next item hand-out)
+
+        // ---- one path vertex = one trace_ray invocation (src/renderer.rs:187-322).  The radiance of the path is
+        // min(P + Q x, R) per channel, x = what the rest of the path returns (closed under x -> E + min(k x, 100), :308-313;
+        // in a medium there is no clamp, R = inf).
+        // The vertex's closest-hit queries -- the path's own, then one per object light -- go through ONE copy of the query
+        // code: `sub` counts them, wave-uniformly.
+        if (COUNT) c_vertices++;
+        const double sigma_t = KA.sc.absorption + KA.sc.scattering;
+        double dmed = kInf;
+        if (MEDIUM) dmed = -log(rng.range(0.0, 1.0)) / sigma_t;   // Medium::sample_d, src/medium.rs:133-146
+        const bool cull = KA.cull != 0u;
+        // A hit beyond the sampled distance cannot change the event (dmed < t, or a miss with dmed < 400, is a medium event
+        // either way, :197-243): the search may end there.  (The counters build searches everything: its counts are the
+        // reference's.)
+        // the query at hand: origin ro (the vertex once the event is known), direction rd (towards the light sample for a
+        // shadow query), and the distance beyond which hits do not matter
+        double qlim = (MEDIUM && !COUNT && cull && dmed < 400.0) ? dmed : kInf;
+        D E = mk(0, 0, 0), T = mk(0, 0, 0), n = mk(0, 1, 0), wo = mk(0, 0, 0);
+        double dist = 0.0;
+        int32_t hobj = -1;          // the object of a surface event
+        bool ev_medium = false;
+        bool active = true;         // false: the path ended at this vertex without an event (miss)
+        uint32_t li = 0;            // wave-uniform: next light to look at
+        const uint32_t n_lights = KA.sc.n_lights;
+        for (uint32_t sub = 0;; sub++) {
+            Query q;
+            q.t = kInf; q.obj = -1; q.aux = 0u; q.p = mk(0, 0, 0);
+            if (active) closest_hit<COUNT>(recs, trecs, ro, rd, qlim, q, c_evals, c_rounds);
+            if (sub == 0) {
+                const bool hit = q.obj >= 0;
+                if (COUNT) {
+                    c_rays++;
+                    if (hit) {
+                        c_hits++;
+                        const double m = fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z));
+                        if (q.t < 1e-9 * (1.0 + m)) c_self++;   // diagnostic: a hit on the surface the ray starts on
+                    }
+                }
+                ev_medium = MEDIUM && dmed < (hit ? q.t : 400.0);   // :197-243 (`d >= h.time` is a surface event)
+                if (!ev_medium && !hit) {   // :198-206 (in a medium the background counts only beyond 400), :288
+                    const D env = (!MEDIUM || dmed >= 400.0) ? ld(KA.sc.env) : mk(0, 0, 0);
+                    const D v = ldD(C_P) + ldD(C_Q) * env;
+                    stD(C_ACC, ldD(C_ACC) + (MEDIUM ? v : vmin(v, ldD(C_R))));
+                    need_path = true;
+                    active = false;
+                } else if (ev_medium) {   // :243-255
+                    ro = ro + dmed * rd;
+                    const double emm = KA.sc.medium_kind == 1 ? 10.0 : 0.0;
+                    E = depth == 0 ? emm * medium_color(ro) : mk(0, 0, 0);
+                } else {   // surface event: :207-216 in a medium, :289-299 without
+                    ro = ro + q.t * rd;
+                    hobj = q.obj;
+                    n = hit_normal(recs, q);
+                    wo = -normalize(rd);
+                    const Mat& mat = KA.sc.shade[hobj].mat;
+                    E = depth == 0 ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
+                }
+            } else {
+                // the shadow test (:339-348, :386-396): the closest hit along wi lies at the sampled distance
+                const double miss = fabs(q.t - dist);
+                const bool visible = active && q.obj >= 0 && miss < kEps;
+                if (COUNT && active) {
+                    c_rays++;
+                    c_shadow++;
+                    if (q.obj >= 0) {
+                        c_hits++;
+                        const double m = fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z));
+                        if (q.t < 1e-9 * (1.0 + m)) c_self++;
+                        if (miss < kEps) c_pass++;
+                        else if (miss < 1e-6 * dist) c_near++;   // diagnostic: the light's own surface, missed by rounding
+                    }
+                }
+                if (visible) E = E + T;
+            }
+            // sample_lights_for_media :325-359 / sample_lights :362-409; lights in scene order fix the draw order.  Ambient
+            // lights add their term; the next object light is sampled and its shadow query becomes the query at hand.
+            bool more = false;
+            while (li < n_lights) {
+                const auto& L = uniform_ref(&KA.sc.lights[li]);
+                li++;
+                if (L.kind == LT_AMBIENT) {
+                    if (active) E = E + ld(L.color) * (ev_medium ? medium_color(ro) : mat_color(KA.sc.shade[hobj < 0 ? 0 : hobj].mat));
+                } else if (L.kind == LT_OBJECT) {
+                    if (active) {
+                        D I, wi;
+                        illuminate_object(L, ro, rng, I, wi, dist);
+                        // the light's term of E if it proves visible
+                        if (ev_medium) {
+                            const double scat = KA.sc.scattering;
+                            const double phase = KA.sc.medium_kind == 1 ? 1.0 / 4.0 * kPi : 1.0 / (4.0 * kPi);   // (sic, src/medium.rs:113)
+                            T = ((scat / sigma_t) * (I * medium_color(ro))) * phase;
+                        } else {
+                            T = (bsdf(KA.sc.shade[hobj].mat, n, wo, wi) * I) * dot(wi, n);
+                        }
+                        rd = wi;
+                        qlim = (COUNT || !cull) ? kInf : dist;
+                    }
+                    more = true;
+                    break;
+                }
+                // Point / Directional: illuminate draws nothing and the test |hit - dist| < 1e-12 can never pass
+                // (dist = the light's position / +inf, src/light.rs:26-33)
+            }
+            if (!more || __ballot(active) == 0ull) break;
+        }
+        if (!active) continue;
+
+        D k = mk(0, 0, 0), wi_next = mk(0, 0, 1);
+        bool cont = false;
+        if (ev_medium) {   // :262-281
+            if (rng.uniform() < 0.8) {
+                const double ax = rng.range(-1.0, 1.0), ay = rng.range(-1.0, 1.0), az = rng.range(-1.0, 1.0);
+                wi_next = normalize(mk(ax, ay, az));   // Medium::sample_ph, src/medium.rs:87-93
+                const double scat = KA.sc.scattering;
+                const double phase = KA.sc.medium_kind == 1 ? 1.0 / 4.0 * kPi : 1.0 / (4.0 * kPi);
+                k = ((((scat / sigma_t) / phase) * medium_color(ro)) * phase) / 0.8;   // (scat/ext) x / ph_p . color * phase / rr_p, ph_p == phase
+                cont = true;
+            }
+        } else {
+            const bool go = MEDIUM ? (rng.uniform() < 0.8) : (depth < KA.max_bounces);   // :222 / :301
+            if (go) {
+                double pdf;
+                const Mat& mat = KA.sc.shade[hobj].mat;
+                if (sample_f(mat, n, wo, rng, wi_next, pdf)) {
+                    const D f = bsdf(mat, n, wo, wi_next);
+                    k = ((1.0 / (MEDIUM ? pdf * 0.8 : pdf)) * f) * fabs(dot(wi_next, n));
                     cont = true;
                 }
-            } else {   // surface event: :207-237 in a medium, :289-318 without
-                pos = ro + h.time * rd;
-                const Mat& mat = sc.objects[obj].mat;
-                const D n = h.normal;
-                E = depth == 0 ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
-                // sample_lights, :362-409
-                for (uint32_t li = 0; li < sc.n_lights; li++) {
-                    const Light& L = sc.lights[li];
-                    if (L.kind == LT_AMBIENT) {
-                        E = E + ld(L.color) * mat_color(mat);
-                    } else if (L.kind == LT_OBJECT) {
-                        D I, wi;
-                        double dist;
-                        illuminate_object(sc, L, pos, rng, I, wi, dist);
-                        if (light_visible(a, pos, wi, dist)) E = E + (bsdf(mat, n, wo, wi) * I) * dot(wi, n);
-                    }
-                }
-                const bool go = medium ? (rng.uniform() < 0.8) : (depth < a.max_bounces);   // :222 / :301
-                if (go) {
-                    double pdf;
-                    if (sample_f(mat, n, wo, rng, wi_next, pdf)) {
-                        const D f = bsdf(mat, n, wo, wi_next);
-                        k = ((1.0 / (medium ? pdf * 0.8 : pdf)) * f) * fabs(dot(wi_next, n));
-                        cont = true;
-                    }
-                }
             }
-            P = P + Q * E;
-            if (!cont) {   // (a path whose weight has become zero goes on, as the reference's recursion does: same rays, same draws)
-                color = color + vmin(P, R);
-                break;
-            }
-            if (!medium) R = vmin(R, P + kFireflyClamp * Q);   // FIREFLY_CLAMP, :311-313
-            Q = Q * k;
-            ro = pos;
-            rd = wi_next;
-            depth++;
         }
+        const D Q = ldD(C_Q);
+        const D P = ldD(C_P) + Q * E;
+        if (!cont) {   // (a path whose weight has become zero goes on, as the reference's recursion does: same rays, same draws)
+            stD(C_ACC, ldD(C_ACC) + (MEDIUM ? P : vmin(P, ldD(C_R))));
+            need_path = true;
+            continue;
+        }
+        stD(C_P, P);
+        if (!MEDIUM) stD(C_R, vmin(ldD(C_R), P + kFireflyClamp * Q));   // FIREFLY_CLAMP, :311-313
+        stD(C_Q, Q * k);
+        rd = wi_next;   // (ro is the vertex already)
+        depth++;
+    }
+    if (COUNT) {
+        const uint32_t v[12] = {c_rays, c_hits, c_self, c_shadow, c_pass, c_near, c_samples, c_vertices, c_evals, c_rounds, c_trips, c_live};
+        for (int i = 0; i < 12; i++)
+            if (v[i]) atomicAdd(&KA.counters[i], (unsigned long long)v[i]);
+    }
+}
+
+// The frame from the slab: a pixel's chunk sums added in chunk order, / iterations * 2^EV (src/renderer.rs:183).
+__global__ __launch_bounds__(256) void resolve_f64_kernel(const Args a, double scale, double* __restrict__ out) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= a.n_owned) return;
+    const uint32_t tl = p >> 10, within = p & 1023u, sb = within >> 6, l = within & 63u;
+    const uint32_t tile = a.tiles[tl], ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const uint32_t x = tx * 32u + (sb & 3u) * 8u + (l & 7u), y = ty * 32u + (sb >> 2) * 8u + (l >> 3);
+    if (x >= a.width || y >= a.height) return;
+    double r = 0.0, g = 0.0, b = 0.0;
+    for (uint32_t c = 0; c < a.n_chunks; c++) {
+        const double2* const sl = reinterpret_cast<const double2*>(a.slab + (size_t(c) * a.n_owned + p) * 4u);
+        const double2 v0 = sl[0], v1 = sl[1];
+        r += v0.x;
+        g += v0.y;
+        b += v1.x;
     }
     const size_t o = (size_t(y) * a.width + x) * 3;
-    const double inv = a.scale / double(a.iterations);   // color / iterations * 2^EV, :183
-    a.out[o] = color.x * inv;
-    a.out[o + 1] = color.y * inv;
-    a.out[o + 2] = color.z * inv;
+    const double inv = scale / double(a.iterations);
+    out[o] = r * inv;
+    out[o + 1] = g * inv;
+    out[o + 2] = b * inv;
 }
 
 }  // namespace rpt64
 
 namespace rptg {
-hipError_t launch_render_f64(const rpt64::Args& a, hipStream_t stream) {
-    if (!a.n_owned) return hipSuccess;
-    hipLaunchKernelGGL(rpt64::render_f64_kernel, dim3((a.n_owned + 255u) / 256u), dim3(256), 0, stream, a);
+template <bool M, bool C>
+static hipError_t launch_f64_t(const rpt64::Args& a, int n_blocks, hipStream_t stream) {
+    const size_t lds = size_t(rpt64::kLdsDoubles) * 8u;
+    if (a.sc.n_objects <= rpt64::kLdsObjs && a.sc.n_obj_tris <= rpt64::kLdsTris)
+        hipLaunchKernelGGL((rpt64::render_f64_kernel<M, C, true>), dim3(n_blocks), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((rpt64::render_f64_kernel<M, C, false>), dim3(n_blocks), dim3(256), lds, stream, a);
     return hipGetLastError();
+}
+hipError_t launch_render_f64(const rpt64::Args& a, int n_blocks, hipStream_t stream) {
+    if (!a.n_items) return hipSuccess;
+    const bool m = a.sc.has_medium != 0, c = a.counters != nullptr;
+    if (m) return c ? launch_f64_t<true, true>(a, n_blocks, stream) : launch_f64_t<true, false>(a, n_blocks, stream);
+    return c ? launch_f64_t<false, true>(a, n_blocks, stream) : launch_f64_t<false, false>(a, n_blocks, stream);
+}
+hipError_t launch_resolve_f64(const rpt64::Args& a, double scale, double* d_out, hipStream_t stream) {
+    if (!a.n_owned) return hipSuccess;
+    hipLaunchKernelGGL(rpt64::resolve_f64_kernel, dim3((a.n_owned + 255u) / 256u), dim3(256), 0, stream, a, scale, d_out);
+    return hipGetLastError();
+}
+hipError_t render_f64_occupancy(bool medium, int* blocks_per_cu) {
+    const size_t lds = size_t(rpt64::kLdsDoubles) * 8u;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        blocks_per_cu, medium ? (const void*)rpt64::render_f64_kernel<true, false, true> : (const void*)rpt64::render_f64_kernel<false, false, true>, 256, lds);
 }
 }  // namespace rptg

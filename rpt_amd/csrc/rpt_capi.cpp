@@ -82,6 +82,7 @@ struct rpt_options {
     int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built
     int64_t scene_tree_meshes = 0;  // 1: meshes with trees of their own are leaves of the scene tree (every query walks to completion);
                                     // 0: they stay outside it and their walks are parked as in scenes without a scene tree (read by rpt_scene_commit)
+    int64_t f64_cull = 1;           // reference-epsilon mode: 1 = a lane evaluates only the objects whose fp32 box its ray can reach (same bits), 0 = every object
     int64_t epsilon_policy = 0;     // 1: the reference-epsilon mode (read by rpt_scene_commit): fp64, generic shapes, t_min = 1e-12, |hit - dist| < 1e-12
 };
 static rpt_options g_defaults;
@@ -112,6 +113,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "pull_batch") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "pull_batch must be 1..64"); o.pull_batch = value; }
     else if (s == "detach_trigger") { if (value < 1 || value > 32) return fail(RPT_ERR_INVALID, "detach_trigger must be 1..32"); o.detach_trigger = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
+    else if (s == "f64_cull") { if (value < 0 || value > 1) return fail(RPT_ERR_INVALID, "f64_cull must be 0 or 1"); o.f64_cull = value; }
     else if (s == "epsilon_policy") { if (value < 0 || value > 1) return fail(RPT_ERR_INVALID, "epsilon_policy must be 0 or 1"); o.epsilon_policy = value; }
     else if (s == "scene_tree_meshes") o.scene_tree_meshes = value;
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); o.scene_bvh_min = value; }
@@ -517,7 +519,7 @@ struct rpt_scene {
     void* arena64 = nullptr;
     rpt64::Scene view64{};
     double medium_color64[3] = {0, 0, 0}, medium_color_hi64[3] = {0, 0, 0};
-    uint64_t last_counters64[8] = {0};
+    uint64_t last_counters64[12] = {0};
     // mesh data interned by content (hash -> candidates), so Arc<Mesh>-style sharing survives the C ABI
     std::unordered_map<uint64_t, std::vector<std::shared_ptr<const std::vector<double>>>> mesh_pool;
     // tile cache key
@@ -1528,7 +1530,20 @@ struct Flattener {
 // ---------------------------------------------------------------------------- reference-epsilon mode (f64_layout.h)
 // The scene as the reference holds it: scene.objects in order, each a generic shape with the matrices Transformed::new
 // derives (src/shape.rs:112-125), meshes as their triangles in local space, materials and lights in fp64.
-static int fill_shape64(const HShape& hs, rpt64::Shape& o, std::vector<rpt64::Tri>& tris) {
+// (What depends on a triangle alone is evaluated here with the reference's operations in the reference's order; the
+// device must find the same bits, so nothing below may be contracted into an fma.)
+#pragma clang fp contract(off)
+static int check_scene64(const rpt_scene* s) {   // what the mode refuses, before anything is allocated
+    if (s->hdri_w) return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports Environment::Color only");
+    for (const auto& o : s->objects)
+        if (o.shape.d.kind == RPT_SHAPE_GROUP)
+            return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports sphere, cube, plane and mesh shapes (no KdTree groups)");
+    for (const auto& l : s->lights)
+        if (l.kind == int(L_OBJECT) && l.obj.shape.d.kind == RPT_SHAPE_GROUP)
+            return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports sphere, cube, plane and mesh shapes (no KdTree groups)");
+    return RPT_OK;
+}
+static int fill_shape64(const HShape& hs, rpt64::Shape& o, std::vector<rpt64::Tri>& tris, std::vector<double>& tri_pdf) {
     if (hs.d.kind == RPT_SHAPE_GROUP)
         return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports sphere, cube, plane and mesh shapes (no KdTree groups)");
     std::memset(&o, 0, sizeof(o));
@@ -1552,6 +1567,12 @@ static int fill_shape64(const HShape& hs, rpt64::Shape& o, std::vector<rpt64::Tr
             rpt64::Tri tr;
             std::memcpy(&tr, T.data() + t * 18, sizeof(tr));
             tris.push_back(tr);
+            // Triangle::sample's pdf (src/shape/mesh.rs:96-98) over KdTree::sample's choice (src/kdtree.rs:141-146)
+            const double e0[3] = {tr.v2[0] - tr.v1[0], tr.v2[1] - tr.v1[1], tr.v2[2] - tr.v1[2]};
+            const double e1[3] = {tr.v3[0] - tr.v1[0], tr.v3[1] - tr.v1[1], tr.v3[2] - tr.v1[2]};
+            const double cx = e0[1] * e1[2] - e0[2] * e1[1], cy = e0[2] * e1[0] - e0[0] * e1[2], cz = e0[0] * e1[1] - e0[1] * e1[0];
+            const double area = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+            tri_pdf.push_back((1.0 / area) / double(o.tri_count));
             for (int v = 0; v < 3; v++)   // Triangle::bounding_box merged over the mesh (src/kdtree.rs:108-113)
                 for (int k = 0; k < 3; k++) {
                     o.bmin[k] = std::min(o.bmin[k], T[t * 18 + v * 3 + k]);
@@ -1569,15 +1590,87 @@ static void fill_mat64(const rpt_material& m, rpt64::Mat& o) {
     o.shininess = m.shininess;
     o.ior = m.ior;
 }
+// What Triangle::intersect (src/shape/mesh.rs:50-83) computes from the triangle alone, by the same operations
+static rpt64::TriRec tri_rec64(const rpt64::Tri& t) {
+    rpt64::TriRec r;
+    double d0[3], d1[3];
+    for (int k = 0; k < 3; k++) { d0[k] = t.v2[k] - t.v1[k]; d1[k] = t.v3[k] - t.v1[k]; r.v1[k] = t.v1[k]; r.d0[k] = d0[k]; r.d1[k] = d1[k]; }
+    const double c[3] = {d0[1] * d1[2] - d0[2] * d1[1], d0[2] * d1[0] - d0[0] * d1[2], d0[0] * d1[1] - d0[1] * d1[0]};
+    const double len = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    for (int k = 0; k < 3; k++) r.pn[k] = c[k] / len;
+    r.d00 = d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2];
+    r.d01 = d0[0] * d1[0] + d0[1] * d1[1] + d0[2] * d1[2];
+    r.d11 = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+    r.denom = r.d00 * r.d11 - r.d01 * r.d01;
+    return r;
+}
+// Padded world-space box of an object in fp32 (f64_layout.h, CullBox): the box of the shape's own bounds under its
+// matrix, grown by 1e-5 of its size and of its coordinates, rounded outwards.
+static rpt64::CullBox cull_box64(const rpt64::Shape& sh) {
+    rpt64::CullBox c{};
+    if (sh.kind == rpt64::SH_PLANE) { c.unbounded = 1u; return c; }
+    double lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        const double h = sh.kind == rpt64::SH_SPHERE ? 1.0 : 0.5;
+        lo[k] = sh.kind == rpt64::SH_MESH ? sh.bmin[k] : -h;
+        hi[k] = sh.kind == rpt64::SH_MESH ? sh.bmax[k] : h;
+    }
+    double wlo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, whi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    for (int corner = 0; corner < 8; corner++) {
+        const double p[3] = {corner & 1 ? hi[0] : lo[0], corner & 2 ? hi[1] : lo[1], corner & 4 ? hi[2] : lo[2]};
+        for (int i = 0; i < 3; i++) {
+            const double w = sh.has_xf ? sh.fwd[i * 4] * p[0] + sh.fwd[i * 4 + 1] * p[1] + sh.fwd[i * 4 + 2] * p[2] + sh.fwd[i * 4 + 3] : p[i];
+            wlo[i] = std::min(wlo[i], w);
+            whi[i] = std::max(whi[i], w);
+        }
+    }
+    double size = 0.0, mag = 0.0;
+    for (int i = 0; i < 3; i++) { size = std::max(size, whi[i] - wlo[i]); mag = std::max(mag, std::max(std::fabs(wlo[i]), std::fabs(whi[i]))); }
+    const double pad = 1e-5 * size + 1e-5 * mag + 1e-30;
+    bool finite = true;
+    for (int i = 0; i < 3; i++) {
+        c.lo[i] = std::nextafter(float(wlo[i] - pad), -HUGE_VALF);
+        c.hi[i] = std::nextafter(float(whi[i] + pad), HUGE_VALF);
+        finite = finite && std::isfinite(c.lo[i]) && std::isfinite(c.hi[i]);
+    }
+    if (!finite) { c = rpt64::CullBox{}; c.unbounded = 1u; }   // (a box fp32 cannot hold: always evaluated)
+    return c;
+}
 static int build_scene64(rpt_scene* s) {
     static_assert(sizeof(rpt64::Tri) == 18 * sizeof(double), "a triangle is its 18 doubles");
-    if (s->hdri_w) return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports Environment::Color only");
-    std::vector<rpt64::Object> objs(s->objects.size());
+    if (int rc = check_scene64(s)) return rc;
+    const size_t n = s->objects.size();
+    std::vector<rpt64::Shape> shapes(n);
+    std::vector<rpt64::CullBox> cull(n);
+    std::vector<rpt64::ObjRec> recs(n);
+    std::vector<rpt64::ObjShade> shade(n);
     std::vector<rpt64::Tri> tris;
+    std::vector<double> tri_pdf;
     std::vector<rpt64::Light> lights(s->lights.size());
-    for (size_t i = 0; i < s->objects.size(); i++) {
-        if (int rc = fill_shape64(s->objects[i].shape, objs[i].shape, tris)) return rc;
-        fill_mat64(s->objects[i].mat, objs[i].mat);
+    for (size_t i = 0; i < n; i++) {
+        if (int rc = fill_shape64(s->objects[i].shape, shapes[i], tris, tri_pdf)) return rc;
+        const rpt64::Shape& sh = shapes[i];
+        cull[i] = cull_box64(sh);
+        rpt64::ObjRec& r = recs[i];
+        std::memset(&r, 0, sizeof(r));
+        r.kind = sh.kind; r.has_xf = sh.has_xf; r.tri_first = sh.tri_first; r.tri_count = sh.tri_count;
+        for (int k = 0; k < 12; k++) r.inv[k] = sh.inv[k];
+        for (int k = 0; k < 3; k++) {
+            if (sh.kind == rpt64::SH_MESH) { r.b[k] = sh.bmin[k]; r.b[3 + k] = sh.bmax[k]; }
+            else if (sh.kind == rpt64::SH_CUBE) { r.b[k] = -0.5; r.b[3 + k] = 0.5; }
+            else if (sh.kind == rpt64::SH_PLANE) { r.b[k] = sh.plane[k]; }
+        }
+        if (sh.kind == rpt64::SH_PLANE) r.b[3] = sh.plane[3];
+        std::memset(&shade[i], 0, sizeof(shade[i]));
+        for (int k = 0; k < 9; k++) shade[i].nrm[k] = sh.nrm[k];
+        fill_mat64(s->objects[i].mat, shade[i].mat);
+    }
+    const size_t n_obj_tris = tris.size();
+    std::vector<rpt64::TriRec> trecs(n_obj_tris);
+    std::vector<rpt64::TriShade> tshade(n_obj_tris);
+    for (size_t t = 0; t < n_obj_tris; t++) {
+        trecs[t] = tri_rec64(tris[t]);
+        for (int k = 0; k < 3; k++) { tshade[t].n1[k] = tris[t].n1[k]; tshade[t].n2[k] = tris[t].n2[k]; tshade[t].n3[k] = tris[t].n3[k]; }
     }
     for (size_t i = 0; i < s->lights.size(); i++) {
         const HLight& hl = s->lights[i];
@@ -1586,23 +1679,35 @@ static int build_scene64(rpt_scene* s) {
         L.kind = hl.kind;
         for (int k = 0; k < 3; k++) L.color[k] = hl.color[k];
         if (hl.kind == int(L_OBJECT)) {
-            if (int rc = fill_shape64(hl.obj.shape, L.obj.shape, tris)) return rc;
-            fill_mat64(hl.obj.mat, L.obj.mat);
+            if (int rc = fill_shape64(hl.obj.shape, L.shape, tris, tri_pdf)) return rc;
+            fill_mat64(hl.obj.mat, L.mat);
         }
     }
-    const size_t b_obj = objs.size() * sizeof(rpt64::Object), b_tri = tris.size() * sizeof(rpt64::Tri), b_l = lights.size() * sizeof(rpt64::Light);
-    const size_t o_tri = (b_obj + 15) & ~size_t(15), o_l = (o_tri + b_tri + 15) & ~size_t(15), total = std::max<size_t>(o_l + b_l, 16);
+    struct Part { const void* src; size_t bytes, off; };
+    Part parts[] = {{cull.data(), cull.size() * sizeof(rpt64::CullBox), 0},       {recs.data(), recs.size() * sizeof(rpt64::ObjRec), 0},
+                    {shade.data(), shade.size() * sizeof(rpt64::ObjShade), 0},    {trecs.data(), trecs.size() * sizeof(rpt64::TriRec), 0},
+                    {tshade.data(), tshade.size() * sizeof(rpt64::TriShade), 0},  {tris.data(), tris.size() * sizeof(rpt64::Tri), 0},
+                    {tri_pdf.data(), tri_pdf.size() * sizeof(double), 0},         {lights.data(), lights.size() * sizeof(rpt64::Light), 0}};
+    size_t total = 0;
+    for (auto& p : parts) { p.off = total; total = (total + p.bytes + 255) & ~size_t(255); }
+    total = std::max<size_t>(total, 256);
     HIP_TRY(hipMalloc(&s->arena64, total));
     char* base = static_cast<char*>(s->arena64);
-    if (b_obj) HIP_TRY(hipMemcpy(base, objs.data(), b_obj, hipMemcpyHostToDevice));
-    if (b_tri) HIP_TRY(hipMemcpy(base + o_tri, tris.data(), b_tri, hipMemcpyHostToDevice));
-    if (b_l) HIP_TRY(hipMemcpy(base + o_l, lights.data(), b_l, hipMemcpyHostToDevice));
+    for (auto& p : parts)
+        if (p.bytes) HIP_TRY(hipMemcpy(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice));
     rpt64::Scene& v = s->view64;
-    v.objects = reinterpret_cast<const rpt64::Object*>(base);
-    v.tris = reinterpret_cast<const rpt64::Tri*>(base + o_tri);
-    v.lights = reinterpret_cast<const rpt64::Light*>(base + o_l);
-    v.n_objects = uint32_t(objs.size());
+    v.cull = reinterpret_cast<const rpt64::CullBox*>(base + parts[0].off);
+    v.recs = reinterpret_cast<const rpt64::ObjRec*>(base + parts[1].off);
+    v.shade = reinterpret_cast<const rpt64::ObjShade*>(base + parts[2].off);
+    v.trecs = reinterpret_cast<const rpt64::TriRec*>(base + parts[3].off);
+    v.tshade = reinterpret_cast<const rpt64::TriShade*>(base + parts[4].off);
+    v.tris = reinterpret_cast<const rpt64::Tri*>(base + parts[5].off);
+    v.tri_pdf = reinterpret_cast<const double*>(base + parts[6].off);
+    v.lights = reinterpret_cast<const rpt64::Light*>(base + parts[7].off);
+    v.n_objects = uint32_t(n);
     v.n_lights = uint32_t(lights.size());
+    v.n_tris = uint32_t(tris.size());
+    v.n_obj_tris = uint32_t(n_obj_tris);
     v.has_medium = s->media.empty() ? 0 : 1;
     v.medium_kind = 0;
     v.absorption = v.scattering = 0.0;
@@ -1617,11 +1722,12 @@ static int build_scene64(rpt_scene* s) {
     for (int k = 0; k < 3; k++) v.env[k] = s->env[k];
     return RPT_OK;
 }
-// Renderer::sample in the reference-epsilon mode: one lane per pixel, frame written directly (no slab).
+// Renderer::sample in the reference-epsilon mode: the fp32 path's launch scheme (persistent grid over (pixel, chunk)
+// items, one launch set per stream) with an fp64 slab.
 static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations, uint64_t seed,
                         uint32_t sample_offset, double* d_out, hipStream_t st) {
-    RenderArgs a{};   // (tiles, sharding and argument checks are shared with the fp32 path)
-    int rc = rpti::prepare_render(s, st, cam, prm, iterations, seed, sample_offset, a);
+    RenderArgs a{};   // (tiles, sharding, chunking, launch sets and argument checks are shared with the fp32 path)
+    int rc = rpti::prepare_render(s, st, cam, prm, iterations, seed, sample_offset, a, 0, 0, 32);
     if (rc) return rc;
     rpt64::Args q{};
     q.sc = s->view64;
@@ -1640,36 +1746,24 @@ static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_pa
     q.cam.focal_distance = cam->focal_distance;
     q.width = prm->width; q.height = prm->height; q.iterations = iterations; q.sample_offset = sample_offset;
     q.max_bounces = prm->max_bounces;
-    q.n_owned = a.n_owned; q.tiles_x = a.tiles_x; q.tiles = a.tiles;
+    q.n_owned = a.n_owned; q.tiles_x = a.tiles_x; q.tiles = a.tiles; q.n_items = a.n_items;
+    q.chunk_spp = a.chunk_spp; q.n_chunks = a.n_chunks;
+    q.pull_batch = a.pull_batch;
+    q.cull = s->opt.f64_cull ? 1u : 0u;
     q.seed_mixed = a.seed_mixed;
     q.dim = double(std::max(prm->width, prm->height));
-    q.scale = std::pow(2.0, prm->exposure_value);
-    q.out = d_out;
-    q.counters = s->opt.counters ? s->d_counters : nullptr;
-    const uint32_t shard_count = prm->shard_count == 0 ? 1 : prm->shard_count;
-    if (shard_count > 1) HIP_TRY(hipMemsetAsync(d_out, 0, size_t(prm->width) * prm->height * 24, st));
-    if (q.counters) HIP_TRY(hipMemsetAsync(q.counters, 0, 512, st));
-    rpt_scene::LaunchSet& mine = s->sets[s->sets[0].d_queue == a.queue ? 0 : 1];
-    hipEvent_t* ev = nullptr;
-    if (s->opt.timing) {
-        const size_t slot = s->ev_count % rpt_scene::kTimedLaunches;
-        while (s->evs.size() < 3 * (slot + 1)) {
-            hipEvent_t e = nullptr;
-            HIP_TRY(hipEventCreate(&e));
-            s->evs.push_back(e);
-        }
-        ev = &s->evs[3 * slot];
-        HIP_TRY(hipEventRecord(ev[0], st));
+    q.queue = a.queue;
+    q.slab = reinterpret_cast<double*>(a.slab);
+    q.counters = a.counters;
+    int bpc = int(s->opt.blocks_per_cu);
+    if (bpc <= 0) {
+        HIP_TRY(render_f64_occupancy(q.sc.has_medium != 0, &bpc));
+        if (bpc < 1) bpc = 1;
     }
-    HIP_TRY(hipEventRecord(mine.launched, st));
-    HIP_TRY(launch_render_f64(q, st));
-    if (ev) {
-        HIP_TRY(hipEventRecord(ev[1], st));
-        HIP_TRY(hipEventRecord(ev[2], st));
-        s->ev_count++;
-    }
-    s->last_blocks = int((q.n_owned + 255u) / 256u);
-    HIP_TRY(hipEventRecord(mine.done, st));
+    rc = rpti::run_persistent(s, prm, a, d_out, st, bpc,
+                              [&q](const RenderArgs&, int nb, hipStream_t stream) { return launch_render_f64(q, nb, stream); }, true, false,
+                              [&q](double scale, double* out, hipStream_t stream) { return launch_resolve_f64(q, scale, out, stream); });
+    if (rc) return rc;
     if (q.counters) {
         HIP_TRY(hipStreamSynchronize(st));
         std::memset(s->last_counters, 0, sizeof(s->last_counters));
@@ -1694,6 +1788,8 @@ int rpt_scene_commit(rpt_scene* s, int device) {
         return fail(RPT_ERR_UNSUPPORTED, std::string("built for gfx950 (MI355X), device is ") + prop.gcnArchName);
     s->n_cus = prop.multiProcessorCount;
 
+    if (s->opt.epsilon_policy == 1)
+        if (int rc64 = check_scene64(s)) return rc64;   // (before anything is allocated on the device)
     Flattener f(s);
     int rc = f.flatten_objects();
     if (rc) return rc;
@@ -1764,7 +1860,7 @@ int rpt_scene_render_chunking(rpt_scene* s, uint32_t iterations, uint32_t* chunk
 }
 
 extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations,
-                         uint64_t seed, uint32_t sample_offset, RenderArgs& a, uint32_t min_chunk, uint32_t fixed_chunk) {
+                         uint64_t seed, uint32_t sample_offset, RenderArgs& a, uint32_t min_chunk, uint32_t fixed_chunk, uint32_t slab_item_bytes) {
     if (!s || !cam || !prm) return fail(RPT_ERR_INVALID, "null argument");
     if (!s->committed) return fail(RPT_ERR_STATE, "rpt_scene_commit must be called before rendering");
     if (prm->width == 0 || prm->height == 0 || iterations == 0) return fail(RPT_ERR_INVALID, "empty render");
@@ -1821,7 +1917,7 @@ extern "C++" int rpti::prepare_render(rpt_scene* s, hipStream_t st, const rpt_ca
     uint64_t n_items = uint64_t(a.n_owned) * a.n_chunks;
     if (n_items >= (1ull << 32) - (1ull << 24)) return fail(RPT_ERR_INVALID, "too many work items; raise chunk_spp");
     a.n_items = uint32_t(n_items);
-    size_t slab_bytes = std::max<size_t>(size_t(n_items) * 16, 16);
+    size_t slab_bytes = std::max<size_t>(size_t(n_items) * slab_item_bytes, 16);
     // the launch set: the one this stream used last, else the other one
     if (s->sets[s->cur_set].used && s->sets[s->cur_set].stream != st) s->cur_set ^= 1;
     rpt_scene::LaunchSet& ls = s->sets[s->cur_set];
@@ -1868,7 +1964,7 @@ extern "C++" int rpti::serialize_with_other_streams(rpt_scene* s, hipStream_t st
 
 extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm, const RenderArgs& a, double* d_out, hipStream_t st,
                          int blocks_per_cu, const std::function<hipError_t(const RenderArgs&, int, hipStream_t)>& launch,
-                         bool indexed_start, bool wave_items) {
+                         bool indexed_start, bool wave_items, const std::function<hipError_t(double, double*, hipStream_t)>& resolve) {
     rpt_scene::LaunchSet& mine = s->sets[s->sets[0].d_queue == a.queue ? 0 : 1];
     rpt_scene::LaunchSet& other = s->sets[s->sets[0].d_queue == a.queue ? 1 : 0];
     // Two launches that become ready at the same moment would share the CUs block by block, and the half of each
@@ -1901,7 +1997,8 @@ extern "C++" int rpti::run_persistent(rpt_scene* s, const rpt_render_params* prm
         HIP_TRY(hipEventRecord(mine.launched, st));
         HIP_TRY(launch(a, n_blocks, st));
         if (ev) HIP_TRY(hipEventRecord(ev[1], st));
-        HIP_TRY(launch_resolve(a, std::pow(2.0, prm->exposure_value), d_out, st));
+        if (resolve) HIP_TRY(resolve(std::pow(2.0, prm->exposure_value), d_out, st));
+        else HIP_TRY(launch_resolve(a, std::pow(2.0, prm->exposure_value), d_out, st));
         if (ev) {
             HIP_TRY(hipEventRecord(ev[2], st));
             s->ev_count++;
@@ -2001,10 +2098,10 @@ int rpt_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_para
     HIP_TRY(hipMemcpy(out_rgb, s->d_out, bytes, hipMemcpyDeviceToHost));
     return rpti::fetch_counters(s, a);
 }
-int rpt_debug_epsilon_counters(rpt_scene* s, uint64_t out[8]) {
+int rpt_debug_epsilon_counters(rpt_scene* s, uint64_t out[12]) {
     if (!s || !out) return fail(RPT_ERR_INVALID, "null argument");
     if (!s->arena64) return fail(RPT_ERR_STATE, "the scene was not committed with epsilon_policy = 1");
-    for (int i = 0; i < 8; i++) out[i] = s->last_counters64[i];
+    for (int i = 0; i < 12; i++) out[i] = s->last_counters64[i];
     return RPT_OK;
 }
 
