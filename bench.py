@@ -45,15 +45,19 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+FP64_PEAK_TFLOPS = 78.6    # fp64 vector = half the fp32 vector rate (one wave64 v_fma_f64 per 4 clocks per SIMD)
 N_SIMD = 1024              # 256 CUs x 4 SIMDs; one wave64 VALU instruction issues every 2 clocks per SIMD
 N_XCD = 8                  # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs: / 8 = the launch's clock cycles
 
 SCENE_FILES = {"C2": "examples/cornell.rs", "C3": "examples/volumetric_pathtrace_lampshade.rs",
                "C4": "examples/volumetric_beamphoton_lampshade.rs", "C5": "examples/dragon.rs layout, procedural 100,352-triangle mesh",
-               "C5G": "C5's mesh inside a KdTree<Box<dyn Bounded>> of 64 spheres (the shape of examples/fractal_teapots.rs:56 with one large mesh)"}
+               "C5G": "C5's mesh inside a KdTree<Box<dyn Bounded>> of 64 spheres (the shape of examples/fractal_teapots.rs:56 with one large mesh)",
+               "C3eps": "examples/volumetric_pathtrace_lampshade.rs, reference-epsilon mode (option epsilon_policy = 1: fp64, rpt's own 1e-12 tests)",
+               "C2eps": "examples/cornell.rs, reference-epsilon mode (option epsilon_policy = 1)"}
 WORKLOAD_NAMES = {"C2": "C2 cornell box path trace", "C3": "C3 lampshade-in-fog path trace",
                   "C4": "C4 lampshade beam x point photon map", "C5": "C5 100k-triangle mesh in fog path trace",
-                  "C5G": "C5G (not a BASELINE configuration) 100k-triangle mesh in a kd-tree group of 64 spheres, in fog"}
+                  "C5G": "C5G (not a BASELINE configuration) 100k-triangle mesh in a kd-tree group of 64 spheres, in fog",
+                  "C3eps": "C3 lampshade-in-fog path trace, reference-epsilon mode (fp64)", "C2eps": "C2 cornell box path trace, reference-epsilon mode (fp64)"}
 
 
 def usable_cpus():
@@ -338,7 +342,10 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
     from rpt_amd import Renderer, scenes
     from rpt_amd.dist import photon_map_build_sharded
 
-    scene, cam, cfg = scenes.CONFIGS[workload]()
+    eps = workload.endswith("eps")   # the reference-epsilon mode of the same configuration (kernels_f64.hip)
+    scene, cam, cfg = scenes.CONFIGS[workload[:-3] if eps else workload]()
+    if eps:
+        scene.set_option("epsilon_policy", 1)
     width = (args.width if headline else 0) or cfg["width"]
     height = (args.height if headline else 0) or cfg["height"]
     spp = (args.spp if headline else 0) or cfg["spp"]
@@ -494,7 +501,7 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
         "ms_per_step": round(ms_per_step, 3),
         "ms_per_step_is": "pipelined over two HIP streams" if n_streams == 2 else "one stream",
         "wall_clock_s": round(single_s, 5),
-        "dtype": "f32",
+        "dtype": "f64" if eps else "f32",
     }
     if host_elapsed is not None:
         out["value_host_resident"] = round(samples_per_step / host_elapsed / 1e6, 3)
@@ -553,14 +560,15 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
     bytes_ps, flops_ps, rays_ps = algorithmic_work(stats, len(scene.objects), cnt, samples_c)
     ach_tflops = flops_ps * local_samples / (k_ms * 1e-3) / 1e12
     chunk_spp, n_chunks = r.chunking(spp)
-    model = n_owned_px * (32.0 * n_chunks + 24.0)   # slab written + read, fp64 frame written
+    model = n_owned_px * ((64.0 if eps else 32.0) * n_chunks + 24.0)   # slab written + read (fp64 partial sums in the reference-epsilon mode), fp64 frame written
+    peak_tflops = FP64_PEAK_TFLOPS if eps else FP32_PEAK_TFLOPS
     out["config"] = {"workload": f"{WORKLOAD_NAMES[workload]} {width}x{height}x{spp}spp", "scene": SCENE_FILES[workload],
                      "parallelism": parallelism, "streams": n_streams, "rays_per_sample": round(rays_ps, 3),
                      "Mrays_per_s": round(value * rays_ps, 1), "chunk_spp": chunk_spp}
-    out["roofline"] = roofline_block("rptg::render_kernel", k_ms, k_src, grid_blocks, pmc, pmc_path, pmc_current, compulsory, model,
+    out["roofline"] = roofline_block("rpt64::render_f64_kernel" if eps else "rptg::render_kernel", k_ms, k_src, grid_blocks, pmc, pmc_path, pmc_current, compulsory, model,
                                      stats["bvh_nodes"] > 0, {"algorithmic_scene_bytes_per_sample": round(bytes_ps, 1)})
-    out.update({"valu_frac": round(ach_tflops / FP32_PEAK_TFLOPS, 4), "valu_tflops": round(ach_tflops, 3),
-                "valu_peak_tflops": FP32_PEAK_TFLOPS, "algorithmic_flops_per_sample": round(flops_ps, 1),
+    out.update({"valu_frac": round(ach_tflops / peak_tflops, 4), "valu_tflops": round(ach_tflops, 3),
+                "valu_peak_tflops": peak_tflops, "algorithmic_flops_per_sample": round(flops_ps, 1),
                 "valu_frac_is": "flops counted on the REFERENCE's structure (every object tested per ray); the device tests fewer, "
                                 "specialised records, so this flatters the kernel -- valu_issue_frac x active_lanes is the lane-slot utilisation",
                 "valu_issue_frac": issue, "active_lanes": lanes, "s_waitcnt_share": wait, "pmc_source": pmc_path if pmc_current else None,

@@ -33,7 +33,7 @@ namespace rpt64 {
 // render_f64_kernel and what it inlines: `Args` is that kernel's one argument.
 #define KA (*rptg::kernarg_args<Args>())
 #ifndef R64_WAVES
-#define R64_WAVES 3   // waves per SIMD the kernel is compiled for (168 VGPRs)
+#define R64_WAVES 4   // waves per SIMD the kernel is compiled for (128 VGPRs; C3 118.6 ms against 126.7 at 3 and 137.7 at 2, although 4 spills)
 #endif
 
 static constexpr double kEps = 1e-12;            // src/renderer.rs:17
@@ -589,13 +589,13 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
         const double sigma_t = KA.sc.absorption + KA.sc.scattering;
         double dmed = kInf;
         if (MEDIUM) dmed = -log(rng.range(0.0, 1.0)) / sigma_t;   // Medium::sample_d, src/medium.rs:133-146
-        const bool cull = KA.cull != 0u;
+        const bool limits = COUNT ? KA.cull == 2u : KA.cull != 0u;   // (cull = 2: the counters build keeps the limits too -- its counts are then the schedule's, not the reference's)
         // A hit beyond the sampled distance cannot change the event (dmed < t, or a miss with dmed < 400, is a medium event
         // either way, :197-243): the search may end there.  (The counters build searches everything: its counts are the
         // reference's.)
         // the query at hand: origin ro (the vertex once the event is known), direction rd (towards the light sample for a
         // shadow query), and the distance beyond which hits do not matter
-        double qlim = (MEDIUM && !COUNT && cull && dmed < 400.0) ? dmed : kInf;
+        double qlim = (MEDIUM && limits && dmed < 400.0) ? dmed : kInf;
         D E = mk(0, 0, 0), T = mk(0, 0, 0), n = mk(0, 1, 0), wo = mk(0, 0, 0);
         double dist = 0.0;
         int32_t hobj = -1;          // the object of a surface event
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
                             T = (bsdf(KA.sc.shade[hobj].mat, n, wo, wi) * I) * dot(wi, n);
                         }
                         rd = wi;
-                        qlim = (COUNT || !cull) ? kInf : dist;
+                        qlim = limits ? dist : kInf;
                     }
                     more = true;
                     break;

@@ -82,7 +82,8 @@ struct rpt_options {
     int64_t scene_bvh_min = 64;     // bounded primitives + BVH meshes from which the scene-level BVH is built
     int64_t scene_tree_meshes = 0;  // 1: meshes with trees of their own are leaves of the scene tree (every query walks to completion);
                                     // 0: they stay outside it and their walks are parked as in scenes without a scene tree (read by rpt_scene_commit)
-    int64_t f64_cull = 1;           // reference-epsilon mode: 1 = a lane evaluates only the objects whose fp32 box its ray can reach (same bits), 0 = every object
+    int64_t f64_cull = 1;           // reference-epsilon mode: 1 = a lane evaluates only the objects whose fp32 box its ray can reach (same bits), 0 = every object;
+                                    // 2 = as 1, and the counters build keeps the search limits as well (its counters then describe the schedule, not the reference's work)
     int64_t epsilon_policy = 0;     // 1: the reference-epsilon mode (read by rpt_scene_commit): fp64, generic shapes, t_min = 1e-12, |hit - dist| < 1e-12
 };
 static rpt_options g_defaults;
@@ -113,7 +114,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "pull_batch") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "pull_batch must be 1..64"); o.pull_batch = value; }
     else if (s == "detach_trigger") { if (value < 1 || value > 32) return fail(RPT_ERR_INVALID, "detach_trigger must be 1..32"); o.detach_trigger = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
-    else if (s == "f64_cull") { if (value < 0 || value > 1) return fail(RPT_ERR_INVALID, "f64_cull must be 0 or 1"); o.f64_cull = value; }
+    else if (s == "f64_cull") { if (value < 0 || value > 2) return fail(RPT_ERR_INVALID, "f64_cull must be 0, 1 or 2"); o.f64_cull = value; }
     else if (s == "epsilon_policy") { if (value < 0 || value > 1) return fail(RPT_ERR_INVALID, "epsilon_policy must be 0 or 1"); o.epsilon_policy = value; }
     else if (s == "scene_tree_meshes") o.scene_tree_meshes = value;
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); o.scene_bvh_min = value; }
@@ -1749,7 +1750,7 @@ static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_pa
     q.n_owned = a.n_owned; q.tiles_x = a.tiles_x; q.tiles = a.tiles; q.n_items = a.n_items;
     q.chunk_spp = a.chunk_spp; q.n_chunks = a.n_chunks;
     q.pull_batch = a.pull_batch;
-    q.cull = s->opt.f64_cull ? 1u : 0u;
+    q.cull = uint32_t(s->opt.f64_cull);
     q.seed_mixed = a.seed_mixed;
     q.dim = double(std::max(prm->width, prm->height));
     q.queue = a.queue;
@@ -1771,6 +1772,7 @@ static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_pa
         s->last_counters[0] = s->last_counters64[6];   // rpt_get_counters: samples, rays, vertices
         s->last_counters[1] = s->last_counters64[0];
         s->last_counters[2] = s->last_counters64[7];
+        s->last_counters[3] = s->last_counters64[10];   // wave-level loop trips
     }
     return RPT_OK;
 }

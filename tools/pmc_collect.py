@@ -24,8 +24,9 @@ ap.add_argument("--photons", type=int, default=0)
 args, _ = ap.parse_known_args()
 
 from rpt_amd import scenes  # noqa: E402  (pure Python: scene constants only)
-cfg = scenes.CONFIGS[args.workload]()[2]
-kernel = "photon_query_kernel" if "photons" in cfg else "render_kernel"
+eps = args.workload.endswith("eps")
+cfg = scenes.CONFIGS[args.workload[:-3] if eps else args.workload]()[2]
+kernel = "render_f64_kernel" if eps else "photon_query_kernel" if "photons" in cfg else "render_kernel"
 tot, launches, durations = defaultdict(float), defaultdict(set), []
 for f in glob.glob(args.out + "/pass*/**/*counter_collection.csv", recursive=True):
     rows = [row for row in csv.DictReader(open(f)) if kernel in row.get("Kernel_Name", "")]
@@ -36,6 +37,8 @@ for f in glob.glob(args.out + "/pass*/**/*counter_collection.csv", recursive=Tru
         rows = [row for row in rows if int(row["Dispatch_Id"]) != last]
     for row in rows:
         name = row.get("Kernel_Name", "")
+        if kernel == "render_f64_kernel" and re.search(r"render_f64_kernel<\w+, true", name):
+            continue  # (the counters instantiation)
         if kernel == "render_kernel" and (re.search(r"render_kernel<\w+, \d, true[,>]", name) or re.search(r"render_kernelILb[01]ELi\dELb1E", name)):
             continue  # the timed launches only (the COUNT = true instantiation is bench.py's untimed counter pass)
         tot[row["Counter_Name"]] += float(row["Counter_Value"])
