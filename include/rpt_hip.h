@@ -147,7 +147,8 @@ int rpt_scene_stats(rpt_scene*, uint64_t out[16]);
 /* Counters of the last rpt_render_sample* call on this scene (device-side, exact):
  * [0] camera samples, [1] closest-hit queries (rays), [2] path vertices, [3] kernel loop trips
  * (wave-iterations summed over waves), [4] primitive tests, [5] BVH nodes visited,
- * [6] BVH triangle tests.  Filled only when the library is built with RPT_COUNTERS or
+ * [6] BVH triangle tests, [7] tree walks that found their stack full (must be 0: scenes whose trees could overflow it
+ * are refused at commit).  Filled only when the library is built with RPT_COUNTERS or
  * rpt_set_option("counters", 1) was called before the render; otherwise zeros (also for a scene with a
  * group as a Light::Object: that kernel flavour has no counters build). */
 int rpt_get_counters(rpt_scene*, uint64_t out[8]);
@@ -296,7 +297,9 @@ int rpt_gather_frame_device(rpt_comm*, uint32_t width, uint32_t height, const vo
  * rank order -- contiguous blocks in rank order ARE the single-GPU arrays.  Collective.  d_local / n_local: this rank's records
  * (device); d_out: room for `capacity` records (device); n_per_rank (optional, n_ranks values) and n_total are filled on the host;
  * the call synchronises hip_stream once (the second all-gather is sized by the counts of the first).  If `capacity` is too
- * small the call fails with RPT_ERR_INVALID after filling n_total -- on every rank alike -- and can be repeated with room. */
+ * small the call fails with RPT_ERR_INVALID after filling n_total -- on every rank alike -- and can be repeated with room.
+ * d_out = NULL with capacity = 0 exchanges the counts only (RPT_OK): how a caller learns the size to bring (a photon stores
+ * one record per scattering event, so no multiple of the photon count bounds it). */
 int rpt_allgather_records_device(rpt_comm*, const void* d_local, uint64_t n_local, void* d_out, uint64_t capacity,
                                  uint64_t* n_per_rank, uint64_t* n_total, void* hip_stream);
 /* The packed layout (pure host function): tile_offsets[r] = first tile of rank r's block in the gathered buffer,

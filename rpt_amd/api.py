@@ -909,7 +909,7 @@ class Renderer:
     def counters(self):
         out = (C.c_uint64 * 8)()
         _lib.check(_lib.load().rpt_get_counters(self.scene._handle, out))
-        names = ["samples", "rays", "vertices", "wave_trips", "prim_tests", "bvh_nodes", "bvh_tris", "_"]
+        names = ["samples", "rays", "vertices", "wave_trips", "prim_tests", "bvh_nodes", "bvh_tris", "stack_overflows"]
         return dict(zip(names, [int(v) for v in out]))
 
     def get_closest_hit(self, origins, dirs):

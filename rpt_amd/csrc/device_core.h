@@ -351,6 +351,7 @@ RPT_DEV void bvh_traverse(const SceneView& scene_, uint32_t root, V o, V d, floa
             if (h0 && h1) {
                 const bool first0 = n0 <= n1;
                 if (sp < cap) { stk[sp * stride] = first0 ? nd.e1 : nd.e0; sp++; }
+                else if (COUNT && sc.stack_overflows) atomicAdd(sc.stack_overflows, 1ull);   // (never, by the commit-time depth check)
                 cur = first0 ? nd.e0 : nd.e1;
             } else if (h0 || h1) {
                 cur = h0 ? nd.e0 : nd.e1;
@@ -588,6 +589,7 @@ RPT_DEV void walk_meshes_resumable(const SceneView& scene_, V o, V d, float tmin
             if (h0 && h1) {
                 const bool first0 = n0 <= n1;
                 if (sp < cap) { stk[sp * stride] = first0 ? nd.e1 : nd.e0; sp++; }
+                else if (COUNT && sc.stack_overflows) atomicAdd(sc.stack_overflows, 1ull);   // (never, by the commit-time depth check)
                 cur = first0 ? nd.e0 : nd.e1;
             } else if (h0 || h1) {
                 cur = h0 ? nd.e0 : nd.e1;

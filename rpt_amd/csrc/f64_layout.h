@@ -103,6 +103,7 @@ struct Args {
     uint32_t width, height, iterations, sample_offset, max_bounces;
     uint32_t n_owned, tiles_x, n_items;
     uint32_t chunk_spp, n_chunks, pull_batch, cull;   // cull: 0 = every object is evaluated for every ray (the plain reference scan)
+    uint32_t surf_batch, _pad;                         // in a medium: lanes of a wave that wait at a surface event before the wave runs the surface code
     const uint32_t* tiles;
     uint64_t seed_mixed;
     double medium_color[3], medium_color_hi[3];   // Medium::color: hex_color(0xD2B48C), or blue (y <= 250) / red for the glowing fog

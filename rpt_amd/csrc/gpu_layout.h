@@ -182,6 +182,9 @@ struct SceneView {
     // Environment::Hdri (src/environment.rs:3-52): hdri_w = 0 means Environment::Color(env)
     const F4* hdri;
     uint32_t hdri_w, hdri_h;
+    // Counters builds only: bumped when a tree walk finds its stack full (bvh_traverse then drops the far child -- the commit-
+    // time depth check is what rules that out; this is where a violation would show).  rpt_get_counters()[7].
+    unsigned long long* stack_overflows;
 };
 
 struct CameraG {

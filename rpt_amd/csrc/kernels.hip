@@ -1500,10 +1500,12 @@ template <bool M, int B, bool C>
 static hipError_t launch_render_t(const RenderArgs& a, int n_blocks, hipStream_t stream) {
     const size_t lds = B == 1 ? kMeshTreeBytes : B ? kStackBytes + kStateBytesBvh : kStateBytes;
     if constexpr (M && B == 1) {
+#ifdef RPT_EXPERIMENTS   // streamed walks: a measured-slower prototype (297 against 237 ms), not in the default build
         if (a.detach == 2 && !a.sc.n_lparts) {
             hipLaunchKernelGGL((render_kernel<true, 1, C, false, 2>), dim3(n_blocks), dim3(256), kDetachBytes, stream, a);
             return hipGetLastError();
         }
+#endif
         if (a.detach && !a.sc.n_lparts) {
             hipLaunchKernelGGL((render_kernel<true, 1, C, false, 1>), dim3(n_blocks), dim3(256), kDetachBytes, stream, a);
             return hipGetLastError();
@@ -1530,8 +1532,10 @@ hipError_t launch_render(const RenderArgs& a, int n_blocks, hipStream_t stream) 
 }
 size_t stream_scratch_bytes_per_block() { return size_t(kWaveScratchDwords) * 4u * 4u; }
 hipError_t render_occupancy(bool medium, int bvh, int* blocks_per_cu, int detach) {
+#ifdef RPT_EXPERIMENTS
     if (detach == 2 && medium && bvh == 1)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)render_kernel<true, 1, false, false, 2>, 256, kDetachBytes);
+#endif
     if (detach && medium && bvh == 1)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)render_kernel<true, 1, false, false, 1>, 256, kDetachBytes);
     const void* f;

@@ -32,6 +32,25 @@ namespace rpt64 {
 // otherwise live in VGPR lanes (kernels.hip, "kernel arguments are read where they are used").  Valid in
 // render_f64_kernel and what it inlines: `Args` is that kernel's one argument.
 #define KA (*rptg::kernarg_args<Args>())
+// -DRPT_MARKERS drops "; SECT k" comments into the ISA (static instruction counts per section: tools/f64_sections.py)
+#ifdef RPT_MARKERS
+#define R64_MARK(k) asm volatile("; SECT " #k ::: "memory")
+#else
+#define R64_MARK(k)
+#endif
+// SECT64(k): the marker, and in the counters build the section's wave-level executions (counters[16 + 2k]) and the lanes
+// enabled in them (counters[17 + 2k]); tools/f64_sections.py puts them beside the static instruction counts.
+#define SECT64(k)                                                                                    \
+    do {                                                                                             \
+        R64_MARK(k);                                                                                 \
+        if (COUNT) {                                                                                 \
+            const uint64_t m_ = __ballot(true);                                                      \
+            if (mbcnt64(m_) == 0u) {                                                                 \
+                atomicAdd(&KA.counters[16 + 2 * (k)], 1ull);                                         \
+                atomicAdd(&KA.counters[17 + 2 * (k)], (unsigned long long)__popcll(m_));             \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
 #ifndef R64_WAVES
 #define R64_WAVES 4   // waves per SIMD the kernel is compiled for (128 VGPRs; C3 118.6 ms against 126.7 at 3 and 137.7 at 2, although 4 spills)
 #endif
@@ -91,20 +110,26 @@ struct Rng64 {
 };
 
 // ---------------------------------------------------------------------------- the closest-hit query
-// HitRecord (src/shape.rs:76-99) of a query in progress.  The normal is formed once, for the winner (`hit_normal`):
-// until then the record keeps what the winning primitive's normal is computed from.
+// HitRecord (src/shape.rs:76-99) of a query.  The normal is formed once, for the winner (`hit_normal`), from the ray, the
+// time and `aux`.
 struct Query {
     double t;        // HitRecord::time
     int32_t obj;     // index into scene.objects, -1: none
     uint32_t aux;    // cube: axis | negative << 2; plane: sign of the cosine; mesh: triangle (index into trecs)
-    D p;             // sphere: o + t d in the sphere's space; mesh: barycentric (u, v, w)
+};
+// What Shape::intersect of ONE object finds for a ray when the record it is handed is empty (time = +inf).
+struct PairHit {
+    double t;        // time of the hit, +inf: none
+    double bm;       // a mesh: max(entry into the tree's bounds, t_min); others: -inf (see closest_hit_wave)
+    uint32_t aux;
 };
 
 // Shape::intersect of object i (Transformed::intersect around it when has_xf, src/shape.rs:128-138; Ray::apply_transform
-// does not renormalise the direction, so t is shared), updating the record as the reference does: a hit replaces it iff
-// its time is smaller.
-template <class RP, class TP>
-R64_DEV void eval_object(RP recs, TP trecs, uint32_t i, D o, D d, Query& q) {
+// does not renormalise the direction, so t is shared) on an empty record.
+template <bool COUNT, class RP, class TP>
+R64_DEV PairHit eval_pair(RP recs, TP trecs, uint32_t i, D o, D d) {
+    SECT64(5);
+    PairHit h{kInf, -kInf, 0u};
     const auto& r = recs[i];
     const int32_t kind = r.kind;
     D ol = o, dl = d;
@@ -113,17 +138,18 @@ R64_DEV void eval_object(RP recs, TP trecs, uint32_t i, D o, D d, Query& q) {
         dl = xf_dir(r.inv, d);
     }
     if (kind == SH_PLANE) {   // Plane::intersect, src/shape/plane.rs:17-32
+        SECT64(6);
         const D n = ld(r.b);
         const double cosine = dot(n, dl);
         if (!(fabs(cosine) < 1e-8)) {
             const double time = (r.b[3] - dot(n, ol)) / cosine;
-            if (time >= kEps && time < q.t) {
-                q.t = time;
-                q.obj = int32_t(i);
-                q.aux = (cosine > 0.0 || (cosine == 0.0 && !__builtin_signbit(cosine))) ? 0u : 1u;   // f64::signum of the cosine
+            if (time >= kEps && time < kInf) {
+                h.t = time;
+                h.aux = (cosine > 0.0 || (cosine == 0.0 && !__builtin_signbit(cosine))) ? 0u : 1u;   // f64::signum of the cosine
             }
         }
     } else if (kind == SH_SPHERE) {   // Sphere::intersect, src/shape/sphere.rs:14-46
+        SECT64(7);
         const double a = dot(dl, dl), b = dot(dl, ol), c = dot(ol, ol) - 1.0;
         double disc = b * b - a * c;
         if (!__builtin_signbit(disc)) {
@@ -134,19 +160,17 @@ R64_DEV void eval_object(RP recs, TP trecs, uint32_t i, D o, D d, Query& q) {
                 t = (-b + disc) / a;
                 ok = !(t < kEps);
             }
-            if (ok && t < q.t) {
-                q.t = t;
-                q.obj = int32_t(i);
-                q.p = ol + t * dl;
-            }
+            if (ok && t < kInf) h.t = t;
         }
     } else {
+        SECT64(8);
         // the six slab roots: Cube::intersect (src/shape/cube.rs:23-35, planes at -0.5 / 0.5) and BoundingBox::intersect of
         // a mesh's bounds (src/kdtree.rs:56-71) are the same (plane - o) / d
         const double x1 = (r.b[0] - ol.x) / dl.x, x2 = (r.b[3] - ol.x) / dl.x;
         const double y1 = (r.b[1] - ol.y) / dl.y, y2 = (r.b[4] - ol.y) / dl.y;
         const double z1 = (r.b[2] - ol.z) / dl.z, z2 = (r.b[5] - ol.z) / dl.z;
         if (kind == SH_CUBE) {   // src/shape/cube.rs:36-74
+            SECT64(9);
             const bool sx = x1 > x2, sy = y1 > y2, sz = z1 > z2;
             const double lo0 = sx ? x2 : x1, hi0 = sx ? x1 : x2;
             const double lo1 = sy ? y2 : y1, hi1 = sy ? y1 : y2;
@@ -158,43 +182,45 @@ R64_DEV void eval_object(RP recs, TP trecs, uint32_t i, D o, D d, Query& q) {
             if (!(start > end || end < kEps)) {
                 const bool use_end = start < kEps;
                 const double time = use_end ? end : start;
-                if (time < q.t) {
+                if (time < kInf) {
                     const int ax = use_end ? ae : as;
                     const bool swapped = ax == 0 ? sx : (ax == 1 ? sy : sz);
                     const bool negative = use_end ? swapped : !swapped;   // start carries the lower root's normal (-1 unless swapped)
-                    q.t = time;
-                    q.obj = int32_t(i);
-                    q.aux = uint32_t(ax) | (negative ? 4u : 0u);
+                    h.t = time;
+                    h.aux = uint32_t(ax) | (negative ? 4u : 0u);
                 }
             }
         } else {
             // `Mesh = KdTree<Triangle>` (src/shape/mesh.rs:106): KdTree::intersect rejects the ray against the tree's bounds
             // (src/kdtree.rs:132-139; f64::min / max ignore a NaN operand like fmin / fmax), then finds the closest triangle.
             // The kd-tree below the root is an acceleration structure: every triangle is tested here.
+            SECT64(10);
             const double b_min = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmin(z1, z2));
             const double b_max = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
-            if (!(fmax(b_min, kEps) > fmin(b_max, q.t))) {
+            h.bm = fmax(b_min, kEps);
+            if (!(h.bm > fmin(b_max, kInf))) {
                 for (uint32_t j = 0; j < r.tri_count; j++) {   // Triangle::intersect, src/shape/mesh.rs:50-83
+                    SECT64(11);
                     const auto& tr = trecs[r.tri_first + j];
                     const D pn = ld(tr.pn), v1 = ld(tr.v1);
                     const double cosine = dot(pn, dl);
                     if (fabs(cosine) < 1e-8) continue;
                     const double time = dot(pn, v1 - ol) / cosine;
-                    if (time < kEps || time >= q.t) continue;
+                    if (time < kEps || time >= h.t) continue;
+                    SECT64(12);
                     const D d2 = (ol + time * dl) - v1;
                     const double d20 = dot(d2, ld(tr.d0)), d21 = dot(d2, ld(tr.d1));
                     const double v = (tr.d11 * d20 - tr.d01 * d21) / tr.denom, w = (tr.d00 * d21 - tr.d01 * d20) / tr.denom;
                     const double u = 1.0 - v - w;
                     if (u >= 0.0 && v >= 0.0 && w >= 0.0) {
-                        q.t = time;
-                        q.obj = int32_t(i);
-                        q.aux = r.tri_first + j;
-                        q.p = mk(u, v, w);
+                        h.t = time;
+                        h.aux = r.tri_first + j;
                     }
                 }
             }
         }
     }
+    return h;
 }
 
 // The fp32 box test that decides which objects a lane evaluates.  Conservative: boxes are padded at commit (1e-5 of
@@ -223,10 +249,37 @@ R64_DEV uint32_t cull32(const CullBox* boxes, uint32_t base, uint32_t nb, float 
     return mask;
 }
 
-// Renderer::get_closest_hit, src/renderer.rs:416-425, into a record the caller has reset.  `tlim`: hits beyond it do not
-// matter to the caller (+inf: all do).
+R64_DEV uint32_t lane_read(uint32_t v, uint32_t src_lane) { return uint32_t(__builtin_amdgcn_ds_bpermute(int(src_lane << 2), int(v))); }
+R64_DEV double lane_read(double v, uint32_t src_lane) {
+    const uint64_t u = __double_as_longlong(v);
+    const uint32_t lo = lane_read(uint32_t(u), src_lane), hi = lane_read(uint32_t(u >> 32), src_lane);
+    return __longlong_as_double((long long)((uint64_t(hi) << 32) | lo));
+}
+R64_DEV D lane_read(D v, uint32_t src_lane) { return mk(lane_read(v.x, src_lane), lane_read(v.y, src_lane), lane_read(v.z, src_lane)); }
+
+// Renderer::get_closest_hit, src/renderer.rs:416-425, for the wave's queries together.  EVERY lane of the wave calls this
+// (wave-uniform control flow); `mine`: the lane has a query (o, d) -- `tlim`: hits beyond it do not matter to it (+inf: all
+// do) --, the others only work.
+//
+// A lane's candidates are the objects its fp32 box test keeps; on average a query has about one and a wave about forty,
+// unevenly: were every lane to evaluate its own, the wave would run as many rounds as its unluckiest lane has candidates
+// with most lanes idle.  So the (ray, object) pairs of the wave are dealt out to its 64 lanes: rank k = the k-th candidate
+// of each lane in scene order; whole ranks are packed into a chunk of at most 64 pairs (pair = slot `used + position among
+// the rank's lanes`, written to the wave's 64 LDS dwords); a slot lane fetches its pair's ray from the owner
+// (ds_bpermute), evaluates the object on an empty record, and the owners collect their results rank by rank, i.e. in scene
+// order, and apply them as the reference's loop does: object i replaces the record iff its time is smaller -- and, for a
+// mesh, iff KdTree::intersect's bounds test (src/kdtree.rs:132-139), which sees the record's time, lets the ray in:
+// !(max(b_min, t_min) > min(b_max, rec.time)); on the empty record that is `bm <= b_max` (else no triangle was tested), so
+// with the record's time R it is !(bm > R).  Inside a mesh the triangles run in order on one lane.  The record is
+// therefore the reference's after every object, bit for bit.
 template <bool COUNT, class RP, class TP>
-R64_DEV void closest_hit(RP recs, TP trecs, D o, D d, double tlim, Query& q, uint32_t& c_evals, uint32_t& c_rounds) {
+R64_DEV void closest_hit_wave(RP recs, TP trecs, volatile uint32_t* slots, bool mine, D o, D d, double tlim, Query& q, uint32_t& c_evals,
+                              uint32_t& c_rounds) {
+    SECT64(3);
+    const uint32_t lane = threadIdx.x & 63u;
+    q.t = kInf;
+    q.obj = -1;
+    q.aux = 0u;
     const uint32_t n = KA.sc.n_objects;
     const bool cull = KA.cull != 0u;
     const float ox = float(o.x), oy = float(o.y), oz = float(o.z);
@@ -235,37 +288,93 @@ R64_DEV void closest_hit(RP recs, TP trecs, D o, D d, double tlim, Query& q, uin
     const float tl = float(tlim) * 1.00001f;
     for (uint32_t base = 0; base < n; base += 32u) {
         const uint32_t nb = min(32u, n - base);
-        uint32_t mask = nb == 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
-        if (cull) mask = cull32(KA.sc.cull, base, nb, ox, oy, oz, ix, iy, iz, eo, tl);
-        while (__ballot(mask != 0u) != 0ull) {
-            if (COUNT && mbcnt64(__ballot(true)) == 0u) c_rounds++;
-            if (mask != 0u) {
-                const uint32_t j = uint32_t(__builtin_ctz(mask));
-                mask &= mask - 1u;
+        uint32_t mask = 0u;
+        if (mine) {
+            mask = nb == 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+            if (cull) mask = cull32(KA.sc.cull, base, nb, ox, oy, oz, ix, iy, iz, eo, tl);
+        }
+        while (__ballot(mask != 0u) != 0ull) {   // one chunk of whole ranks per iteration
+            SECT64(4);
+            if (COUNT && lane == 0u) c_rounds++;
+            // ---- deal the pairs out
+            slots[lane] = 0u;
+            uint32_t used = 0u, n_ranks = 0u;   // wave-uniform
+            uint32_t mm = mask;
+            for (;;) {
+                const uint64_t B = __ballot(mm != 0u);
+                const uint32_t c = uint32_t(__popcll(B));
+                if (c == 0u || used + c > 64u) break;   // (the first rank always fits)
+                if (mm != 0u) {
+                    slots[used + mbcnt64(B)] = (lane + 1u) | ((base + uint32_t(__builtin_ctz(mm))) << 8);
+                    mm &= mm - 1u;
+                }
+                used += c;
+                n_ranks++;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t info = slots[lane];
+            // ---- a slot lane takes its pair's ray from the owner and evaluates the object
+            const uint32_t owner = info ? (info & 0xFFu) - 1u : lane;
+            const D po = lane_read(o, owner), pd = lane_read(d, owner);
+            PairHit ph{kInf, -kInf, 0u};
+            if (info != 0u) {
                 if (COUNT) c_evals++;
-                eval_object(recs, trecs, base + j, o, d, q);
+                ph = eval_pair<COUNT>(recs, trecs, info >> 8, po, pd);
+            }
+            // ---- the owners collect, rank by rank = in scene order
+            uint32_t cum = 0u;
+            for (uint32_t rk = 0; rk < n_ranks; rk++) {
+                SECT64(13);
+                const uint64_t B = __ballot(mask != 0u);
+                const bool has = mask != 0u;
+                const uint32_t src = has ? cum + mbcnt64(B) : lane;
+                const double t = lane_read(ph.t, src), bm = lane_read(ph.bm, src);
+                const uint32_t aux = lane_read(ph.aux, src);
+                if (has) {
+                    if (!(bm > q.t) && t < q.t) {
+                        q.t = t;
+                        q.obj = int32_t(base + uint32_t(__builtin_ctz(mask)));
+                        q.aux = aux;
+                    }
+                    mask &= mask - 1u;
+                }
+                cum += uint32_t(__popcll(B));
             }
         }
     }
 }
 
-// The winner's world-space normal: what each Shape::intersect stores in the record, then Transformed::intersect's
-// normalize(normal_transform * n) (src/shape.rs:135-136).
-template <class RP>
-R64_DEV D hit_normal(RP recs, const Query& q) {
+// The winner's world-space normal: what its Shape::intersect stores in the record -- formed here from the ray, the time
+// and `aux` by the same operations on the same operands --, then Transformed::intersect's normalize(normal_transform * n)
+// (src/shape.rs:135-136).
+template <class RP, class TP>
+R64_DEV D hit_normal(RP recs, TP trecs, const Query& q, D o, D d) {
     const auto& r = recs[q.obj];
     D n;
     if (r.kind == SH_CUBE) {
         const double sg = (q.aux & 4u) ? -1.0 : 1.0;
         const uint32_t ax = q.aux & 3u;
         n = mk(ax == 0u ? sg : 0.0, ax == 1u ? sg : 0.0, ax == 2u ? sg : 0.0);
-    } else if (r.kind == SH_SPHERE) {
-        n = normalize(q.p);
     } else if (r.kind == SH_PLANE) {
         n = -(normalize(ld(r.b))) * (q.aux ? -1.0 : 1.0);
     } else {
-        const TriShade& ts = KA.sc.tshade[q.aux];
-        n = normalize(q.p.x * ld(ts.n1) + q.p.y * ld(ts.n2) + q.p.z * ld(ts.n3));
+        D ol = o, dl = d;
+        if (r.has_xf) {
+            ol = xf_point(r.inv, o);
+            dl = xf_dir(r.inv, d);
+        }
+        if (r.kind == SH_SPHERE) {
+            n = normalize(ol + q.t * dl);   // src/shape/sphere.rs:40
+        } else {   // src/shape/mesh.rs:64-80
+            const auto& tr = trecs[q.aux];
+            const D d2 = (ol + q.t * dl) - ld(tr.v1);
+            const double d20 = dot(d2, ld(tr.d0)), d21 = dot(d2, ld(tr.d1));
+            const double v = (tr.d11 * d20 - tr.d01 * d21) / tr.denom, w = (tr.d00 * d21 - tr.d01 * d20) / tr.denom;
+            const double u = 1.0 - v - w;
+            const TriShade& ts = KA.sc.tshade[q.aux];
+            n = normalize(u * ld(ts.n1) + v * ld(ts.n2) + w * ld(ts.n3));
+        }
     }
     if (r.has_xf) n = normalize(mul3(KA.sc.shade[q.obj].nrm, n));
     return n;
@@ -446,11 +555,12 @@ R64_DEV void cast_ray(const CP& c, double x, double y, Rng64& rng, D& o, D& d) {
 }
 
 // LDS of a block, in doubles: [kColsD columns of 256: acc, P, Q, R][kColsU / 2 columns' worth of dword columns: slab slot,
-// sample, end, pixel][ObjRec x kLdsObjs][TriRec x kLdsTris]
+// sample, end, pixel][ObjRec x kLdsObjs][TriRec x kLdsTris][64 dwords per wave: closest_hit_wave's slots]
 static constexpr uint32_t kColsD = 12u, kColsU = 4u;
 static constexpr uint32_t kTabBase = (kColsD + kColsU / 2u) * 256u;
 static constexpr uint32_t kObjDoubles = sizeof(ObjRec) / 8u, kTriDoubles = sizeof(TriRec) / 8u;
-static constexpr uint32_t kLdsDoubles = kTabBase + kLdsObjs * kObjDoubles + kLdsTris * kTriDoubles;
+static constexpr uint32_t kSlotBase = kTabBase + kLdsObjs * kObjDoubles + kLdsTris * kTriDoubles;   // 4 waves x 64 dwords: the pairs of a chunk
+static constexpr uint32_t kLdsDoubles = kSlotBase + 4u * 32u;
 static_assert(sizeof(ObjRec) == 160 && sizeof(TriRec) == 128 && sizeof(CullBox) == 32, "record sizes");
 static_assert(kLdsDoubles * 8u * 4u <= 160u * 1024u, "four blocks per CU");
 
@@ -475,6 +585,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
         recs = reinterpret_cast<const ObjRec*>(t0);
         trecs = reinterpret_cast<const TriRec*>(t0 + kLdsObjs * kObjDoubles);
     }
+    volatile uint32_t* const slots = reinterpret_cast<uint32_t*>(lds64 + kSlotBase) + (threadIdx.x >> 6) * 64u;   // this wave's
     auto ldD = [&](int c) { return mk(cd[c * 256], cd[(c + 1) * 256], cd[(c + 2) * 256]); };
     auto stD = [&](int c, D v) { cd[c * 256] = v.x; cd[(c + 1) * 256] = v.y; cd[(c + 2) * 256] = v.z; };
 
@@ -483,6 +594,8 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
     D ro = mk(0, 0, 0), rd = mk(0, 0, 1);
     uint32_t depth = 0;
     bool alive = true, have_item = false, need_path = true, item_done = true;
+    bool parked = false;            // the lane's path waits at a surface event (below)
+    Query pq{kInf, -1, 0u};         // ... with this record
     bool drained = false, first_batch = true;                                   // wave-uniform
     uint32_t pool_next = 0, pool_end = 0, pool_chunk = 0, pool_x0 = 0, pool_y0 = 0;   // wave-uniform: the batch of work items at hand
     uint32_t c_rays = 0, c_hits = 0, c_self = 0, c_shadow = 0, c_pass = 0, c_near = 0, c_samples = 0, c_vertices = 0, c_evals = 0,
@@ -495,6 +608,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
         bool want = alive && need_path && item_done;
         const uint32_t n_want = uint32_t(__popcll(__ballot(want)));
         if (n_want != 0u && (n_want >= KA.pull_batch || __ballot(alive && !want) == 0ull)) {
+            SECT64(0);
             const auto& ka = KA;
             if (want && have_item) {
                 double* const sl = ka.slab + size_t(cu[U_SLAB * 256]) * 4u;
@@ -554,6 +668,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
             }
         }
         if (need_path && alive && !item_done) {   // the item's next sample: src/renderer.rs:174-181
+            SECT64(1);
             const auto& ka = KA;
             const uint32_t s = cu[U_S * 256], xy = cu[U_XY * 256], x = xy & 0xFFFFu, y = xy >> 16;
             rng.r.seed(ka.seed_mixed, y * ka.width + x, ka.sample_offset + s);
@@ -578,17 +693,27 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
             if (mbcnt64(__ballot(true)) == 0u) c_trips++;
             if (alive && !need_path) c_live++;
         }
-        if (!alive || need_path) continue;   // (a lane without a path waits for the wave's next item hand-out)
-
         // ---- one path vertex = one trace_ray invocation (src/renderer.rs:187-322).  The radiance of the path is
         // min(P + Q x, R) per channel, x = what the rest of the path returns (closed under x -> E + min(k x, 100), :308-313;
         // in a medium there is no clamp, R = inf).
         // The vertex's closest-hit queries -- the path's own, then one per object light -- go through ONE copy of the query
-        // code: `sub` counts them, wave-uniformly.
-        if (COUNT) c_vertices++;
+        // code, which every lane of the wave enters (closest_hit_wave: lanes without a query work for the others); `sub`
+        // counts the queries, wave-uniformly.
+        // In a medium most events are medium events, and the code of a surface event -- the winner's normal, the BSDF, the
+        // direction sampler with its libm calls: a third of a trip's instructions -- would run in nearly every trip for the three
+        // or four lanes of a wave that need it.  A lane whose closest-hit query ends in a surface event therefore PARKS: it keeps
+        // its ray and the query's record and sits out until `surf_batch` lanes of the wave are parked or no lane has anything
+        // else to do; then they go through the surface code together.  Every lane still draws its own numbers in its own
+        // order: the frame does not depend on the threshold (tests/test_gpu_epsilon.py).
+        const bool live = alive && !need_path;   // (a lane without a path waits for the wave's next item hand-out)
+        const bool fresh = live && !parked;      // a new vertex starts here
+        if (COUNT && fresh) c_vertices++;
         const double sigma_t = KA.sc.absorption + KA.sc.scattering;
         double dmed = kInf;
-        if (MEDIUM) dmed = -log(rng.range(0.0, 1.0)) / sigma_t;   // Medium::sample_d, src/medium.rs:133-146
+        if (MEDIUM && fresh) {
+            SECT64(2);
+            dmed = -log(rng.range(0.0, 1.0)) / sigma_t;   // Medium::sample_d, src/medium.rs:133-146
+        }
         const bool limits = COUNT ? KA.cull == 2u : KA.cull != 0u;   // (cull = 2: the counters build keeps the limits too -- its counts are then the schedule's, not the reference's)
         // A hit beyond the sampled distance cannot change the event (dmed < t, or a miss with dmed < 400, is a medium event
         // either way, :197-243): the search may end there.  (The counters build searches everything: its counts are the
@@ -600,58 +725,80 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
         double dist = 0.0;
         int32_t hobj = -1;          // the object of a surface event
         bool ev_medium = false;
-        bool active = true;         // false: the path ended at this vertex without an event (miss)
+        bool active = fresh;        // false: no path, parked, or the path ended at this vertex without an event (miss)
+        auto surface_event = [&](const Query& h) {   // :207-216 in a medium, :289-299 without
+            SECT64(16);
+            hobj = h.obj;
+            n = hit_normal(recs, trecs, h, ro, rd);
+            ro = ro + h.t * rd;
+            wo = -normalize(rd);
+            const Mat& mat = KA.sc.shade[hobj].mat;
+            E = depth == 0 ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
+        };
         uint32_t li = 0;            // wave-uniform: next light to look at
         const uint32_t n_lights = KA.sc.n_lights;
         for (uint32_t sub = 0;; sub++) {
             Query q;
-            q.t = kInf; q.obj = -1; q.aux = 0u; q.p = mk(0, 0, 0);
-            if (active) closest_hit<COUNT>(recs, trecs, ro, rd, qlim, q, c_evals, c_rounds);
-            if (sub == 0) {
-                const bool hit = q.obj >= 0;
-                if (COUNT) {
-                    c_rays++;
-                    if (hit) {
-                        c_hits++;
-                        const double m = fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z));
-                        if (q.t < 1e-9 * (1.0 + m)) c_self++;   // diagnostic: a hit on the surface the ray starts on
+            closest_hit_wave<COUNT>(recs, trecs, slots, active, ro, rd, qlim, q, c_evals, c_rounds);
+            if (active) {
+                SECT64(14);
+                if (sub == 0) {
+                    const bool hit = q.obj >= 0;
+                    if (COUNT) {
+                        c_rays++;
+                        if (hit) {
+                            c_hits++;
+                            const double m = fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z));
+                            if (q.t < 1e-9 * (1.0 + m)) c_self++;   // diagnostic: a hit on the surface the ray starts on
+                        }
+                    }
+                    ev_medium = MEDIUM && dmed < (hit ? q.t : 400.0);   // :197-243 (`d >= h.time` is a surface event)
+                    if (!ev_medium && !hit) {   // :198-206 (in a medium the background counts only beyond 400), :288
+                        const D env = (!MEDIUM || dmed >= 400.0) ? ld(KA.sc.env) : mk(0, 0, 0);
+                        const D v = ldD(C_P) + ldD(C_Q) * env;
+                        stD(C_ACC, ldD(C_ACC) + (MEDIUM ? v : vmin(v, ldD(C_R))));
+                        need_path = true;
+                        active = false;
+                    } else if (ev_medium) {   // :243-255
+                        SECT64(15);
+                        ro = ro + dmed * rd;
+                        const double emm = KA.sc.medium_kind == 1 ? 10.0 : 0.0;
+                        E = depth == 0 ? emm * medium_color(ro) : mk(0, 0, 0);
+                    } else if (MEDIUM) {   // a surface event: waits for company (see above)
+                        parked = true;
+                        pq = q;
+                        active = false;
+                    } else {
+                        surface_event(q);
+                    }
+                } else {
+                    SECT64(17);
+                    // the shadow test (:339-348, :386-396): the closest hit along wi lies at the sampled distance
+                    const double miss = fabs(q.t - dist);
+                    const bool visible = q.obj >= 0 && miss < kEps;
+                    if (COUNT) {
+                        c_rays++;
+                        c_shadow++;
+                        if (q.obj >= 0) {
+                            c_hits++;
+                            const double m = fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z));
+                            if (q.t < 1e-9 * (1.0 + m)) c_self++;
+                            if (miss < kEps) c_pass++;
+                            else if (miss < 1e-6 * dist) c_near++;   // diagnostic: the light's own surface, missed by rounding
+                        }
+                    }
+                    if (visible) E = E + T;
+                }
+            }
+            if (MEDIUM && sub == 0) {
+                const uint64_t pk = __ballot(parked);
+                if (pk != 0ull && (uint32_t(__popcll(pk)) >= KA.surf_batch || __ballot(active) == 0ull)) {
+                    if (parked) {
+                        surface_event(pq);
+                        parked = false;
+                        active = true;
                     }
                 }
-                ev_medium = MEDIUM && dmed < (hit ? q.t : 400.0);   // :197-243 (`d >= h.time` is a surface event)
-                if (!ev_medium && !hit) {   // :198-206 (in a medium the background counts only beyond 400), :288
-                    const D env = (!MEDIUM || dmed >= 400.0) ? ld(KA.sc.env) : mk(0, 0, 0);
-                    const D v = ldD(C_P) + ldD(C_Q) * env;
-                    stD(C_ACC, ldD(C_ACC) + (MEDIUM ? v : vmin(v, ldD(C_R))));
-                    need_path = true;
-                    active = false;
-                } else if (ev_medium) {   // :243-255
-                    ro = ro + dmed * rd;
-                    const double emm = KA.sc.medium_kind == 1 ? 10.0 : 0.0;
-                    E = depth == 0 ? emm * medium_color(ro) : mk(0, 0, 0);
-                } else {   // surface event: :207-216 in a medium, :289-299 without
-                    ro = ro + q.t * rd;
-                    hobj = q.obj;
-                    n = hit_normal(recs, q);
-                    wo = -normalize(rd);
-                    const Mat& mat = KA.sc.shade[hobj].mat;
-                    E = depth == 0 ? mat_emit(mat) * mat_color(mat) : mk(0, 0, 0);
-                }
-            } else {
-                // the shadow test (:339-348, :386-396): the closest hit along wi lies at the sampled distance
-                const double miss = fabs(q.t - dist);
-                const bool visible = active && q.obj >= 0 && miss < kEps;
-                if (COUNT && active) {
-                    c_rays++;
-                    c_shadow++;
-                    if (q.obj >= 0) {
-                        c_hits++;
-                        const double m = fmax(fmax(fabs(ro.x), fabs(ro.y)), fabs(ro.z));
-                        if (q.t < 1e-9 * (1.0 + m)) c_self++;
-                        if (miss < kEps) c_pass++;
-                        else if (miss < 1e-6 * dist) c_near++;   // diagnostic: the light's own surface, missed by rounding
-                    }
-                }
-                if (visible) E = E + T;
             }
             // sample_lights_for_media :325-359 / sample_lights :362-409; lights in scene order fix the draw order.  Ambient
             // lights add their term; the next object light is sampled and its shadow query becomes the query at hand.
@@ -663,14 +810,17 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
                     if (active) E = E + ld(L.color) * (ev_medium ? medium_color(ro) : mat_color(KA.sc.shade[hobj < 0 ? 0 : hobj].mat));
                 } else if (L.kind == LT_OBJECT) {
                     if (active) {
+                        SECT64(18);
                         D I, wi;
                         illuminate_object(L, ro, rng, I, wi, dist);
                         // the light's term of E if it proves visible
                         if (ev_medium) {
+                            SECT64(19);
                             const double scat = KA.sc.scattering;
                             const double phase = KA.sc.medium_kind == 1 ? 1.0 / 4.0 * kPi : 1.0 / (4.0 * kPi);   // (sic, src/medium.rs:113)
                             T = ((scat / sigma_t) * (I * medium_color(ro))) * phase;
                         } else {
+                            SECT64(20);
                             T = (bsdf(KA.sc.shade[hobj].mat, n, wo, wi) * I) * dot(wi, n);
                         }
                         rd = wi;
@@ -689,6 +839,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
         D k = mk(0, 0, 0), wi_next = mk(0, 0, 1);
         bool cont = false;
         if (ev_medium) {   // :262-281
+            SECT64(21);
             if (rng.uniform() < 0.8) {
                 const double ax = rng.range(-1.0, 1.0), ay = rng.range(-1.0, 1.0), az = rng.range(-1.0, 1.0);
                 wi_next = normalize(mk(ax, ay, az));   // Medium::sample_ph, src/medium.rs:87-93
@@ -698,6 +849,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
                 cont = true;
             }
         } else {
+            SECT64(22);
             const bool go = MEDIUM ? (rng.uniform() < 0.8) : (depth < KA.max_bounces);   // :222 / :301
             if (go) {
                 double pdf;
@@ -709,6 +861,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
                 }
             }
         }
+        SECT64(23);
         const D Q = ldD(C_Q);
         const D P = ldD(C_P) + Q * E;
         if (!cont) {   // (a path whose weight has become zero goes on, as the reference's recursion does: same rays, same draws)

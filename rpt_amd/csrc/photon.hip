@@ -2085,7 +2085,9 @@ void rpti::photon_release(void* p) {
     }
 }
 
-// The split camera pass (PHASE 1, then 2): same grid, same work items; the work counter starts again in between.
+// The split camera pass (PHASE 1, then 2): same grid, same work items; the work counter starts again in between.  A measured-
+// slower prototype (112 ms against 95 on C4): its eight kernel flavours are built with -DRPT_EXPERIMENTS only.
+#ifdef RPT_EXPERIMENTS
 template <bool B>
 static void launch_query_split(const QueryArgs& q, int kind, int nb, size_t lds, hipStream_t st) {
     const dim3 g(nb), b(256);
@@ -2095,12 +2097,15 @@ static void launch_query_split(const QueryArgs& q, int kind, int nb, size_t lds,
     if (kind == RPT_PHOTON_BEAM_BEAM) hipLaunchKernelGGL((photon_query_kernel<true, B, false, RPT_PHOTON_BEAM_BEAM, 2>), g, b, lds, st, q);
     else hipLaunchKernelGGL((photon_query_kernel<true, B, false, RPT_PHOTON_POINT_BEAM, 2>), g, b, lds, st, q);
 }
+#endif
 template <bool M, bool B, bool G>
 static void launch_query_k(const QueryArgs& q, int kind, int nb, size_t lds, hipStream_t st) {
     const dim3 g(nb), b(256);
+#ifdef RPT_EXPERIMENTS
     if constexpr (M && !G) {
         if (q.r.slab2 && kind != RPT_PHOTON_MAP) return launch_query_split<B>(q, kind, nb, lds, st);
     }
+#endif
     if (kind == RPT_PHOTON_MAP) hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_MAP>), g, b, lds, st, q);
     else if (kind == RPT_PHOTON_BEAM_BEAM) hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_BEAM_BEAM>), g, b, lds, st, q);
     else hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_POINT_BEAM>), g, b, lds, st, q);
@@ -2415,6 +2420,9 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     // the split camera pass (option "photon_split"; off by default -- two launches cannot overlap the two estimates the way
     // one kernel's mix of waves does: 112 ms against 95 on C4): a second slab for the surface term
     q.r.slab2 = nullptr;
+#ifndef RPT_EXPERIMENTS
+    if (rpti::option_photon_split(s)) return rpti::fail(RPT_ERR_UNSUPPORTED, "photon_split: a rejected prototype, built with -DRPT_EXPERIMENTS only");
+#endif
     if (medium && !gg && pm->kind != RPT_PHOTON_MAP && rpti::option_photon_split(s)) {
         const size_t bytes = std::max<size_t>(size_t(q.r.n_chunks) * q.r.n_owned * 16u, 16u);
         if (bytes > pm->slab2_bytes) {

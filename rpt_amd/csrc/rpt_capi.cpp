@@ -84,6 +84,7 @@ struct rpt_options {
                                     // 0: they stay outside it and their walks are parked as in scenes without a scene tree (read by rpt_scene_commit)
     int64_t f64_cull = 1;           // reference-epsilon mode: 1 = a lane evaluates only the objects whose fp32 box its ray can reach (same bits), 0 = every object;
                                     // 2 = as 1, and the counters build keeps the search limits as well (its counters then describe the schedule, not the reference's work)
+    int64_t f64_surf_batch = 8;     // reference-epsilon mode, scenes with a medium: lanes of a wave that wait at a surface event before the wave runs the surface code (1..64)
     int64_t epsilon_policy = 0;     // 1: the reference-epsilon mode (read by rpt_scene_commit): fp64, generic shapes, t_min = 1e-12, |hit - dist| < 1e-12
 };
 static rpt_options g_defaults;
@@ -99,7 +100,12 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "photon_skip") o.photon_skip = value;
     else if (s == "photon_block_lists") o.photon_block_lists = value;
     else if (s == "photon_parts") o.photon_parts = value;
-    else if (s == "photon_split") o.photon_split = value;
+    else if (s == "photon_split") {
+#ifndef RPT_EXPERIMENTS
+        if (value != 0) return fail(RPT_ERR_UNSUPPORTED, "photon_split: a rejected prototype, built with -DRPT_EXPERIMENTS only");
+#endif
+        o.photon_split = value;
+    }
     else if (s == "photon_coop_gather") o.photon_coop_gather = value;
     else if (s == "instancing") o.instancing = value;
     else if (s == "defer_lanes") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_lanes must be 1..64"); o.defer_lanes = value; }
@@ -107,7 +113,13 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "bvh_sweep_below") { if (value < 0) return fail(RPT_ERR_INVALID, "bvh_sweep_below must be >= 0"); o.bvh_sweep_below = value; }
     else if (s == "bvh_max_depth") { if (value < 1 || value > 20) return fail(RPT_ERR_INVALID, "bvh_max_depth must be 1..20"); o.bvh_max_depth = value; }
     else if (s == "walk_leaf_quarters") { if (value < 0 || value > 256) return fail(RPT_ERR_INVALID, "walk_leaf_quarters must be 0..256"); o.walk_leaf_quarters = value; }
-    else if (s == "detach_shadows") { if (value < 0 || value > 2) return fail(RPT_ERR_INVALID, "detach_shadows must be 0, 1 or 2"); o.detach_shadows = value; }
+    else if (s == "detach_shadows") {
+        if (value < 0 || value > 2) return fail(RPT_ERR_INVALID, "detach_shadows must be 0, 1 or 2");
+#ifndef RPT_EXPERIMENTS
+        if (value == 2) return fail(RPT_ERR_UNSUPPORTED, "detach_shadows = 2 (streamed walks): a rejected prototype, built with -DRPT_EXPERIMENTS only");
+#endif
+        o.detach_shadows = value;
+    }
     else if (s == "stream_contexts") { if (value < 1 || value > 6) return fail(RPT_ERR_INVALID, "stream_contexts must be 1..6"); o.stream_contexts = value; }
     else if (s == "stream_backlog") { if (value < 1 || value > 256) return fail(RPT_ERR_INVALID, "stream_backlog must be 1..256"); o.stream_backlog = value; }
     else if (s == "detach_lanes") { if (value < 1 || value > 96) return fail(RPT_ERR_INVALID, "detach_lanes must be 1..96"); o.detach_lanes = value; }
@@ -115,6 +127,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "detach_trigger") { if (value < 1 || value > 32) return fail(RPT_ERR_INVALID, "detach_trigger must be 1..32"); o.detach_trigger = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
     else if (s == "f64_cull") { if (value < 0 || value > 2) return fail(RPT_ERR_INVALID, "f64_cull must be 0, 1 or 2"); o.f64_cull = value; }
+    else if (s == "f64_surf_batch") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "f64_surf_batch must be 1..64"); o.f64_surf_batch = value; }
     else if (s == "epsilon_policy") { if (value < 0 || value > 1) return fail(RPT_ERR_INVALID, "epsilon_policy must be 0 or 1"); o.epsilon_policy = value; }
     else if (s == "scene_tree_meshes") o.scene_tree_meshes = value;
     else if (s == "scene_bvh_min") { if (value < 0) return fail(RPT_ERR_INVALID, "scene_bvh_min must be >= 0"); o.scene_bvh_min = value; }
@@ -520,7 +533,7 @@ struct rpt_scene {
     void* arena64 = nullptr;
     rpt64::Scene view64{};
     double medium_color64[3] = {0, 0, 0}, medium_color_hi64[3] = {0, 0, 0};
-    uint64_t last_counters64[12] = {0};
+    uint64_t last_counters64[64] = {0};   // [0..11] rpt_debug_epsilon_counters, [16 + 2k], [17 + 2k] section k of kernels_f64.hip (executions, lanes)
     // mesh data interned by content (hash -> candidates), so Arc<Mesh>-style sharing survives the C ABI
     std::unordered_map<uint64_t, std::vector<std::shared_ptr<const std::vector<double>>>> mesh_pool;
     // tile cache key
@@ -1521,6 +1534,7 @@ struct Flattener {
             HIP_TRY(hipEventCreateWithFlags(&ls.launched, hipEventDisableTiming));
         }
         HIP_TRY(hipMalloc((void**)&s->d_counters, 64 * sizeof(unsigned long long)));
+        s->view.stack_overflows = s->d_counters + 7;
         s->device = device;
         s->committed = true;
         return RPT_OK;
@@ -1751,6 +1765,7 @@ static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_pa
     q.chunk_spp = a.chunk_spp; q.n_chunks = a.n_chunks;
     q.pull_batch = a.pull_batch;
     q.cull = uint32_t(s->opt.f64_cull);
+    q.surf_batch = uint32_t(s->opt.f64_surf_batch);
     q.seed_mixed = a.seed_mixed;
     q.dim = double(std::max(prm->width, prm->height));
     q.queue = a.queue;
@@ -1773,6 +1788,7 @@ static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_pa
         s->last_counters[1] = s->last_counters64[0];
         s->last_counters[2] = s->last_counters64[7];
         s->last_counters[3] = s->last_counters64[10];   // wave-level loop trips
+        for (int i = 0; i < 48; i++) s->last_counters[8 + i] = s->last_counters64[16 + i];   // rpt_debug_section_counters
     }
     return RPT_OK;
 }

@@ -43,7 +43,8 @@ void load_rccl() {
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW);
     if (!h) {
-        g_rccl.error = std::string("librccl.so.1 cannot be loaded: ") + (dlerror() ? dlerror() : "?");
+        const char* why = dlerror();   // (read once: dlerror() clears the message it returns)
+        g_rccl.error = std::string("librccl.so.1 cannot be loaded: ") + (why ? why : "?");
         return;
     }
     auto sym = [&](const char* name) -> void* {
@@ -213,20 +214,23 @@ int rpt_gather_frame_device(rpt_comm* c, uint32_t width, uint32_t height, const 
     if (c->rank == 0 && !d_frame) return fail(RPT_ERR_INVALID, "rank 0 needs the frame to assemble into");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     RPTI_HIP_TRY(hipSetDevice(c->device));
-    TileLayout& L = c->layout;
-    if (L.width != width || L.height != height || L.n_ranks != uint32_t(c->n_ranks)) {
-        // a new frame size: tile lists to the device, staging buffer (rank 0: the whole frame's tiles)
+    if (c->layout.width != width || c->layout.height != height || c->layout.n_ranks != uint32_t(c->n_ranks)) {
+        // a new frame size: tile lists to the device, staging buffer (rank 0: the whole frame's tiles).  The cached layout is
+        // replaced only once every allocation and upload has succeeded: a failure below leaves it invalid, so that the next
+        // call with the same size sets everything up again instead of launching on buffers that were never filled.
         RPTI_HIP_TRY(hipStreamSynchronize(st));   // nothing in flight may still read the old lists
-        if (int rc = build_layout(width, height, uint32_t(c->n_ranks), L)) { L.width = 0; return rc; }
-        if (L.all.size() > c->tiles_cap) {
+        c->layout.width = 0;
+        TileLayout fresh;
+        if (int rc = build_layout(width, height, uint32_t(c->n_ranks), fresh)) return rc;
+        if (fresh.all.size() > c->tiles_cap) {
             if (c->d_tiles) RPTI_HIP_TRY(hipFree(c->d_tiles));
             c->d_tiles = nullptr; c->tiles_cap = 0;
-            RPTI_HIP_TRY(hipMalloc((void**)&c->d_tiles, L.all.size() * 4));
-            c->tiles_cap = L.all.size();
+            RPTI_HIP_TRY(hipMalloc((void**)&c->d_tiles, fresh.all.size() * 4));
+            c->tiles_cap = fresh.all.size();
         }
-        RPTI_HIP_TRY(hipMemcpy(c->d_tiles, L.all.data(), L.all.size() * 4, hipMemcpyHostToDevice));
+        RPTI_HIP_TRY(hipMemcpy(c->d_tiles, fresh.all.data(), fresh.all.size() * 4, hipMemcpyHostToDevice));
         // rank 0: every rank's block + room to receive its own once more (loopback); others: their own block
-        const uint64_t tiles = c->rank == 0 ? L.offsets[L.n_ranks] + L.offsets[1] : L.offsets[c->rank + 1] - L.offsets[c->rank];
+        const uint64_t tiles = c->rank == 0 ? fresh.offsets[fresh.n_ranks] + fresh.offsets[1] : fresh.offsets[c->rank + 1] - fresh.offsets[c->rank];
         const size_t bytes = std::max<size_t>(size_t(tiles) * kTileDoubles * 8, 8);
         if (bytes > c->stage_cap) {
             if (c->d_stage) RPTI_HIP_TRY(hipFree(c->d_stage));
@@ -234,7 +238,9 @@ int rpt_gather_frame_device(rpt_comm* c, uint32_t width, uint32_t height, const 
             RPTI_HIP_TRY(hipMalloc((void**)&c->d_stage, bytes));
             c->stage_cap = bytes;
         }
+        c->layout = std::move(fresh);
     }
+    TileLayout& L = c->layout;
     const bool loop = (flags & RPT_GATHER_LOOPBACK) != 0;
     const double* shard = static_cast<const double*>(d_shard);
     double* frame = static_cast<double*>(d_frame);
@@ -280,7 +286,8 @@ int rpt_gather_frame_device(rpt_comm* c, uint32_t width, uint32_t height, const 
 
 // The photon maps' exchange step (src/photon.rs:656-690 sharded by photon index): every rank needs every rank's records, in
 // rank order.  Two ncclAllGathers -- the counts, then blocks padded to the largest count -- and one device copy per rank
-// that closes the gaps.  The counts come to the host in between (the second collective is sized by them).
+// that closes the gaps.  The counts come to the host in between (the second collective is sized by them).  With d_out = NULL and
+// capacity = 0 only the counts are exchanged (n_per_rank, n_total): how a caller learns the size of the buffer to bring.
 int rpt_allgather_records_device(rpt_comm* c, const void* d_local, uint64_t n_local, void* d_out, uint64_t capacity,
                                  uint64_t* n_per_rank, uint64_t* n_total, void* hip_stream) {
     if (!c || !n_total) return fail(RPT_ERR_INVALID, "null argument");
@@ -303,6 +310,7 @@ int rpt_allgather_records_device(rpt_comm* c, const void* d_local, uint64_t n_lo
         largest = std::max<uint64_t>(largest, counts[r]);
     }
     *n_total = total;
+    if (!d_out && capacity == 0) return RPT_OK;   // a counts-only call: the caller sizes its buffer from n_total and calls again (every rank takes this exit together)
     if (total > capacity) return fail(RPT_ERR_INVALID, "rpt_allgather_records_device: the output holds fewer records than the ranks have shot");
     if (total == 0) return RPT_OK;
     if (!d_out) return fail(RPT_ERR_INVALID, "null output");

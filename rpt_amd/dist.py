@@ -1,15 +1,16 @@
-"""One-process-per-GPU plumbing over torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the
-CPU tests).  The path has exactly two exchange steps:
+"""One-process-per-GPU plumbing.  The path has exactly two exchange steps, and both are in the
+library, behind the C ABI, over a communicator of its own (`FrameComm` = rpt_comm_*: RCCL bound with dlopen):
 
-  * frames: every rank renders its 32x32 tile shard into a zero-initialised full frame and the frames
-    are sum-reduced to rank 0 (`reduce_frame`);
-  * photon maps: the shooting loop (src/photon.rs:656-690) is sharded by photon index, every rank
-    needs the whole map, so the shot records are all-gathered in rank order (`gather_records`,
+  * frames: every rank renders its 32x32 tile shard; the owned tiles travel packed (f64) to rank 0, which scatters them
+    into its frame (`FrameComm.gather` = rpt_gather_frame_device: ncclSend / grouped ncclRecv);
+  * photon maps: the shooting loop (src/photon.rs:656-690) is sharded by photon index, every rank needs the whole map,
+    so the shot records are all-gathered in rank order (`FrameComm.allgather_records` = rpt_allgather_records_device;
     `photon_map_build_sharded`).
 
-The frame exchange itself is in the library, behind the C ABI (`FrameComm` = rpt_comm_* / rpt_gather_frame_device:
-owned tiles packed f64, ncclSend / ncclRecv to rank 0); torch.distributed is then only the launcher and the store that
-hands out the communicator id.  `reduce_frame` is the older sum-reduce of zero-padded frames through torch.
+torch.distributed is the launcher and the store that hands out the communicator id (backend "nccl" = RCCL on ROCm, "gloo"
+in the CPU tests).  `reduce_frame` (sum-reduce of zero-padded full frames) and `gather_records` are the same two steps
+through torch.distributed itself: what the CPU tests run with gloo, and the fallback when a rank cannot form the
+library's communicator.
 
 torch is imported lazily so that `import rpt_amd` stays numpy-only."""
 import ctypes as _C
@@ -45,8 +46,17 @@ class FrameComm:
         """Create the communicator of an initialised torch.distributed job: rank 0 draws the id, the job's store /
         broadcast hands it out (any backend: the id is 128 bytes of host data)."""
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [cls.unique_id() if rank == 0 else None]
+        # Rank 0 broadcasts whatever happened: were it to raise before the broadcast (librccl.so.1 missing, say), the other
+        # ranks would sit in theirs while rank 0 moves on to its next collective.
+        box = [None]
+        if rank == 0:
+            try:
+                box = [cls.unique_id()]
+            except Exception as e:   # noqa: BLE001 -- handed to every rank below
+                box = [f"{type(e).__name__}: {e}"]
         dist.broadcast_object_list(box, src=0)
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise _lib.RptError(f"rank 0 could not draw a communicator id ({box[0]})")
         return cls(box[0], rank, world, device)
 
     def gather(self, width, height, d_shard, d_frame=None, stream=None, loopback=False):
@@ -55,7 +65,8 @@ class FrameComm:
                                                        GATHER_LOOPBACK if loopback else 0, _C.c_void_p(stream) if stream else None))
 
     def allgather_records(self, d_local, n_local, d_out, capacity, stream=None):
-        """rpt_allgather_records_device: every rank's photon records in rank order -> (per-rank counts, total)."""
+        """rpt_allgather_records_device: every rank's photon records in rank order -> (per-rank counts, total).
+        With d_out = None and capacity = 0 only the counts are exchanged."""
         per = (_C.c_uint64 * self.world)()
         tot = _C.c_uint64()
         _lib.check(_lib.load().rpt_allgather_records_device(self._h, _C.c_void_p(d_local) if n_local else None, int(n_local),
@@ -142,10 +153,12 @@ def photon_map_build_sharded(renderer, photon_count, kind, rank, world, group=No
     for which in (0, 1):
         ptr, n = renderer.photon_records(which)
         if comm is not None:
+            # the counts first (a photon stores one record per scattering event: no bound short of the walk's length), then
+            # the records into a buffer of exactly that size
             st = torch.cuda.current_stream(device).cuda_stream
-            cap = max(1, 4 * photon_count)   # generous: repeated with the exact size should it ever be short
-            out = torch.empty((cap, RECORD_BYTES), dtype=torch.uint8, device=device)
-            _, total = comm.allgather_records(ptr, n, out.data_ptr(), cap, st)
+            _, total = comm.allgather_records(ptr, n, None, 0, st)
+            out = torch.empty((max(total, 1), RECORD_BYTES), dtype=torch.uint8, device=device)
+            _, total = comm.allgather_records(ptr, n, out.data_ptr(), max(total, 1), st)
             gathered.append(out[:total])
             continue
         gathered.append(gather_records(_view(ptr, n, device), group))

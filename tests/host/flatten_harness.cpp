@@ -10,7 +10,9 @@ hipError_t render_occupancy(bool, int, int* b, int) { *b = 4; return hipSuccess;
 size_t stream_scratch_bytes_per_block() { return 0; }
 int bvh_mode(const SceneView& sc) { return sc.scene_bvh ? 2 : (sc.n_nodes ? 1 : 0); }
 hipError_t launch_resolve(const RenderArgs&, double, double*, hipStream_t) { return hipSuccess; }
-hipError_t launch_render_f64(const rpt64::Args&, hipStream_t) { return hipSuccess; }
+hipError_t launch_render_f64(const rpt64::Args&, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_resolve_f64(const rpt64::Args&, double, double*, hipStream_t) { return hipSuccess; }
+hipError_t render_f64_occupancy(bool, int* blocks_per_cu) { *blocks_per_cu = 4; return hipSuccess; }
 hipError_t launch_intersect(const SceneView&, uint64_t, const float*, const float*, float*, int32_t*, float*, bool, hipStream_t) { return hipSuccess; }
 hipError_t launch_debug_rng(uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*, hipStream_t) { return hipSuccess; }
 hipError_t launch_debug_sample_f(const Material&, uint64_t, const float*, const float*, uint64_t, float*, float*, int32_t*, hipStream_t) { return hipSuccess; }

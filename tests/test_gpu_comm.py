@@ -93,3 +93,50 @@ def test_one_rank_all_gather_of_photon_records():
             comm.allgather_records(rec.data_ptr(), rec.shape[0], out.data_ptr(), 10)
     finally:
         comm.close()
+
+
+def test_counts_only_call_and_a_medium_that_stores_many_records_per_photon():
+    """rpt_allgather_records_device with d_out = NULL, capacity = 0 exchanges the counts only; the sharded map build sizes
+    its buffers from it.  In a dense, nearly non-absorbing medium a photon stores far more than four records (the walk goes
+    on with probability sigma_s / sigma_t): the comm path must build the same map as the single-process call."""
+    import torch
+    from rpt_amd import Renderer, scenes
+    from rpt_amd.dist import photon_map_build_sharded
+    comm = FrameComm(FrameComm.unique_id(), 0, 1, 0)
+    try:
+        rec = torch.randint(0, 256, (77, 48), dtype=torch.uint8, device="cuda")
+        per, total = comm.allgather_records(rec.data_ptr(), 77, None, 0)
+        assert per == [77] and total == 77
+        stats = []
+        for use_comm in (False, True):
+            scene, cam, cfg = scenes.lampshade(absorb=0.0002, scat=0.02)   # albedo 0.99, mean free path 50 in a 550-unit room
+            r = Renderer(scene, cam).width(32).height(32).gather_size(20).gather_size_volume(3).watts(1000.0)
+            if use_comm:
+                stats.append(photon_map_build_sharded(r, 5000, Renderer.PHOTON_POINT_BEAM, 0, 1, comm=comm))
+            else:
+                stats.append(r.photon_map_build(5000, Renderer.PHOTON_POINT_BEAM))
+        for k in ("surface", "volume", "shot"):
+            assert stats[0][k] == stats[1][k], k
+        assert stats[0]["volume"] > 4 * 5000     # (what a buffer of 4 x photon_count records could not hold)
+    finally:
+        comm.close()
+
+
+def test_two_ranks_assemble_the_single_gpu_frame_and_map():
+    """Two processes, two GPUs (skipped on a one-GPU box): the gathered frame and the all-gathered photon records equal the
+    single-GPU arrays bit for bit -- rank 0's staging offsets, the one unpack over the other ranks' blocks, the non-root
+    ncclSend and the padded all-gather with unequal counts all take part.  The ranks are started before anything touches a
+    GPU in this process's children (tests/mp_comm_worker.py under torch.distributed.run)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "tests", "mp_comm_worker.py")]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "frames equal" in out.stdout and "records equal" in out.stdout

@@ -173,3 +173,16 @@ def test_launches_on_two_streams_overlap_without_sharing_their_slab():
     torch.cuda.synchronize()
     for i, f in enumerate(frames):
         assert np.array_equal(f.cpu().numpy().reshape(-1, 3), expect[i % 3])
+
+
+def test_no_tree_walk_ever_finds_its_stack_full():
+    """bvh_traverse drops the far child when its stack is full; rpt_scene_commit refuses scenes whose trees are deep enough for
+    that.  The counters build counts the event (rpt_get_counters()[7]): zero on the per-mesh-tree and the scene-tree flavours."""
+    from rpt_amd import Renderer, scenes
+    for make in (lambda: scenes.mesh_in_fog(48, 48), lambda: scenes.fractal_spheres(4)):
+        scene, cam, cfg = make()
+        scene.set_option("counters", 1)
+        r = Renderer(scene, cam).width(96).height(96).max_bounces(cfg["max_bounces"]).seed(1)
+        r.sample_array(4)
+        c = r.counters()
+        assert c["bvh_nodes"] > 0 and c["stack_overflows"] == 0

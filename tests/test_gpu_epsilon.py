@@ -142,6 +142,19 @@ def test_box_culling_does_not_change_a_bit(name, size, spp):
     assert counts[0]["objects_evaluated"] < counts[1]["objects_evaluated"]
 
 
+def test_parked_surface_events_do_not_depend_on_the_threshold():
+    """In a medium a lane whose query ends in a surface event waits until "f64_surf_batch" lanes of its wave do (or nothing
+    else is left to do).  Every lane draws its own numbers in its own order, so the frame keeps its bits."""
+    frames = []
+    for batch in (1, 5, 16, 64):
+        scene, cam, cfg = scenes.CONFIGS["C3"]()
+        scene.set_option("epsilon_policy", 1)
+        scene.set_option("f64_surf_batch", batch)
+        frames.append(Renderer(scene, cam).width(160).height(96).max_bounces(cfg["max_bounces"]).seed(2).sample_array(24))
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
+
+
 def test_what_the_mode_refuses():
     from rpt_amd import KdTree
     sc = Scene()

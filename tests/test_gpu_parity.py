@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from rpt_amd import Camera, Material, Object, Renderer, Scene, plane, scenes, vec3
+from rpt_amd import Camera, Material, Object, Renderer, RptError, Scene, plane, scenes, vec3
 from rpt_amd import _lib
 from tests.util import random_rays, rel_rms
 
@@ -366,8 +366,13 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
             rpt_amd.set_option("pull_batch", 2)
         # streamed walks (DETACH = 2): primary queries leave as well, their paths wait in memory; session threshold and exit rule
         streamed = []
+        have_streamed = fog
         if fog:
-            rpt_amd.set_option("detach_shadows", 2)
+            try:
+                rpt_amd.set_option("detach_shadows", 2)
+            except RptError:   # a rejected prototype: in the library only when it is built with -DRPT_EXPERIMENTS
+                have_streamed = False
+        if have_streamed:
             for backlog, stop, contexts in ((128, 16, 4), (1, 1, 1), (256, 64, 6), (64, 32, 2), (200, 1, 3), (48, 16, 1)):
                 rpt_amd.set_option("stream_backlog", backlog)
                 rpt_amd.set_option("stream_contexts", contexts)
@@ -397,7 +402,8 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
     if fog:   # the same algorithm in another kernel: last bits, and the odd path whose fp32 decision falls the other way (1e-6 per decision)
         assert rel_rms(detached[0], frames[0]) < 2e-4 and abs(detached[0].mean() - frames[0].mean()) < 1e-5 * frames[0].mean()
         assert rel_rms(detached[0], exp) < 2e-2 and abs(detached[0].mean() - exp.mean()) / exp.mean() < 5e-3
-        assert rel_rms(streamed[0], frames[0]) < 2e-4 and abs(streamed[0].mean() - frames[0].mean()) < 1e-5 * frames[0].mean()
+        if streamed:
+            assert rel_rms(streamed[0], frames[0]) < 2e-4 and abs(streamed[0].mean() - frames[0].mean()) < 1e-5 * frames[0].mean()
         assert rel_rms(streamed[0], exp) < 2e-2 and abs(streamed[0].mean() - exp.mean()) / exp.mean() < 5e-3
 
 
