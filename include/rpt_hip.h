@@ -335,6 +335,11 @@ int rpt_debug_material_sample_f(const rpt_material*, uint64_t n, const float* no
                                 uint64_t seed, float* wi, float* pdf, int32_t* some);
 int rpt_debug_material_bsdf(const rpt_material*, uint64_t n, const float* normals, const float* wos,
                             const float* wis, float* out_rgb);
+/* sort_scan.h, the photon-map build's own device-wide primitives (host arrays in and out): the stable radix sort of 64-bit keys --
+ * keys_out = the keys in ascending order, order_out[i] = input position of the i-th (equal keys keep their input order) -- and the
+ * exclusive prefix sums of two u32 arrays with their 64-bit totals. */
+int rpt_debug_radix_sort(uint64_t n, const uint64_t* keys, uint64_t* keys_out, uint32_t* order_out);
+int rpt_debug_exclusive_scan2(uint64_t n, const uint32_t* a, const uint32_t* b, uint32_t* out_a, uint32_t* out_b, uint64_t totals[2]);
 int rpt_debug_camera_rays(const rpt_camera*, const rpt_render_params*, uint64_t seed, uint32_t sample,
                           float* origins, float* dirs); /* one ray per pixel, width*height*3 each */
 

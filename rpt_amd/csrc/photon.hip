@@ -8,7 +8,6 @@
 //   * the per-photon gather radius = distance to the 10th nearest volume photon (:214-232);
 //   * the camera pass (get_color_with_photon_map / estimate_indirect, :316-628, :950-985) as a
 //     persistent kernel sharing the path tracer's work queue, slab and resolve.
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -20,6 +19,7 @@
 #include "device_core.h"
 #include "host_internal.h"
 #include "kernels.h"
+#include "sort_scan.h"
 
 namespace rptg {
 
@@ -223,13 +223,19 @@ __global__ void morton_kernel(const PhotonRec* p, uint32_t n, const float* lohi,
     keys[i] = (expand21(x) << 2) | (expand21(y) << 1) | expand21(z);
     vals[i] = i;
 }
-__global__ void gather_kernel(const PhotonRec* in, const uint32_t* perm, uint32_t n, PhotonRec* out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    PhotonRec r = in[perm[i]];
-    r.dir.w = __uint_as_float(perm[i]);
-    out[i] = r;
-}
+// The last pass of the radix sort (sort_scan.h) hands every (position, key, photon index) to this: the sorted key (Karras'
+// construction reads them) and the photon's record, its index in shooting order kept in dir.w -- the gather is part of the sort.
+struct GatherPhotons {
+    const PhotonRec* in;
+    PhotonRec* out;
+    uint64_t* keys_out;
+    __device__ __forceinline__ void operator()(uint32_t dst, uint64_t key, uint32_t val) const {
+        PhotonRec r = in[val];
+        r.dir.w = __uint_as_float(val);
+        out[dst] = r;
+        keys_out[dst] = key;
+    }
+};
 RPT_DEV int lcp(const uint64_t* keys, int n, int i, int j) {  // Karras' delta with index tie-break
     if (j < 0 || j >= n) return -1;
     uint64_t a = keys[i], b = keys[j];
@@ -2025,16 +2031,15 @@ int build_lbvh(DevPool& pool, PhotonRec* raw, uint32_t n, int mode, DevLbvh& out
     uint32_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(bounds_kernel, dim3(std::min(blocks, 1024u)), dim3(256), 0, st, raw, n, lohi, first_mode);
     hipLaunchKernelGGL(morton_kernel, dim3(blocks), dim3(256), 0, st, raw, n, lohi, keys, vals, first_mode);
-    size_t temp_bytes = 0;
-    RPTI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys2, vals, vals2, int(n), 0, 63, st));
-    void* temp;
-    RPTI_HIP_TRY(tmp.alloc((char**)&temp, temp_bytes));
-    RPTI_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, int(n), 0, 63, st));
+    // stable radix sort of (Morton key, photon index), eight 8-bit passes; the last one gathers the records (sort_scan.h).  Equal keys
+    // keep their shooting order, so the sorted array -- and with it the tree -- is a function of the photons alone.
+    char* temp;
+    RPTI_HIP_TRY(tmp.alloc(&temp, ss::rsort_temp_bytes(n)));
     RPTI_HIP_TRY(pool.alloc((void**)&out.sorted, size_t(n) * sizeof(PhotonRec)));
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, raw, vals2, n, out.sorted);
+    RPTI_HIP_TRY(ss::radix_sort_pairs(keys, vals, keys2, vals2, n, 8u, temp, GatherPhotons{raw, out.sorted, keys}, st));   // (pass 7 reads keys2 / vals2: keys is free for the sorted keys)
     if (n >= 2) {
         RPTI_HIP_TRY(pool.alloc((void**)&out.nodes, size_t(n - 1) * sizeof(BvhNode)));
-        hipLaunchKernelGGL(karras_kernel, dim3(blocks), dim3(256), 0, st, keys2, int(n), left, right, par_i, par_l, rlo, rhi);
+        hipLaunchKernelGGL(karras_kernel, dim3(blocks), dim3(256), 0, st, keys, int(n), left, right, par_i, par_l, rlo, rhi);
         RPTI_HIP_TRY(hipMemsetAsync(flags, 0, size_t(n) * 4, st));
         hipLaunchKernelGGL(refit_small_kernel, dim3(blocks), dim3(256), 0, st, out.sorted, int(n), rlo, rhi, box, first_mode);
         hipLaunchKernelGGL(refit_kernel, dim3(2u * blocks), dim3(256), 0, st, out.sorted, int(n), left, right, par_i, par_l, rlo, rhi, flags, box, first_mode);
@@ -2060,9 +2065,6 @@ int build_lbvh(DevPool& pool, PhotonRec* raw, uint32_t n, int mode, DevLbvh& out
     return RPT_OK;
 }
 
-struct Widen {
-    __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; }
-};
 template <bool W>
 hipError_t launch_shoot(const ShootArgs& a, bool medium, bool bvh, int blocks, hipStream_t st) {
     size_t lds = bvh ? 32u * 256u * 4u : 0;
@@ -2156,22 +2158,12 @@ static int shoot_range(rpt_scene* s, PhotonMapDev* pm, uint64_t photon_count, ui
     uint32_t *d_os, *d_ov;
     RPTI_HIP_TRY(tmp.alloc(&d_os, n));
     RPTI_HIP_TRY(tmp.alloc(&d_ov, n));
-    size_t scan_bytes = 0;
-    RPTI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, a.cnt_s, d_os, int(n), st));
+    // (totals in 64 bits: the 32-bit offsets are only used once the totals are known to fit)
     char* scan_tmp;
-    RPTI_HIP_TRY(tmp.alloc(&scan_tmp, scan_bytes));
-    RPTI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, a.cnt_s, d_os, int(n), st));
-    RPTI_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, a.cnt_v, d_ov, int(n), st));
-    // totals in 64 bits (the 32-bit offsets are only used once the totals are known to fit)
+    RPTI_HIP_TRY(tmp.alloc(&scan_tmp, std::max<size_t>(ss::scan2_temp_bytes(uint32_t(n)), 8)));
     unsigned long long* d_tot;
     RPTI_HIP_TRY(tmp.alloc(&d_tot, 2));
-    hipcub::TransformInputIterator<unsigned long long, Widen, const uint32_t*> in_s(a.cnt_s, Widen{}), in_v(a.cnt_v, Widen{});
-    size_t red_bytes = 0;
-    RPTI_HIP_TRY(hipcub::DeviceReduce::Sum(nullptr, red_bytes, in_s, d_tot, int(n), st));
-    char* red_tmp;
-    RPTI_HIP_TRY(tmp.alloc(&red_tmp, red_bytes));
-    RPTI_HIP_TRY(hipcub::DeviceReduce::Sum(red_tmp, red_bytes, in_s, d_tot, int(n), st));
-    RPTI_HIP_TRY(hipcub::DeviceReduce::Sum(red_tmp, red_bytes, in_v, d_tot + 1, int(n), st));
+    RPTI_HIP_TRY(ss::exclusive_scan2(a.cnt_s, a.cnt_v, uint32_t(n), d_os, d_ov, d_tot, scan_tmp, st));
     unsigned long long tot[2] = {0, 0};
     RPTI_HIP_TRY(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, st));
     RPTI_HIP_TRY(hipStreamSynchronize(st));
@@ -2464,6 +2456,64 @@ int rpt_photon_render_sample_device(rpt_scene* s, const rpt_camera* cam, const r
     if (!s || !cam || !prm || !d_out_rgb) return rpti::fail(RPT_ERR_INVALID, "null argument");
     return photon_render_impl(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset,
                               static_cast<double*>(d_out_rgb), static_cast<hipStream_t>(hip_stream), true);
+}
+
+
+// ---- test hooks of sort_scan.h (host arrays in and out)
+int rpt_debug_radix_sort(uint64_t n, const uint64_t* keys, uint64_t* keys_out, uint32_t* order_out) {
+    if (n && (!keys || !keys_out || !order_out)) return rpti::fail(RPT_ERR_INVALID, "null argument");
+    if (n >= (1ull << 31)) return rpti::fail(RPT_ERR_INVALID, "too many pairs");
+    if (n == 0) return RPT_OK;
+    const uint32_t m = uint32_t(n);
+    uint64_t *k0 = nullptr, *k1 = nullptr;
+    uint32_t *v0 = nullptr, *v1 = nullptr;
+    char* temp = nullptr;
+    auto cleanup = [&]() { (void)hipFree(k0); (void)hipFree(k1); (void)hipFree(v0); (void)hipFree(v1); (void)hipFree(temp); };
+    std::vector<uint32_t> iota(m);
+    for (uint32_t i = 0; i < m; i++) iota[i] = i;
+    hipError_t e = hipMalloc((void**)&k0, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&k1, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&v0, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&v1, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&temp, ss::rsort_temp_bytes(m));
+    if (e == hipSuccess) e = hipMemcpy(k0, keys, n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v0, iota.data(), n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = ss::radix_sort_pairs(k0, v0, k1, v1, m, 8u, temp, ss::StorePair{k0, v0}, nullptr);   // (pass 7 reads k1 / v1)
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(keys_out, k0, n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(order_out, v0, n * 4, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return rpti::fail(RPT_ERR_DEVICE, std::string("rpt_debug_radix_sort: ") + hipGetErrorString(e));
+    return RPT_OK;
+}
+int rpt_debug_exclusive_scan2(uint64_t n, const uint32_t* a, const uint32_t* b, uint32_t* out_a, uint32_t* out_b, uint64_t totals[2]) {
+    if (!totals || (n && (!a || !b || !out_a || !out_b))) return rpti::fail(RPT_ERR_INVALID, "null argument");
+    if (n >= (1ull << 31)) return rpti::fail(RPT_ERR_INVALID, "too many values");
+    const uint32_t m = uint32_t(n);
+    uint32_t *da = nullptr, *db = nullptr, *oa = nullptr, *ob = nullptr;
+    unsigned long long* dt = nullptr;
+    char* temp = nullptr;
+    auto cleanup = [&]() { (void)hipFree(da); (void)hipFree(db); (void)hipFree(oa); (void)hipFree(ob); (void)hipFree(dt); (void)hipFree(temp); };
+    const size_t bytes = std::max<size_t>(n * 4, 4);
+    hipError_t e = hipMalloc((void**)&da, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&db, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&oa, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&ob, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&dt, 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&temp, std::max<size_t>(ss::scan2_temp_bytes(m), 8));
+    if (e == hipSuccess && n) e = hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = ss::exclusive_scan2(da, db, m, oa, ob, dt, temp, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && n) e = hipMemcpy(out_a, oa, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n) e = hipMemcpy(out_b, ob, n * 4, hipMemcpyDeviceToHost);
+    unsigned long long t[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(t, dt, 16, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return rpti::fail(RPT_ERR_DEVICE, std::string("rpt_debug_exclusive_scan2: ") + hipGetErrorString(e));
+    totals[0] = t[0];
+    totals[1] = t[1];
+    return RPT_OK;
 }
 
 }  // extern "C"

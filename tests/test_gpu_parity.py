@@ -404,7 +404,7 @@ def test_deferred_tree_walks_do_not_depend_on_the_schedule(fog):
         assert rel_rms(detached[0], exp) < 2e-2 and abs(detached[0].mean() - exp.mean()) / exp.mean() < 5e-3
         if streamed:
             assert rel_rms(streamed[0], frames[0]) < 2e-4 and abs(streamed[0].mean() - frames[0].mean()) < 1e-5 * frames[0].mean()
-        assert rel_rms(streamed[0], exp) < 2e-2 and abs(streamed[0].mean() - exp.mean()) / exp.mean() < 5e-3
+            assert rel_rms(streamed[0], exp) < 2e-2 and abs(streamed[0].mean() - exp.mean()) / exp.mean() < 5e-3
 
 
 def test_too_deep_mesh_tree_is_rebuilt_balanced_with_the_same_hits():
