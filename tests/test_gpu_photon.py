@@ -120,7 +120,9 @@ def test_c4_at_its_configured_one_million_photons():
         json.dump(out, f, indent=1)
     print(out)
     assert err256 < 5e-3 and abs(bias256) < 1e-3
-    assert err_lit < 3e-2 and abs(bias_lit) < 1e-2     # (tightened to the measured interval once known: DESIGN.md section 2)
+    # measured (round 4): 8.5e-3 / +0.69 % -- the same as the robust oracle against the literal one (8.5e-3 / +0.69 %): what separates
+    # this library's C4 from rpt's is the epsilon policy, not the fp32 arithmetic
+    assert err_lit < 1.2e-2 and 4e-3 < bias_lit < 1e-2
 
 
 def test_photon_map_is_deterministic_and_seeded():
