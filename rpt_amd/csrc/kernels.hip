@@ -333,6 +333,7 @@ void render_kernel(const RenderArgs a) {
     uint32_t pool_chunk = 0, pool_x0 = 0, pool_y0 = 0;  // wave-uniform: the batch's chunk and 8x8 block origin
 
     uint32_t c_samples = 0, c_rays = 0, c_vertices = 0, c_trips = 0, c_nodes = 0, c_btris = 0;
+    uint32_t c_nodes_primary = 0;   // (detached kernel) tree nodes visited by the parked primary walks in the sessions
     uint32_t c_wave[2] = {0, 0}, w_tot[2] = {0, 0};   // steps of the deferred walks (descent, triangles): of the walk at hand as its lanes count them; wave-level totals
 
     // ---- per-mesh-tree flavours (BVH == 1; BVH == 3: the same beside a scene tree that holds everything else): deferred walks.  In fog most rays never reach a mesh, a few walk
@@ -998,7 +999,7 @@ void render_kernel(const RenderArgs a) {
                             if (COUNT) c_wave[0]++;
                             if (!inner) continue;
                             const BvhNode nd = nodes[cur];
-                            if (COUNT) c_nodes++;
+                            if (COUNT) { c_nodes++; if (mode == 1u) c_nodes_primary++; }
                             float n0, f0, n1, f1;
                             slab2(nd.lo0, nd.hi0, wo, inv, n0, f0);
                             slab2(nd.lo1, nd.hi1, wo, inv, n1, f1);
@@ -1315,6 +1316,7 @@ void render_kernel(const RenderArgs a) {
         if ((threadIdx.x & 63u) == 0) atomicAdd(&a.counters[3], (unsigned long long)c_trips);
         if ((threadIdx.x & 63u) == 0) { atomicAdd(&a.counters[46], (unsigned long long)w_tot[0]); atomicAdd(&a.counters[47], (unsigned long long)w_tot[1]); }
         atomicAdd(&a.counters[5], (unsigned long long)c_nodes);
+        if (c_nodes_primary) atomicAdd(&a.counters[61], (unsigned long long)c_nodes_primary);
         atomicAdd(&a.counters[6], (unsigned long long)c_btris);
     }
 }

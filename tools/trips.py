@@ -19,6 +19,9 @@ r = Renderer(scene, cam).width(min(cfg["width"], 1024)).height(min(cfg["height"]
 if len(sys.argv) > 3:
     rpt_amd.set_option("detach_shadows", int(sys.argv[3]))
 import os  # noqa: E402
+for kv in os.environ.get("RPT_OPTS", "").split(","):   # e.g. RPT_OPTS=walk_steal=0,detach_lanes=32
+    if kv:
+        rpt_amd.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 if os.environ.get("CHUNK_SPP"):
     rpt_amd.set_option("chunk_spp", int(os.environ["CHUNK_SPP"]))
 rpt_amd.set_option("counters", 1)
@@ -32,6 +35,8 @@ for k, nm in enumerate(NAMES):
     w, l = int(out[2 * k]), int(out[2 * k + 1])
     if w:
         print(f"  {nm:48s} execs/trip {w / c['wave_trips']:.3f}   lanes {l / w:5.1f} / 64")
+if int(out[53]):   # counters[61]
+    print(f"  tree nodes visited by parked PRIMARY walks: {int(out[53]) / max(c['bvh_nodes'], 1):.3f} of all")
 if int(out[38]):
     nd, tr = int(out[38]), int(out[39])   # wave-level steps of the deferred walks: descent, triangles
     print(f"  deferred walks: {nd / c['wave_trips']:.2f} descent steps per trip with {c['bvh_nodes'] / nd:5.1f} / 64 lanes, "
