@@ -55,12 +55,25 @@ struct CullBox {
     float hi[3];
     uint32_t _pad;
 };
-// What Shape::intersect of one object needs, read per lane (every lane may hold a different object): 160 bytes.
+// What Shape::intersect of one object needs, read per lane (every lane may hold a different object): 176 bytes.
+// A shape inside `KdTree<Box<dyn Bounded>>` groups (src/kdtree.rs:103-146) is a record of its own -- the group's kd-tree is an
+// acceleration structure, its children are tested like the triangles of a mesh --; `frame` lists the groups around it, outermost
+// first: each transforms the ray (when the group itself is `Transformed`) and applies KdTree::intersect's bounds test.
+static constexpr uint32_t kMaxFrames = 3u;
 struct ObjRec {
     int32_t kind, has_xf;
     uint32_t tri_first, tri_count;
+    uint32_t n_frames, frame[kMaxFrames];
     double inv[12];   // rows of M^-1 (3 x 4)
     double b[6];      // SH_MESH: KdTree::bounds min, max; SH_CUBE: -0.5 x 3, 0.5 x 3 (src/shape/cube.rs:25-26); SH_PLANE: normal, value
+};
+struct FrameRec {     // one group level: 144 bytes
+    double inv[12];   // rows of the group's own M^-1 (has_xf)
+    double b[6];      // KdTree::bounds of the group (src/kdtree.rs:108-113), in the group's own space
+};
+struct FrameShade {
+    int32_t has_xf, _pad;
+    double nrm[9];    // (linear)^-T of the group's own transform
 };
 // Triangle::intersect (src/shape/mesh.rs:50-83) with everything that depends on the triangle alone evaluated once, on
 // the host, by the same IEEE operations in the same order (no contraction): the plane normal normalize(cross(d0, d1)),
@@ -79,9 +92,11 @@ struct TriShade {
 };
 
 struct Scene {
-    const CullBox* cull;        // [n_objects]
+    const CullBox* cull;        // [n_objects]: one per record (a group's children are records of their own)
     const ObjRec* recs;         // [n_objects]
     const ObjShade* shade;      // [n_objects]
+    const FrameRec* frames;     // group levels (ObjRec::frame)
+    const FrameShade* fshade;
     const TriRec* trecs;        // [n_obj_tris]: the triangles of scene.objects' meshes
     const TriShade* tshade;     // [n_obj_tris]
     const Tri* tris;            // [n_tris]: vertices and normals as given -- the objects' triangles, then those of the lights' meshes (Triangle::sample)

@@ -133,9 +133,30 @@ R64_DEV PairHit eval_pair(RP recs, TP trecs, uint32_t i, D o, D d) {
     const auto& r = recs[i];
     const int32_t kind = r.kind;
     D ol = o, dl = d;
+    double bm = -kInf;
+    // the groups around the shape, outermost first: Transformed::intersect's ray map (when the group is transformed), then
+    // KdTree::intersect's bounds test (src/kdtree.rs:132-139) on the empty record
+    for (uint32_t f = 0; f < r.n_frames; f++) {
+        const FrameRec& F = KA.sc.frames[r.frame[f]];
+        if (KA.sc.fshade[r.frame[f]].has_xf) {
+            const D p = xf_point(F.inv, ol), q = xf_dir(F.inv, dl);
+            ol = p;
+            dl = q;
+        }
+        const double x1 = (F.b[0] - ol.x) / dl.x, x2 = (F.b[3] - ol.x) / dl.x;
+        const double y1 = (F.b[1] - ol.y) / dl.y, y2 = (F.b[4] - ol.y) / dl.y;
+        const double z1 = (F.b[2] - ol.z) / dl.z, z2 = (F.b[5] - ol.z) / dl.z;
+        const double b_min = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmin(z1, z2));
+        const double b_max = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
+        const double g = fmax(b_min, kEps);
+        if (g > fmin(b_max, kInf)) return h;
+        bm = fmax(bm, g);
+    }
+    h.bm = bm;
     if (r.has_xf) {
-        ol = xf_point(r.inv, o);
-        dl = xf_dir(r.inv, d);
+        const D p = xf_point(r.inv, ol), q = xf_dir(r.inv, dl);
+        ol = p;
+        dl = q;
     }
     if (kind == SH_PLANE) {   // Plane::intersect, src/shape/plane.rs:17-32
         SECT64(6);
@@ -197,8 +218,9 @@ R64_DEV PairHit eval_pair(RP recs, TP trecs, uint32_t i, D o, D d) {
             SECT64(10);
             const double b_min = fmax(fmax(fmin(x1, x2), fmin(y1, y2)), fmin(z1, z2));
             const double b_max = fmin(fmin(fmax(x1, x2), fmax(y1, y2)), fmax(z1, z2));
-            h.bm = fmax(b_min, kEps);
-            if (!(h.bm > fmin(b_max, kInf))) {
+            const double own = fmax(b_min, kEps);
+            h.bm = fmax(bm, own);
+            if (!(own > fmin(b_max, kInf))) {
                 for (uint32_t j = 0; j < r.tri_count; j++) {   // Triangle::intersect, src/shape/mesh.rs:50-83
                     SECT64(11);
                     const auto& tr = trecs[r.tri_first + j];
@@ -360,9 +382,17 @@ R64_DEV D hit_normal(RP recs, TP trecs, const Query& q, D o, D d) {
         n = -(normalize(ld(r.b))) * (q.aux ? -1.0 : 1.0);
     } else {
         D ol = o, dl = d;
+        for (uint32_t f = 0; f < r.n_frames; f++)
+            if (KA.sc.fshade[r.frame[f]].has_xf) {
+                const FrameRec& F = KA.sc.frames[r.frame[f]];
+                const D p = xf_point(F.inv, ol), q2 = xf_dir(F.inv, dl);
+                ol = p;
+                dl = q2;
+            }
         if (r.has_xf) {
-            ol = xf_point(r.inv, o);
-            dl = xf_dir(r.inv, d);
+            const D p = xf_point(r.inv, ol), q2 = xf_dir(r.inv, dl);
+            ol = p;
+            dl = q2;
         }
         if (r.kind == SH_SPHERE) {
             n = normalize(ol + q.t * dl);   // src/shape/sphere.rs:40
@@ -377,6 +407,10 @@ R64_DEV D hit_normal(RP recs, TP trecs, const Query& q, D o, D d) {
         }
     }
     if (r.has_xf) n = normalize(mul3(KA.sc.shade[q.obj].nrm, n));
+    for (uint32_t f = r.n_frames; f != 0u; f--) {   // the groups' own Transformed::intersect, innermost first
+        const FrameShade& fs = KA.sc.fshade[r.frame[f - 1u]];
+        if (fs.has_xf) n = normalize(mul3(fs.nrm, n));
+    }
     return n;
 }
 
@@ -561,7 +595,7 @@ static constexpr uint32_t kTabBase = (kColsD + kColsU / 2u) * 256u;
 static constexpr uint32_t kObjDoubles = sizeof(ObjRec) / 8u, kTriDoubles = sizeof(TriRec) / 8u;
 static constexpr uint32_t kSlotBase = kTabBase + kLdsObjs * kObjDoubles + kLdsTris * kTriDoubles;   // 4 waves x 64 dwords: the pairs of a chunk
 static constexpr uint32_t kLdsDoubles = kSlotBase + 4u * 32u;
-static_assert(sizeof(ObjRec) == 160 && sizeof(TriRec) == 128 && sizeof(CullBox) == 32, "record sizes");
+static_assert(sizeof(ObjRec) == 176 && sizeof(TriRec) == 128 && sizeof(CullBox) == 32 && sizeof(FrameRec) == 144, "record sizes");
 static_assert(kLdsDoubles * 8u * 4u <= 160u * 1024u, "four blocks per CU");
 
 template <bool MEDIUM, bool COUNT, bool LDSTAB>

@@ -1550,15 +1550,21 @@ struct Flattener {
 #pragma clang fp contract(off)
 static int check_scene64(const rpt_scene* s) {   // what the mode refuses, before anything is allocated
     if (s->hdri_w) return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports Environment::Color only");
+    std::function<int(const HShape&)> depth = [&](const HShape& h) {   // group levels around the deepest shape
+        int d = 0;
+        for (const HShape& c : h.children) d = std::max(d, depth(c));
+        return d + (h.d.kind == RPT_SHAPE_GROUP ? 1 : 0);
+    };
     for (const auto& o : s->objects)
-        if (o.shape.d.kind == RPT_SHAPE_GROUP)
-            return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports sphere, cube, plane and mesh shapes (no KdTree groups)");
+        if (depth(o.shape) > int(rpt64::kMaxFrames))
+            return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports KdTree groups nested at most three deep");
     for (const auto& l : s->lights)
         if (l.kind == int(L_OBJECT) && l.obj.shape.d.kind == RPT_SHAPE_GROUP)
-            return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports sphere, cube, plane and mesh shapes (no KdTree groups)");
+            return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 does not support a KdTree group as a Light::Object");
     return RPT_OK;
 }
-static int fill_shape64(const HShape& hs, rpt64::Shape& o, std::vector<rpt64::Tri>& tris, std::vector<double>& tri_pdf) {
+static int fill_shape64(const HShape& hs, rpt64::Shape& o, std::vector<rpt64::Tri>& tris, std::vector<double>& tri_pdf,
+                        std::unordered_map<const std::vector<double>*, uint32_t>* shared = nullptr) {
     if (hs.d.kind == RPT_SHAPE_GROUP)
         return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports sphere, cube, plane and mesh shapes (no KdTree groups)");
     std::memset(&o, 0, sizeof(o));
@@ -1575,12 +1581,22 @@ static int fill_shape64(const HShape& hs, rpt64::Shape& o, std::vector<rpt64::Tr
     o.plane[3] = hs.d.plane_value;
     if (hs.d.kind == RPT_SHAPE_MESH) {
         const std::vector<double>& T = hs.T();
-        o.tri_first = uint32_t(tris.size());
+        // (an `Arc<Mesh>` used by several shapes keeps one copy of its triangles)
+        const auto known = (shared && hs.mesh) ? shared->find(hs.mesh.get()) : decltype(shared->end()){};
+        const bool have = shared && hs.mesh && known != shared->end();
+        o.tri_first = have ? known->second : uint32_t(tris.size());
         o.tri_count = uint32_t(T.size() / 18);
+        if (shared && hs.mesh && !have) (*shared)[hs.mesh.get()] = o.tri_first;
         for (int k = 0; k < 3; k++) { o.bmin[k] = std::numeric_limits<double>::infinity(); o.bmax[k] = -o.bmin[k]; }
         for (size_t t = 0; t < T.size() / 18; t++) {
             rpt64::Tri tr;
             std::memcpy(&tr, T.data() + t * 18, sizeof(tr));
+            for (int v = 0; v < 3; v++)   // Triangle::bounding_box merged over the mesh (src/kdtree.rs:108-113)
+                for (int k = 0; k < 3; k++) {
+                    o.bmin[k] = std::min(o.bmin[k], T[t * 18 + v * 3 + k]);
+                    o.bmax[k] = std::max(o.bmax[k], T[t * 18 + v * 3 + k]);
+                }
+            if (have) continue;
             tris.push_back(tr);
             // Triangle::sample's pdf (src/shape/mesh.rs:96-98) over KdTree::sample's choice (src/kdtree.rs:141-146)
             const double e0[3] = {tr.v2[0] - tr.v1[0], tr.v2[1] - tr.v1[1], tr.v2[2] - tr.v1[2]};
@@ -1588,11 +1604,6 @@ static int fill_shape64(const HShape& hs, rpt64::Shape& o, std::vector<rpt64::Tr
             const double cx = e0[1] * e1[2] - e0[2] * e1[1], cy = e0[2] * e1[0] - e0[0] * e1[2], cz = e0[0] * e1[1] - e0[1] * e1[0];
             const double area = 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
             tri_pdf.push_back((1.0 / area) / double(o.tri_count));
-            for (int v = 0; v < 3; v++)   // Triangle::bounding_box merged over the mesh (src/kdtree.rs:108-113)
-                for (int k = 0; k < 3; k++) {
-                    o.bmin[k] = std::min(o.bmin[k], T[t * 18 + v * 3 + k]);
-                    o.bmax[k] = std::max(o.bmax[k], T[t * 18 + v * 3 + k]);
-                }
         }
     }
     return RPT_OK;
@@ -1651,35 +1662,152 @@ static rpt64::CullBox cull_box64(const rpt64::Shape& sh) {
     if (!finite) { c = rpt64::CullBox{}; c.unbounded = 1u; }   // (a box fp32 cannot hold: always evaluated)
     return c;
 }
+// Bounded::bounding_box of a shape in its parent's space (src/shape/*.rs, src/kdtree.rs:108-113, src/shape.rs:154-176: a
+// Transformed shape's box is the box of the eight transformed corners of the inner box).
+struct Box64 {
+    double lo[3], hi[3];
+};
+static Box64 bbox64(const HShape& hs) {
+    Box64 b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = std::numeric_limits<double>::infinity(); b.hi[k] = -b.lo[k]; }
+    if (hs.d.kind == RPT_SHAPE_SPHERE || hs.d.kind == RPT_SHAPE_CUBE) {
+        const double h = hs.d.kind == RPT_SHAPE_SPHERE ? 1.0 : 0.5;
+        for (int k = 0; k < 3; k++) { b.lo[k] = -h; b.hi[k] = h; }
+    } else if (hs.d.kind == RPT_SHAPE_MESH) {
+        const std::vector<double>& T = hs.T();
+        for (size_t t = 0; t < T.size() / 18; t++)
+            for (int v = 0; v < 3; v++)
+                for (int k = 0; k < 3; k++) {
+                    b.lo[k] = std::min(b.lo[k], T[t * 18 + v * 3 + k]);
+                    b.hi[k] = std::max(b.hi[k], T[t * 18 + v * 3 + k]);
+                }
+    } else if (hs.d.kind == RPT_SHAPE_GROUP) {
+        for (const HShape& c : hs.children) {
+            const Box64 cb = bbox64(c);
+            for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], cb.lo[k]); b.hi[k] = std::max(b.hi[k], cb.hi[k]); }
+        }
+    }
+    if (!hs.d.has_transform) return b;
+    Box64 w;
+    for (int k = 0; k < 3; k++) { w.lo[k] = std::numeric_limits<double>::infinity(); w.hi[k] = -w.lo[k]; }
+    const double* M = hs.d.transform;
+    for (int c = 0; c < 8; c++) {
+        const double p[3] = {c & 4 ? b.hi[0] : b.lo[0], c & 2 ? b.hi[1] : b.lo[1], c & 1 ? b.hi[2] : b.lo[2]};
+        for (int i = 0; i < 3; i++) {
+            const double v = M[i * 4] * p[0] + M[i * 4 + 1] * p[1] + M[i * 4 + 2] * p[2] + M[i * 4 + 3] * 1.0;
+            w.lo[i] = std::min(w.lo[i], v);
+            w.hi[i] = std::max(w.hi[i], v);
+        }
+    }
+    return w;
+}
+struct Flat64 {
+    std::unordered_map<const std::vector<double>*, uint32_t> shared_meshes;
+    std::vector<rpt64::CullBox> cull;
+    std::vector<rpt64::ObjRec> recs;
+    std::vector<rpt64::ObjShade> shade;
+    std::vector<rpt64::FrameRec> frames;
+    std::vector<rpt64::FrameShade> fshade;
+    std::vector<rpt64::Tri> tris;
+    std::vector<double> tri_pdf;
+};
+// One shape of scene.objects[..] into records: a leaf becomes an ObjRec under the group levels in `chain`; a group adds a level and
+// recurses.  `outer`: the forward matrices of the transformed levels above, outermost first (for the fp32 world box only).
+static int flatten64(const HShape& hs, const rpt_material& mat, std::vector<uint32_t>& chain, std::vector<const double*>& outer, Flat64& F) {
+    Xf x;
+    if (!make_xf(hs.d, x)) return fail(RPT_ERR_INVALID, "singular transform");
+    if (hs.d.kind == RPT_SHAPE_GROUP) {
+        rpt64::FrameRec fr;
+        rpt64::FrameShade fs;
+        std::memset(&fr, 0, sizeof(fr));
+        std::memset(&fs, 0, sizeof(fs));
+        fs.has_xf = x.has ? 1 : 0;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 4; j++) fr.inv[i * 4 + j] = x.Minv[i][j];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) fs.nrm[i * 3 + j] = x.N[i][j];
+        HShape inner = hs;   // the group's bounds are those of KdTree::new: its children's boxes merged, in the group's own space
+        inner.d.has_transform = 0;
+        const Box64 gb = bbox64(inner);
+        for (int k = 0; k < 3; k++) { fr.b[k] = gb.lo[k]; fr.b[3 + k] = gb.hi[k]; }
+        chain.push_back(uint32_t(F.frames.size()));
+        F.frames.push_back(fr);
+        F.fshade.push_back(fs);
+        if (x.has) outer.push_back(hs.d.transform);
+        for (const HShape& c : hs.children)
+            if (int rc = flatten64(c, mat, chain, outer, F)) return rc;
+        if (x.has) outer.pop_back();
+        chain.pop_back();
+        return RPT_OK;
+    }
+    rpt64::Shape sh;
+    if (int rc = fill_shape64(hs, sh, F.tris, F.tri_pdf, &F.shared_meshes)) return rc;
+    rpt64::ObjRec r;
+    std::memset(&r, 0, sizeof(r));
+    r.kind = sh.kind; r.has_xf = sh.has_xf; r.tri_first = sh.tri_first; r.tri_count = sh.tri_count;
+    r.n_frames = uint32_t(chain.size());
+    for (size_t k = 0; k < chain.size(); k++) r.frame[k] = chain[k];
+    for (int k = 0; k < 12; k++) r.inv[k] = sh.inv[k];
+    for (int k = 0; k < 3; k++) {
+        if (sh.kind == rpt64::SH_MESH) { r.b[k] = sh.bmin[k]; r.b[3 + k] = sh.bmax[k]; }
+        else if (sh.kind == rpt64::SH_CUBE) { r.b[k] = -0.5; r.b[3 + k] = 0.5; }
+        else if (sh.kind == rpt64::SH_PLANE) { r.b[k] = sh.plane[k]; }
+    }
+    if (sh.kind == rpt64::SH_PLANE) r.b[3] = sh.plane[3];
+    // the fp32 world box: the shape's own box under its matrix, then under the groups' matrices, innermost first
+    rpt64::CullBox cb = cull_box64(sh);
+    if (!cb.unbounded && !outer.empty()) {
+        double lo[3], hi[3];
+        for (int k = 0; k < 3; k++) { lo[k] = cb.lo[k]; hi[k] = cb.hi[k]; }
+        for (size_t lvl = outer.size(); lvl-- > 0;) {
+            const double* M = outer[lvl];
+            double wlo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, whi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+            for (int c = 0; c < 8; c++) {
+                const double p[3] = {c & 1 ? hi[0] : lo[0], c & 2 ? hi[1] : lo[1], c & 4 ? hi[2] : lo[2]};
+                for (int i = 0; i < 3; i++) {
+                    const double v = M[i * 4] * p[0] + M[i * 4 + 1] * p[1] + M[i * 4 + 2] * p[2] + M[i * 4 + 3];
+                    wlo[i] = std::min(wlo[i], v);
+                    whi[i] = std::max(whi[i], v);
+                }
+            }
+            for (int k = 0; k < 3; k++) { lo[k] = wlo[k]; hi[k] = whi[k]; }
+        }
+        double size = 0.0, mag = 0.0;
+        for (int i = 0; i < 3; i++) { size = std::max(size, hi[i] - lo[i]); mag = std::max(mag, std::max(std::fabs(lo[i]), std::fabs(hi[i]))); }
+        const double pad = 1e-5 * size + 1e-5 * mag + 1e-30;
+        bool finite = true;
+        for (int i = 0; i < 3; i++) {
+            cb.lo[i] = std::nextafter(float(lo[i] - pad), -HUGE_VALF);
+            cb.hi[i] = std::nextafter(float(hi[i] + pad), HUGE_VALF);
+            finite = finite && std::isfinite(cb.lo[i]) && std::isfinite(cb.hi[i]);
+        }
+        if (!finite) { cb = rpt64::CullBox{}; cb.unbounded = 1u; }
+    }
+    rpt64::ObjShade os;
+    std::memset(&os, 0, sizeof(os));
+    for (int k = 0; k < 9; k++) os.nrm[k] = sh.nrm[k];
+    fill_mat64(mat, os.mat);
+    F.cull.push_back(cb);
+    F.recs.push_back(r);
+    F.shade.push_back(os);
+    return RPT_OK;
+}
 static int build_scene64(rpt_scene* s) {
     static_assert(sizeof(rpt64::Tri) == 18 * sizeof(double), "a triangle is its 18 doubles");
     if (int rc = check_scene64(s)) return rc;
-    const size_t n = s->objects.size();
-    std::vector<rpt64::Shape> shapes(n);
-    std::vector<rpt64::CullBox> cull(n);
-    std::vector<rpt64::ObjRec> recs(n);
-    std::vector<rpt64::ObjShade> shade(n);
-    std::vector<rpt64::Tri> tris;
-    std::vector<double> tri_pdf;
-    std::vector<rpt64::Light> lights(s->lights.size());
-    for (size_t i = 0; i < n; i++) {
-        if (int rc = fill_shape64(s->objects[i].shape, shapes[i], tris, tri_pdf)) return rc;
-        const rpt64::Shape& sh = shapes[i];
-        cull[i] = cull_box64(sh);
-        rpt64::ObjRec& r = recs[i];
-        std::memset(&r, 0, sizeof(r));
-        r.kind = sh.kind; r.has_xf = sh.has_xf; r.tri_first = sh.tri_first; r.tri_count = sh.tri_count;
-        for (int k = 0; k < 12; k++) r.inv[k] = sh.inv[k];
-        for (int k = 0; k < 3; k++) {
-            if (sh.kind == rpt64::SH_MESH) { r.b[k] = sh.bmin[k]; r.b[3 + k] = sh.bmax[k]; }
-            else if (sh.kind == rpt64::SH_CUBE) { r.b[k] = -0.5; r.b[3 + k] = 0.5; }
-            else if (sh.kind == rpt64::SH_PLANE) { r.b[k] = sh.plane[k]; }
-        }
-        if (sh.kind == rpt64::SH_PLANE) r.b[3] = sh.plane[3];
-        std::memset(&shade[i], 0, sizeof(shade[i]));
-        for (int k = 0; k < 9; k++) shade[i].nrm[k] = sh.nrm[k];
-        fill_mat64(s->objects[i].mat, shade[i].mat);
+    Flat64 F;
+    for (size_t i = 0; i < s->objects.size(); i++) {
+        std::vector<uint32_t> chain;
+        std::vector<const double*> outer;
+        if (int rc = flatten64(s->objects[i].shape, s->objects[i].mat, chain, outer, F)) return rc;
     }
+    std::vector<rpt64::CullBox>& cull = F.cull;
+    std::vector<rpt64::ObjRec>& recs = F.recs;
+    std::vector<rpt64::ObjShade>& shade = F.shade;
+    std::vector<rpt64::Tri>& tris = F.tris;
+    std::vector<double>& tri_pdf = F.tri_pdf;
+    const size_t n = recs.size();
+    std::vector<rpt64::Light> lights(s->lights.size());
     const size_t n_obj_tris = tris.size();
     std::vector<rpt64::TriRec> trecs(n_obj_tris);
     std::vector<rpt64::TriShade> tshade(n_obj_tris);
@@ -1702,7 +1830,8 @@ static int build_scene64(rpt_scene* s) {
     Part parts[] = {{cull.data(), cull.size() * sizeof(rpt64::CullBox), 0},       {recs.data(), recs.size() * sizeof(rpt64::ObjRec), 0},
                     {shade.data(), shade.size() * sizeof(rpt64::ObjShade), 0},    {trecs.data(), trecs.size() * sizeof(rpt64::TriRec), 0},
                     {tshade.data(), tshade.size() * sizeof(rpt64::TriShade), 0},  {tris.data(), tris.size() * sizeof(rpt64::Tri), 0},
-                    {tri_pdf.data(), tri_pdf.size() * sizeof(double), 0},         {lights.data(), lights.size() * sizeof(rpt64::Light), 0}};
+                    {tri_pdf.data(), tri_pdf.size() * sizeof(double), 0},         {lights.data(), lights.size() * sizeof(rpt64::Light), 0},
+                    {F.frames.data(), F.frames.size() * sizeof(rpt64::FrameRec), 0}, {F.fshade.data(), F.fshade.size() * sizeof(rpt64::FrameShade), 0}};
     size_t total = 0;
     for (auto& p : parts) { p.off = total; total = (total + p.bytes + 255) & ~size_t(255); }
     total = std::max<size_t>(total, 256);
@@ -1719,6 +1848,8 @@ static int build_scene64(rpt_scene* s) {
     v.tris = reinterpret_cast<const rpt64::Tri*>(base + parts[5].off);
     v.tri_pdf = reinterpret_cast<const double*>(base + parts[6].off);
     v.lights = reinterpret_cast<const rpt64::Light*>(base + parts[7].off);
+    v.frames = reinterpret_cast<const rpt64::FrameRec*>(base + parts[8].off);
+    v.fshade = reinterpret_cast<const rpt64::FrameShade*>(base + parts[9].off);
     v.n_objects = uint32_t(n);
     v.n_lights = uint32_t(lights.size());
     v.n_tris = uint32_t(tris.size());

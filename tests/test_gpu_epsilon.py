@@ -155,10 +155,67 @@ def test_parked_surface_events_do_not_depend_on_the_threshold():
         assert np.array_equal(f, frames[0])
 
 
+def _group_scene(kind):
+    from rpt_amd import KdTree, Mesh
+    sc = Scene()
+    sc.add(Object(plane(vec3(0, 1, 0), -1.2)).material(Material.diffuse(hex_color(0xCCCCCC))))
+    if kind == "spheres":      # examples/fractal_spheres.rs in small: groups of spheres, one material per level
+        scene, cam, cfg = scenes.fractal_spheres(3)
+        return scene, cam, cfg["max_bounces"] + 2
+    mesh = Mesh(scenes.bumpy_torus(10, 8, major=0.5, minor=0.22, bump=0.1))
+    kids = [sphere().scale(vec3(0.35, 0.35, 0.35)).translate(vec3(-1.1, 0.0, 0.2)),
+            cube().rotate_y(0.4).scale(vec3(0.6, 0.5, 0.6)).translate(vec3(1.0, -0.3, 0.0)),
+            mesh.rotate_x(0.6).translate(vec3(0.0, 0.2, -0.4)),
+            mesh.scale(vec3(0.5, 0.5, 0.5)).translate(vec3(0.2, 1.0, 0.6))]     # the same mesh twice (Arc<Mesh>)
+    inner = KdTree(kids)
+    if kind == "transformed group":
+        sc.add(Object(inner.rotate_z(0.3).scale(vec3(1.1, 0.9, 1.0)).translate(vec3(0.1, 0.2, 0.0))).material(Material.specular(hex_color(0xE7A94D), 6.0)))
+    else:                      # a kd-tree of kd-trees, both levels transformed
+        outer = KdTree([inner.rotate_y(0.7).translate(vec3(-0.4, 0.0, 0.0)), sphere().scale(vec3(0.3, 0.3, 0.3)).translate(vec3(1.9, 0.9, -0.5)),
+                        KdTree([cube().scale(vec3(0.3, 0.3, 0.3)).translate(vec3(-1.9, 0.9, 0.4))])])
+        sc.add(Object(outer.scale(vec3(0.9, 0.9, 0.9)).translate(vec3(0.0, 0.1, 0.0))).material(Material.diffuse(hex_color(0x7CA3E7))))
+    light = cube().scale(vec3(1.2, 0.05, 1.2)).translate(vec3(0.0, 3.0, 0.5))
+    sc.add(Object(light.clone()).material(Material.light(vec3(1, 1, 1), 30.0)))
+    sc.add(Light.Object(Object(light.clone()).material(Material.light(vec3(1, 1, 1), 30.0))))
+    sc.add(Light.Ambient(vec3(0.03, 0.03, 0.03)))
+    cam = Camera.look_at(vec3(0.0, 1.6, 6.0), vec3(0.0, 0.2, 0.0), vec3(0, 1, 0), 0.7)
+    return sc, cam, 3
+
+
+@pytest.mark.parametrize("kind", ["spheres", "transformed group", "group of groups"])
+def test_kdtree_groups_follow_the_literal_oracle(kind):
+    """`KdTree<Box<dyn Bounded>>` objects (src/kdtree.rs:103-146) in the reference-epsilon mode: a group's children are records of
+    their own under the group's ray map and bounds test -- against the oracle, which walks rpt's kd-tree of shapes.  The box
+    culling must not change a bit here either."""
+    sc, cam, mb = _group_scene(kind)
+    w, h, spp = 72, 54, 8
+    frames = []
+    for cull in (1, 0):
+        sc.set_option("f64_cull", cull) if cull else None
+        s2, c2, _ = _group_scene(kind)
+        s2.set_option("epsilon_policy", 1)
+        s2.set_option("f64_cull", cull)
+        frames.append(Renderer(s2, c2).width(w).height(h).max_bounces(mb).seed(5).sample_array(spp))
+    assert np.array_equal(frames[0], frames[1])
+    exp = _oracle(sc).render(cam, w, h, spp, mb, seed=5, robust=0)
+    assert np.all(np.isfinite(frames[0])) and exp.mean() > 0
+    assert rel_rms(frames[0], exp) < 5e-3, kind
+    assert abs(frames[0].mean() - exp.mean()) < 5e-4 * exp.mean(), kind
+
+
 def test_what_the_mode_refuses():
     from rpt_amd import KdTree
+    deep = sphere()
+    for _ in range(4):                                    # groups nested four deep: one more than the records hold
+        deep = KdTree([deep, sphere().translate(vec3(3, 0, 0))])
     sc = Scene()
-    sc.add(Object(KdTree([sphere(), sphere().translate(vec3(3, 0, 0))])).material(Material.diffuse(vec3(1, 1, 1))))
+    sc.add(Object(deep).material(Material.diffuse(vec3(1, 1, 1))))
+    sc.set_option("epsilon_policy", 1)
+    with pytest.raises(RptError):
+        Renderer(sc, Camera.look_at(vec3(0, 0, 5), vec3(0, 0, 0), vec3(0, 1, 0), 0.6)).width(8).height(8).sample_array(1)
+    sc = Scene()                                           # a group as a Light::Object
+    sc.add(Object(sphere()).material(Material.diffuse(vec3(1, 1, 1))))
+    sc.add(Light.Object(Object(KdTree([sphere(), sphere().translate(vec3(3, 0, 0))])).material(Material.light(vec3(1, 1, 1), 5.0))))
     sc.set_option("epsilon_policy", 1)
     with pytest.raises(RptError):
         Renderer(sc, Camera.look_at(vec3(0, 0, 5), vec3(0, 0, 0), vec3(0, 1, 0), 0.6)).width(8).height(8).sample_array(1)
