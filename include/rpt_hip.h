@@ -316,12 +316,16 @@ int rpt_frame_unpack_device(uint32_t width, uint32_t height, uint32_t rank, uint
  * The fp32 path replaces the reference's 1e-12 epsilons (src/renderer.rs:17, 348, 396, 420), which fp32 cannot resolve, by
  * scaled tolerances and a geometric twin test; its images are brighter than rpt's by the energy rpt loses to
  * self-intersections and near-miss shadow rejections.  A scene committed with epsilon_policy = 1
- * is rendered by a second, fp64 kernel that follows the reference literally instead: every object tested per ray in scene
- * order as the generic shape under its own Transformed matrices, t_min = 1e-12, light visible iff |hit - dist| < 1e-12,
- * f64 colours, no fused multiply-adds.  Same entry points (rpt_render_sample*, rpt_render_into_buffer), same RNG streams,
- * same sharding; several times slower.  Supported: spheres, cubes, planes, meshes (scanned triangle by triangle), all
- * materials, lights and media, Environment::Color.  Refused with RPT_ERR_UNSUPPORTED: KdTree groups, Environment::Hdri,
- * photon mapping.
+ * is rendered by a second, fp64 kernel whose arithmetic follows the reference literally instead: every object the generic
+ * shape under its own Transformed matrices, in scene order, t_min = 1e-12, light visible iff |hit - dist| < 1e-12, f64
+ * colours, no fused multiply-adds (only the objects a ray's padded fp32 box test keeps are evaluated -- the result is that of
+ * the full scan bit for bit; option "f64_cull" = 0 runs the full scan).  Same entry points (rpt_render_sample*,
+ * rpt_render_into_buffer), same RNG streams, same sharding; 4-5 times slower than the fp32 path (C3: 2.9 Gsamples/s).
+ * Supported: spheres, cubes, planes, meshes (scanned triangle by triangle), KdTree groups of them as objects (nested at
+ * most three deep), all materials, lights and media, Environment::Color and Environment::Hdri.  Refused with
+ * RPT_ERR_UNSUPPORTED: a KdTree group as a Light::Object, photon mapping.
+ * Options of the mode: "f64_cull" (1; 0 = full scan, 2 = the counters build keeps the search limits), "f64_surf_batch"
+ * (8: lanes of a wave that wait at a surface event in a medium before the wave runs the surface code).
  * rpt_debug_epsilon_counters (option "counters" = 1): [0] closest-hit queries, [1] accepted hits, [2] accepted hits with
  * t < 1e-9 (1 + |origin|) -- a ray hitting the surface it starts on --, [3] shadow tests, [4] passed, [5] failed although
  * |hit - dist| < 1e-6 dist -- the light's own surface missed by rounding --, [6] camera samples, [7] path vertices; the

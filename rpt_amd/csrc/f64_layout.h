@@ -106,6 +106,8 @@ struct Scene {
     int32_t has_medium, medium_kind;
     double absorption, scattering;
     double env[3];
+    const double* hdri;         // Environment::Hdri (src/environment.rs:3-52): width x height x 3, row-major; hdri_w = 0: Environment::Color(env)
+    uint32_t hdri_w, hdri_h;
 };
 struct Camera {   // src/camera.rs:9-27, with `d` and `right` of cast_ray (:67-68) evaluated once, in fp64, on the host
     double eye[3], direction[3], up[3], right[3];

@@ -567,6 +567,26 @@ R64_DEV D bsdf(const Mat& m, D n, D wo, D wi) {
 }
 
 // ---------------------------------------------------------------------------- the path
+// Environment::get_color (src/environment.rs:64-77) / Hdri::get_color + bilinear_sample (:25-52).  (x0 + 1, y0 + 1 are clamped to
+// the image: the reference indexes them unclamped and panics or wraps exactly where the weight is zero.)
+R64_DEV D env_color(D dir_in) {
+    const uint32_t w = KA.sc.hdri_w, h = KA.sc.hdri_h;
+    if (w == 0u) return ld(KA.sc.env);
+    const D dir = normalize(dir_in);
+    const double azimuth = atan2(dir.z, dir.x) + kPi;
+    const double polar = acos(dir.y);
+    const double x = azimuth / (2.0 * kPi) * double(w - 1u);
+    const double y = polar / kPi * double(h - 1u);
+    // (`as u32` saturates: negative and NaN -> 0)
+    const uint32_t xi = x > 0.0 ? (x < 4294967295.0 ? uint32_t(x) : 4294967295u) : 0u, yi = y > 0.0 ? (y < 4294967295.0 ? uint32_t(y) : 4294967295u) : 0u;
+    const uint32_t x0 = min(xi, w - 1u), y0 = min(yi, h - 1u);
+    const double ax = x - double(x0), ay = y - double(y0);
+    const uint32_t x1 = min(x0 + 1u, w - 1u), y1 = min(y0 + 1u, h - 1u);
+    const double* const t = KA.sc.hdri;
+    auto texel = [&](uint32_t xx, uint32_t yy) { return ld(t + (size_t(yy) * w + xx) * 3u); };
+    auto mix = [](D a, D b, double f) { return a * (1.0 - f) + b * f; };   // glm::mix
+    return mix(mix(texel(x0, y0), texel(x1, y0), ax), mix(texel(x0, y1), texel(x1, y1), ax), ay);
+}
 // Medium::color (src/medium.rs:80-122): hex_color(0xD2B48C) for homogeneous_isotropic; blue below / red above y = 250 for
 // colored_glowing_fog (the host passes the colours, src/color.rs:10-15 evaluated in fp64)
 R64_DEV D medium_color(D pos) {
@@ -788,7 +808,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
                     }
                     ev_medium = MEDIUM && dmed < (hit ? q.t : 400.0);   // :197-243 (`d >= h.time` is a surface event)
                     if (!ev_medium && !hit) {   // :198-206 (in a medium the background counts only beyond 400), :288
-                        const D env = (!MEDIUM || dmed >= 400.0) ? ld(KA.sc.env) : mk(0, 0, 0);
+                        const D env = (!MEDIUM || dmed >= 400.0) ? env_color(rd) : mk(0, 0, 0);
                         const D v = ldD(C_P) + ldD(C_Q) * env;
                         stD(C_ACC, ldD(C_ACC) + (MEDIUM ? v : vmin(v, ldD(C_R))));
                         need_path = true;

@@ -487,6 +487,7 @@ struct rpt_scene {
     double env[3] = {0, 0, 0};
     uint32_t hdri_w = 0, hdri_h = 0;
     std::vector<float> hdri;  // w*h*4
+    std::vector<double> hdri64;  // w*h*3: the texels as they were given (the reference-epsilon mode reads these)
     bool committed = false;
     rpt_options opt;  // this scene's options (rpt_scene_set_option; starts as a copy of the process defaults)
     int device = 0;
@@ -716,6 +717,7 @@ int rpt_scene_set_environment_color(rpt_scene* s, const double rgb[3]) {
     std::memcpy(s->env, rgb, 24);
     s->hdri_w = s->hdri_h = 0;
     s->hdri.clear();
+    s->hdri64.clear();
     return RPT_OK;
 }
 int rpt_scene_set_environment_hdri(rpt_scene* s, uint32_t width, uint32_t height, const double* rgb) {
@@ -725,6 +727,7 @@ int rpt_scene_set_environment_hdri(rpt_scene* s, uint32_t width, uint32_t height
     s->hdri_w = width;
     s->hdri_h = height;
     s->hdri.resize(size_t(width) * height * 4);
+    s->hdri64.assign(rgb, rgb + size_t(width) * height * 3);
     for (size_t i = 0; i < size_t(width) * height; i++) {
         s->hdri[4 * i] = float(rgb[3 * i]); s->hdri[4 * i + 1] = float(rgb[3 * i + 1]); s->hdri[4 * i + 2] = float(rgb[3 * i + 2]);
         s->hdri[4 * i + 3] = 0.f;
@@ -1549,7 +1552,6 @@ struct Flattener {
 // device must find the same bits, so nothing below may be contracted into an fma.)
 #pragma clang fp contract(off)
 static int check_scene64(const rpt_scene* s) {   // what the mode refuses, before anything is allocated
-    if (s->hdri_w) return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports Environment::Color only");
     std::function<int(const HShape&)> depth = [&](const HShape& h) {   // group levels around the deepest shape
         int d = 0;
         for (const HShape& c : h.children) d = std::max(d, depth(c));
@@ -1831,7 +1833,8 @@ static int build_scene64(rpt_scene* s) {
                     {shade.data(), shade.size() * sizeof(rpt64::ObjShade), 0},    {trecs.data(), trecs.size() * sizeof(rpt64::TriRec), 0},
                     {tshade.data(), tshade.size() * sizeof(rpt64::TriShade), 0},  {tris.data(), tris.size() * sizeof(rpt64::Tri), 0},
                     {tri_pdf.data(), tri_pdf.size() * sizeof(double), 0},         {lights.data(), lights.size() * sizeof(rpt64::Light), 0},
-                    {F.frames.data(), F.frames.size() * sizeof(rpt64::FrameRec), 0}, {F.fshade.data(), F.fshade.size() * sizeof(rpt64::FrameShade), 0}};
+                    {F.frames.data(), F.frames.size() * sizeof(rpt64::FrameRec), 0}, {F.fshade.data(), F.fshade.size() * sizeof(rpt64::FrameShade), 0},
+                    {s->hdri64.data(), s->hdri64.size() * sizeof(double), 0}};
     size_t total = 0;
     for (auto& p : parts) { p.off = total; total = (total + p.bytes + 255) & ~size_t(255); }
     total = std::max<size_t>(total, 256);
@@ -1850,6 +1853,9 @@ static int build_scene64(rpt_scene* s) {
     v.lights = reinterpret_cast<const rpt64::Light*>(base + parts[7].off);
     v.frames = reinterpret_cast<const rpt64::FrameRec*>(base + parts[8].off);
     v.fshade = reinterpret_cast<const rpt64::FrameShade*>(base + parts[9].off);
+    v.hdri = reinterpret_cast<const double*>(base + parts[10].off);
+    v.hdri_w = s->hdri64.empty() ? 0u : s->hdri_w;
+    v.hdri_h = s->hdri64.empty() ? 0u : s->hdri_h;
     v.n_objects = uint32_t(n);
     v.n_lights = uint32_t(lights.size());
     v.n_tris = uint32_t(tris.size());

@@ -203,6 +203,30 @@ def test_kdtree_groups_follow_the_literal_oracle(kind):
     assert abs(frames[0].mean() - exp.mean()) < 5e-4 * exp.mean(), kind
 
 
+def test_hdri_environment_follows_the_literal_oracle():
+    """Environment::Hdri (src/environment.rs:3-52) in the reference-epsilon mode: fp64 texels as given, atan2 / acos lookup, glm::mix --
+    with and without fog (in a medium the background counts only beyond 400, src/renderer.rs:198-206)."""
+    from rpt_amd import Environment
+    w, h = 64, 32
+    yy, xx = np.mgrid[0:h, 0:w]
+    sky = np.stack([0.2 + 0.8 * xx / (w - 1), 0.3 + 0.5 * (1 - yy / (h - 1)), 0.1 + 0.9 * ((xx // 8 + yy // 8) % 2)], axis=-1)
+    for fog in (False, True):
+        sc = Scene()
+        sc.environment = Environment.Hdri(w, h, sky.reshape(-1, 3))
+        sc.add(Object(plane(vec3(0, 1, 0), 0.0)).material(Material.diffuse(hex_color(0xCCCCCC))))
+        sc.add(Object(sphere().translate(vec3(-1.2, 1, 0))).material(Material.mirror()))
+        sc.add(Object(sphere().translate(vec3(1.2, 1, 0))).material(Material.specular(hex_color(0xE7A94D), 20.0)))
+        if fog:
+            sc.add(Medium.homogeneous_isotropic(0.0005, 0.002))
+        cam = Camera.look_at(vec3(0, 2.0, 6.0), vec3(0, 0.8, 0), vec3(0, 1, 0), 0.7)
+        size, spp, mb = 64, 16, 3
+        got = _eps_renderer(sc, cam).width(size).height(size).max_bounces(mb).seed(12).sample_array(spp)
+        exp = _oracle(sc).render(cam, size, size, spp, mb, seed=12, robust=0)
+        assert exp.mean() > 0 and np.all(np.isfinite(got))
+        assert rel_rms(got, exp) < 2e-3, fog
+        assert abs(got.mean() - exp.mean()) < 2e-4 * exp.mean(), fog
+
+
 def test_what_the_mode_refuses():
     from rpt_amd import KdTree
     deep = sphere()
