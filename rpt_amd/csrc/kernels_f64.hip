@@ -252,6 +252,8 @@ R64_DEV PairHit eval_pair(RP recs, TP trecs, uint32_t i, D o, D d) {
 R64_DEV uint32_t cull32(const CullBox* boxes, uint32_t base, uint32_t nb, float ox, float oy, float oz, float ix, float iy, float iz,
                         float eo, float tlim) {
     uint32_t mask = 0u;
+    // (the origin's error bound goes into the origin once: lo - eo - o = lo - (o + eo))
+    const float oxl = ox + eo, oyl = oy + eo, ozl = oz + eo, oxh = ox - eo, oyh = oy - eo, ozh = oz - eo;
     for (uint32_t j = 0; j < nb; j++) {
         const rptg::F4 lo = rptg::uload(reinterpret_cast<const rptg::F4*>(boxes + base + j));
         const rptg::F4 hi = rptg::uload(reinterpret_cast<const rptg::F4*>(boxes + base + j) + 1);
@@ -259,9 +261,9 @@ R64_DEV uint32_t cull32(const CullBox* boxes, uint32_t base, uint32_t nb, float 
             mask |= 1u << j;
             continue;
         }
-        const float x1 = (lo.x - eo - ox) * ix, x2 = (hi.x + eo - ox) * ix;
-        const float y1 = (lo.y - eo - oy) * iy, y2 = (hi.y + eo - oy) * iy;
-        const float z1 = (lo.z - eo - oz) * iz, z2 = (hi.z + eo - oz) * iz;
+        const float x1 = (lo.x - oxl) * ix, x2 = (hi.x - oxh) * ix;
+        const float y1 = (lo.y - oyl) * iy, y2 = (hi.y - oyh) * iy;
+        const float z1 = (lo.z - ozl) * iz, z2 = (hi.z - ozh) * iz;
         const float tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
         const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
         const float tn_lo = tn - 4e-6f * fabsf(tn), tf_hi = tf + 4e-6f * fabsf(tf);
@@ -351,16 +353,17 @@ R64_DEV void closest_hit_wave(RP recs, TP trecs, volatile uint32_t* slots, bool 
                 const uint64_t B = __ballot(mask != 0u);
                 const bool has = mask != 0u;
                 const uint32_t src = has ? cum + mbcnt64(B) : lane;
-                const double t = lane_read(ph.t, src), bm = lane_read(ph.bm, src);
-                const uint32_t aux = lane_read(ph.aux, src);
-                if (has) {
-                    if (!(bm > q.t) && t < q.t) {
+                const double t = lane_read(ph.t, src);
+                if (__ballot(has && t < q.t) != 0ull) {   // (the rest of the result only where some record may change)
+                    const double bm = lane_read(ph.bm, src);
+                    const uint32_t aux = lane_read(ph.aux, src);
+                    if (has && !(bm > q.t) && t < q.t) {
                         q.t = t;
                         q.obj = int32_t(base + uint32_t(__builtin_ctz(mask)));
                         q.aux = aux;
                     }
-                    mask &= mask - 1u;
                 }
+                if (has) mask &= mask - 1u;
                 cum += uint32_t(__popcll(B));
             }
         }
