@@ -532,6 +532,7 @@ struct rpt_scene {
     void* photon = nullptr;  // PhotonMapDev*, owned by photon.hip
     // reference-epsilon mode (option "epsilon_policy" = 1 at commit): the fp64 scene of kernels_f64.hip
     void* arena64 = nullptr;
+    size_t arena64_bytes = 0;
     rpt64::Scene view64{};
     double medium_color64[3] = {0, 0, 0}, medium_color_hi64[3] = {0, 0, 0};
     uint64_t last_counters64[64] = {0};   // [0..11] rpt_debug_epsilon_counters, [16 + 2k], [17 + 2k] section k of kernels_f64.hip (executions, lanes)
@@ -1839,6 +1840,8 @@ static int build_scene64(rpt_scene* s) {
     for (auto& p : parts) { p.off = total; total = (total + p.bytes + 255) & ~size_t(255); }
     total = std::max<size_t>(total, 256);
     HIP_TRY(hipMalloc(&s->arena64, total));
+    HIP_TRY(hipMemset(s->arena64, 0, total));   // (the gaps between the arrays too: the host tests checksum the arena)
+    s->arena64_bytes = total;
     char* base = static_cast<char*>(s->arena64);
     for (auto& p : parts)
         if (p.bytes) HIP_TRY(hipMemcpy(base + p.off, p.src, p.bytes, hipMemcpyHostToDevice));

@@ -108,6 +108,26 @@ int main() {
         report("groups", s);
         rpt_scene_destroy(s);
     }
+    {   // the reference-epsilon mode's scene (f64_layout.h): generic shapes, groups as records under frames, a shared mesh stored once,
+        // per-triangle constants evaluated with the reference's operations (no contraction: every build must find the same bits)
+        rpt_scene* s = rpt_scene_create();
+        rpt_scene_set_option(s, "epsilon_policy", 1);
+        add(s, polygon({{0, 0, 0}, {0, 0, 5.5}, {5.5, 0, 5.5}, {5.5, 0, 0}}));
+        add(s, cube().scale({1.65, 3.3, 1.65}).rotate_y(0.3).translate({3.68, 1.65, 3.51}));
+        add(s, plane({0, 1, 0}, -0.25));
+        Shape shared = torus(9, 7, 0.6, 0.25);
+        std::vector<Shape> inner = {sphere().scale({0.3, 0.2, 0.3}).translate({1, 1, 1}), shared.rotate_x(0.7).translate({2, 1, 0.5}), shared.scale({0.5, 0.5, 0.5})};
+        std::vector<Shape> outer = {kdtree(inner).rotate_z(0.2).translate({0.1, 0.2, 0.3}), cube().scale({0.3, 0.3, 0.3}).translate({4, 0.5, 1}),
+                                    kdtree({sphere().translate({0, 3, 0})})};
+        add(s, kdtree(outer).scale({0.9, 1.1, 1.0}));
+        Shape quad = polygon({{2.13, 5.4, 2.27}, {3.43, 5.4, 2.27}, {3.43, 5.4, 3.32}, {2.13, 5.4, 3.32}});
+        add(s, quad);
+        add(s, quad, true);
+        const int rc = rpt_scene_commit(s, 0);
+        std::printf("epsilon rc=%d records=%u arena64=%016llx bytes=%zu\n", rc, s->view64.n_objects,
+                    (unsigned long long)(rc == 0 && s->arena64 ? fnv(s->arena64, s->arena64_bytes) : 0ull), s->arena64_bytes);
+        rpt_scene_destroy(s);
+    }
     {   // error paths: nothing may be read out of bounds or leak
         rpt_scene* s = rpt_scene_create();
         rpt_shape_desc bad{};

@@ -1,5 +1,6 @@
 """Host half of the library on a CPU: rpt_amd/csrc/rpt_capi.cpp compiled with malloc-backed HIP stubs
-(tests/host/) commits a room, a mesh scene, a scene of groups with a shared mesh and a few invalid shapes.
+(tests/host/) commits a room, a mesh scene, a scene of groups with a shared mesh, a scene in the reference-epsilon mode (groups as
+records under frames, per-triangle constants with the reference's own operation order) and a few invalid shapes.
 
   * under AddressSanitizer + UBSan (g++): no report, exit code 0;
   * at -O0, -O3 and -O3 -fno-unroll-loops: byte-identical flattened scenes (arena checksums).  The last
@@ -48,4 +49,6 @@ def test_flatten_is_clean_under_sanitizers_and_independent_of_the_optimiser(tmp_
     assert lines["room"][1] == "rc=0" and lines["room"][3:8] == ["1", "0", "0", "1", "6"] and lines["room"][16] == "5"
     assert lines["mesh"][2:6] == ["1", "0", "1", "18"] and lines["mesh"][8] == "2048" and lines["mesh"][12] == "0"
     assert lines["groups"][2:4] == ["30", "40"] and lines["groups"][12:16] == ["1", "110", "40", "1"] and lines["groups"][8] == "192"
+    eps = [l for l in first.splitlines() if l.startswith("epsilon ")]
+    assert len(eps) == 1 and "rc=0" in eps[0] and "records=9 " in eps[0]     # 4 plain objects + the 5 shapes inside the (nested) groups
     assert "bad kind rc=-1" in first and "empty mesh rc=-1" in first and "singular rc=-1" in first and "second commit rc=-2" in first
