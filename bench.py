@@ -464,6 +464,25 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- N > 1: is the assembled frame the frame?  Rank 0 renders the whole image alone (same seed: the render is a function of
+    # scene, seed and pixel) and compares it with the last frame the exchange delivered, bit for bit (the exchange carries the
+    # frame's own f64).  Untimed; no collective involved.
+    exchange_verified = None
+    if xchg is not None and not photon:
+        if rank == 0:
+            fi_last = (step_no[0] - 1) % n_frames
+            whole = torch.zeros_like(frames[fi_last])
+            r.shard(0, 1)
+            r._sample_offset = 0
+            r.sample_device(spp, whole.data_ptr(), 0)
+            torch.cuda.synchronize()
+            r.shard(rank, world)
+            if headline and args.emulate_shard > 1 and world == 1:
+                r.shard(0, args.emulate_shard)
+            exchange_verified = bool(torch.equal(whole, frames[fi_last])) if not (headline and args.emulate_shard > 1) else None
+            del whole
+        r.timing_mean()   # (keep that launch out of the kernel-time mean)
+
     # ---- one step alone: strictly one stream, synchronised after every step (launch -> frame in HBM).  With two launches
     # in flight the HIP events of one also span its wait for the other grid's CUs, so the kernel's own duration comes
     # from these launches as well.
@@ -530,6 +549,8 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
         out["value_host_resident"] = round(samples_per_step / host_elapsed / 1e6, 3)
         out["ms_per_step_host_resident"] = round(host_elapsed * 1e3, 3)
     parallelism = f"tile-shard x{world}" + (f", frame {xchg.mode} on rank 0" if xchg is not None else "")
+    if exchange_verified is not None:
+        out["exchange_verified"] = exchange_verified   # rank 0's own render of the whole frame == the frame assembled from the ranks' tiles
     if xchg is not None and xchg.fallback:
         out["exchange_fallback"] = f"rpt_gather_frame_device unavailable ({xchg.fallback}): torch.distributed sum-reduce used instead"
 
