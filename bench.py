@@ -700,12 +700,12 @@ def main(argv=None):
     default_run = args.workload == "C3" and not (args.width or args.height or args.spp or args.chunk_spp or args.emulate_shard)
     if world == 1 and dist is None and default_run and not args.no_secondary:
         secondary = []
-        for wl in ("C3eps", "C2", "C4", "C5", "C5G"):
+        for wl in ("C3eps", "C2", "C2eps", "C4", "C5", "C5G"):
             entry = measure(wl, args, 2, 1, 1, torch, None, rank, local_rank, world, False)
             entry = dict({"workload": wl}, **entry)
             secondary.append(entry)
         out["secondary"] = secondary
-        out["secondary_note"] = ("C3eps: the headline configuration in the reference-epsilon mode (option epsilon_policy = 1: fp64, rpt's own 1e-12 tests -- "
+        out["secondary_note"] = ("C3eps (and C2eps): the headline configuration (and C2) in the reference-epsilon mode (option epsilon_policy = 1: fp64, rpt's own 1e-12 tests -- "
                                  "the mode that is within 1e-3 of the reference per pixel); then the other BASELINE configurations at their configured sizes (and C5G: the scene-tree + parked-mesh-walk flavour, "
                                  "2048x2048x256), 2 timed steps each after 1 warm-up, strictly one stream (ms_per_step = wall_clock_s x 1000), "
                                  "same definitions as the headline")
