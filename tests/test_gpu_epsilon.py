@@ -203,6 +203,23 @@ def test_kdtree_groups_follow_the_literal_oracle(kind):
     assert abs(frames[0].mean() - exp.mean()) < 5e-4 * exp.mean(), kind
 
 
+def test_tile_shards_add_up_to_the_frame_bit_for_bit():
+    """The mode shards like the fp32 path (32 x 32 tiles, owner (tx + ty) mod n): every rank's frame is zero outside its tiles,
+    the shards' sum is the single-GPU frame exactly, for frame sizes that clip tiles too."""
+    for name, w, h, n in (("C3", 200, 136, 3), ("C2", 96, 96, 2)):
+        scene, cam, cfg = scenes.CONFIGS[name]()
+        scene.set_option("epsilon_policy", 1)
+        r = Renderer(scene, cam).width(w).height(h).max_bounces(cfg["max_bounces"]).seed(8)
+        whole = r.sample_array(6)
+        total = np.zeros_like(whole)
+        for k in range(n):
+            r._sample_offset = 0
+            part = r.shard(k, n).sample_array(6)
+            assert np.all((part == 0) | (part == whole))      # a rank writes its own pixels only, with the frame's values
+            total += part
+        assert np.array_equal(total, whole)
+
+
 def test_hdri_environment_follows_the_literal_oracle():
     """Environment::Hdri (src/environment.rs:3-52) in the reference-epsilon mode: fp64 texels as given, atan2 / acos lookup, glm::mix --
     with and without fog (in a medium the background counts only beyond 400, src/renderer.rs:198-206)."""
