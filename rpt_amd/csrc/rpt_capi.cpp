@@ -636,26 +636,35 @@ rpt_scene* rpt_scene_create(void) {
     return s;
 }
 
+// Everything a commit (and the renders after it) put on the device; the pointers are cleared, so this is safe to repeat and
+// a commit that fails half-way (the reference-epsilon scene after the fp32 upload) leaves nothing behind.
+static void release_device(rpt_scene* s) {
+    if (!s->committed && !s->arena && !s->arena64) return;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->arena); s->arena = nullptr;
+    (void)hipFree(s->arena64); s->arena64 = nullptr; s->arena64_bytes = 0;
+    (void)hipFree(s->d_tiles); s->d_tiles = nullptr; s->tiles_cap = 0;
+    for (auto& ls : s->sets) {
+        (void)hipFree(ls.d_slab); ls.d_slab = nullptr; ls.slab_cap = 0;
+        (void)hipFree(ls.d_queue); ls.d_queue = nullptr;
+        (void)hipFree(ls.d_stream); ls.d_stream = nullptr; ls.stream_cap = 0;
+        if (ls.done) (void)hipEventDestroy(ls.done);
+        if (ls.launched) (void)hipEventDestroy(ls.launched);
+        ls.done = nullptr; ls.launched = nullptr; ls.used = false;
+    }
+    (void)hipFree(s->d_counters); s->d_counters = nullptr;
+    (void)hipFree(s->d_out); s->d_out = nullptr; s->out_cap = 0;
+    for (auto& e : s->evs)
+        if (e) (void)hipEventDestroy(e);
+    s->evs.clear();
+    if (s->photon) rpti::photon_release(s->photon);
+    s->photon = nullptr;
+    s->committed = false;
+}
+
 void rpt_scene_destroy(rpt_scene* s) {
     if (!s) return;
-    if (s->committed) {
-        (void)hipSetDevice(s->device);
-        (void)hipFree(s->arena);
-        (void)hipFree(s->arena64);
-        (void)hipFree(s->d_tiles);
-        for (auto& ls : s->sets) {
-            (void)hipFree(ls.d_slab);
-            (void)hipFree(ls.d_queue);
-            (void)hipFree(ls.d_stream);
-            if (ls.done) (void)hipEventDestroy(ls.done);
-            if (ls.launched) (void)hipEventDestroy(ls.launched);
-        }
-        (void)hipFree(s->d_counters);
-        (void)hipFree(s->d_out);
-        for (auto& e : s->evs)
-            if (e) (void)hipEventDestroy(e);
-        if (s->photon) rpti::photon_release(s->photon);
-    }
+    release_device(s);
     delete s;
 }
 
@@ -1961,7 +1970,7 @@ int rpt_scene_commit(rpt_scene* s, int device) {
     if (rc) return rc;
     if (s->opt.epsilon_policy == 1) {
         rc = build_scene64(s);
-        if (rc) { s->committed = false; return rc; }
+        if (rc) { release_device(s); return rc; }
     }
     return RPT_OK;
 }
