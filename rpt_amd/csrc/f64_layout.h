@@ -93,6 +93,7 @@ struct TriShade {
 
 struct Scene {
     const CullBox* cull;        // [n_objects]: one per record (a group's children are records of their own)
+    const CullBox* cull32;      // [ceil(n_objects / 32)]: the union of the boxes of records 32 g .. 32 g + 31 (unbounded if one of them is)
     const ObjRec* recs;         // [n_objects]
     const ObjShade* shade;      // [n_objects]
     const FrameRec* frames;     // group levels (ObjRec::frame)

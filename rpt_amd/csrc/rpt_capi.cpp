@@ -1838,13 +1838,25 @@ static int build_scene64(rpt_scene* s) {
             fill_mat64(hl.obj.mat, L.mat);
         }
     }
+    std::vector<rpt64::CullBox> cull_groups((n + 31) / 32);
+    for (size_t g = 0; g < cull_groups.size(); g++) {
+        rpt64::CullBox u{};
+        for (int k = 0; k < 3; k++) { u.lo[k] = HUGE_VALF; u.hi[k] = -HUGE_VALF; }
+        for (size_t i = 32 * g; i < std::min(n, 32 * g + 32); i++) {
+            if (cull[i].unbounded) u.unbounded = 1u;
+            for (int k = 0; k < 3; k++) { u.lo[k] = std::min(u.lo[k], cull[i].lo[k]); u.hi[k] = std::max(u.hi[k], cull[i].hi[k]); }
+        }
+        if (u.unbounded) for (int k = 0; k < 3; k++) u.lo[k] = u.hi[k] = 0.f;
+        cull_groups[g] = u;
+    }
     struct Part { const void* src; size_t bytes, off; };
     Part parts[] = {{cull.data(), cull.size() * sizeof(rpt64::CullBox), 0},       {recs.data(), recs.size() * sizeof(rpt64::ObjRec), 0},
                     {shade.data(), shade.size() * sizeof(rpt64::ObjShade), 0},    {trecs.data(), trecs.size() * sizeof(rpt64::TriRec), 0},
                     {tshade.data(), tshade.size() * sizeof(rpt64::TriShade), 0},  {tris.data(), tris.size() * sizeof(rpt64::Tri), 0},
                     {tri_pdf.data(), tri_pdf.size() * sizeof(double), 0},         {lights.data(), lights.size() * sizeof(rpt64::Light), 0},
                     {F.frames.data(), F.frames.size() * sizeof(rpt64::FrameRec), 0}, {F.fshade.data(), F.fshade.size() * sizeof(rpt64::FrameShade), 0},
-                    {s->hdri64.data(), s->hdri64.size() * sizeof(double), 0}};
+                    {s->hdri64.data(), s->hdri64.size() * sizeof(double), 0},
+                    {cull_groups.data(), cull_groups.size() * sizeof(rpt64::CullBox), 0}};
     size_t total = 0;
     for (auto& p : parts) { p.off = total; total = (total + p.bytes + 255) & ~size_t(255); }
     total = std::max<size_t>(total, 256);
@@ -1866,6 +1878,7 @@ static int build_scene64(rpt_scene* s) {
     v.frames = reinterpret_cast<const rpt64::FrameRec*>(base + parts[8].off);
     v.fshade = reinterpret_cast<const rpt64::FrameShade*>(base + parts[9].off);
     v.hdri = reinterpret_cast<const double*>(base + parts[10].off);
+    v.cull32 = reinterpret_cast<const rpt64::CullBox*>(base + parts[11].off);
     v.hdri_w = s->hdri64.empty() ? 0u : s->hdri_w;
     v.hdri_h = s->hdri64.empty() ? 0u : s->hdri_h;
     v.n_objects = uint32_t(n);
