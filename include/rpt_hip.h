@@ -321,9 +321,9 @@ int rpt_frame_unpack_device(uint32_t width, uint32_t height, uint32_t rank, uint
  * colours, no fused multiply-adds (only the objects a ray's padded fp32 box test keeps are evaluated -- the result is that of
  * the full scan bit for bit; option "f64_cull" = 0 runs the full scan).  Same entry points (rpt_render_sample*,
  * rpt_render_into_buffer), same RNG streams, same sharding; 4-5 times slower than the fp32 path (C3: 2.9 Gsamples/s).
- * Supported: spheres, cubes, planes, meshes (scanned triangle by triangle), KdTree groups of them as objects (nested at
- * most three deep), all materials, lights and media, Environment::Color and Environment::Hdri.  Refused with
- * RPT_ERR_UNSUPPORTED: a KdTree group as a Light::Object, photon mapping.
+ * Supported: spheres, cubes, planes, meshes (scanned triangle by triangle), KdTree groups of them as objects and as
+ * Light::Objects (nested at most three deep), all materials, lights and media, Environment::Color and Environment::Hdri.
+ * Refused with RPT_ERR_UNSUPPORTED: groups nested deeper, photon mapping.
  * Options of the mode: "f64_cull" (1; 0 = full scan, 2 = the counters build keeps the search limits), "f64_surf_batch"
  * (8: lanes of a wave that wait at a surface event in a medium before the wave runs the surface code).
  * rpt_debug_epsilon_counters (option "counters" = 1): [0] closest-hit queries, [1] accepted hits, [2] accepted hits with

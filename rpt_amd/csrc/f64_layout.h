@@ -17,14 +17,15 @@
 
 namespace rpt64 {
 
-enum : int32_t { SH_SPHERE = 0, SH_CUBE = 1, SH_PLANE = 2, SH_MESH = 3 };
+enum : int32_t { SH_SPHERE = 0, SH_CUBE = 1, SH_PLANE = 2, SH_MESH = 3, SH_GROUP = 4 };   // (SH_GROUP: in a light's shape tree only)
 enum : int32_t { LT_POINT = 0, LT_AMBIENT = 1, LT_DIRECTIONAL = 2, LT_OBJECT = 3 };
 
 // One `Box<dyn Shape>`: unit primitive / plane / mesh, optionally under Transformed<T> (src/shape.rs:102-152).  The full
 // record: what Shape::sample of a light needs (wave-uniform, scalar loads).
 struct Shape {
     int32_t kind, has_xf;
-    uint32_t tri_first, tri_count;   // SH_MESH: triangles in the mesh's own (local) space, in the order they were given
+    uint32_t tri_first, tri_count;   // SH_MESH: triangles in the mesh's own (local) space, in the order they were given;
+                                     // SH_GROUP (a `KdTree<Box<dyn Bounded>>` as a Light::Object): its children in Scene::lshapes
     double inv[12];     // rows of M^-1 (3 x 4)            Transformed::inverse_transform
     double fwd[12];     // rows of M (3 x 4)               Transformed::transform
     double lin[9];      // linear part of M                Transformed::linear
@@ -103,6 +104,7 @@ struct Scene {
     const Tri* tris;            // [n_tris]: vertices and normals as given -- the objects' triangles, then those of the lights' meshes (Triangle::sample)
     const double* tri_pdf;      // [n_tris]: (1 / area) / triangles of the mesh (src/shape/mesh.rs:96-98, src/kdtree.rs:141-146)
     const Light* lights;
+    const Shape* lshapes;       // the shapes inside the groups of group lights (KdTree::sample picks one per sample, per lane)
     uint32_t n_objects, n_lights, n_tris, n_obj_tris;
     int32_t has_medium, medium_kind;
     double absorption, scattering;
@@ -121,7 +123,8 @@ struct Args {
     uint32_t width, height, iterations, sample_offset, max_bounces;
     uint32_t n_owned, tiles_x, n_items;
     uint32_t chunk_spp, n_chunks, pull_batch, cull;   // cull: 0 = every object is evaluated for every ray (the plain reference scan)
-    uint32_t surf_batch, _pad;                         // in a medium: lanes of a wave that wait at a surface event before the wave runs the surface code
+    uint32_t surf_batch;      // in a medium: lanes of a wave that wait at a surface event before the wave runs the surface code
+    uint32_t group_lights;    // some Light::Object is a KdTree group (its own kernel instantiation)
     const uint32_t* tiles;
     uint64_t seed_mixed;
     double medium_color[3], medium_color_hi[3];   // Medium::color: hex_color(0xD2B48C), or blue (y <= 250) / red for the glowing fog

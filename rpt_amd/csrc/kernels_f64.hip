@@ -479,12 +479,58 @@ R64_DEV void sample_shape(const S& s, D target, Rng64& rng, D& v, D& n, double& 
     n = new_normal;
     p = pl / base;
 }
+// Transformed::sample's second half (src/shape.rs:143-150): the sample of the inner shape carried into the outer space
+template <class S>
+R64_DEV void transformed_sample_out(const S& s, D& v, D& n, double& p) {
+    const D new_normal = normalize(mul3(s.nrm, n));
+    const double height = dot(mul3(s.lin, n), new_normal);
+    const double base = s.det / height;
+    v = xf_point(s.fwd, v);
+    n = new_normal;
+    p = p / base;
+}
+// Shape::sample of a light's shape, which may be a `KdTree<Box<dyn Bounded>>` (KdTree::sample, src/kdtree.rs:141-146: a uniformly
+// chosen child's sample, its pdf divided by the number of children), nested up to three groups deep, every level possibly
+// under its own Transformed.  The light's own record is wave-uniform; the children a lane picks are its own (global loads).
+template <class S>
+R64_DEV void sample_light_shape(const S& top, D target, Rng64& rng, D& v, D& n, double& p) {
+    if (top.kind != SH_GROUP) return sample_shape(top, target, rng, v, n, p);
+    const Shape* const pool = KA.sc.lshapes;
+    D tgt = top.has_xf ? xf_point(top.inv, target) : target;
+    const Shape* c1 = pool + top.tri_first + rng.index(top.tri_count);
+    const Shape* c2 = nullptr;
+    const Shape* c3 = nullptr;
+    const Shape* leaf = c1;
+    if (c1->kind == SH_GROUP) {
+        if (c1->has_xf) tgt = xf_point(c1->inv, tgt);
+        c2 = pool + c1->tri_first + rng.index(c1->tri_count);
+        leaf = c2;
+        if (c2->kind == SH_GROUP) {
+            if (c2->has_xf) tgt = xf_point(c2->inv, tgt);
+            c3 = pool + c2->tri_first + rng.index(c2->tri_count);
+            leaf = c3;   // (a shape: the commit refuses deeper nesting)
+        }
+    }
+    sample_shape(*leaf, tgt, rng, v, n, p);
+    // back out: a group divides the pdf by its number of children, then its own Transformed::sample carries the sample outwards
+    if (c3) {
+        p = p / double(c2->tri_count);
+        if (c2->has_xf) transformed_sample_out(*c2, v, n, p);
+    }
+    if (c2) {
+        p = p / double(c1->tri_count);
+        if (c1->has_xf) transformed_sample_out(*c1, v, n, p);
+    }
+    p = p / double(top.tri_count);
+    if (top.has_xf) transformed_sample_out(top, v, n, p);
+}
 // Light::illuminate for Light::Object, src/light.rs:34-45
-template <class LT>
+template <bool GROUPL, class LT>
 R64_DEV void illuminate_object(const LT& L, D pos, Rng64& rng, D& intensity, D& wi, double& dist) {
     D v, n;
     double p;
-    sample_shape(L.shape, pos, rng, v, n, p);
+    if constexpr (GROUPL) sample_light_shape(L.shape, pos, rng, v, n, p);
+    else sample_shape(L.shape, pos, rng, v, n, p);
     const D disp = v - pos;
     const double len = length(disp);
     const double cosine = fmax(-dot(disp, n), 0.0) / len;
@@ -625,7 +671,9 @@ static constexpr uint32_t kLdsDoubles = kSlotBase + 4u * 32u;
 static_assert(sizeof(ObjRec) == 176 && sizeof(TriRec) == 128 && sizeof(CullBox) == 32 && sizeof(FrameRec) == 144, "record sizes");
 static_assert(kLdsDoubles * 8u * 4u <= 160u * 1024u, "four blocks per CU");
 
-template <bool MEDIUM, bool COUNT, bool LDSTAB>
+// GROUPL: some Light::Object is a KdTree group (per-lane child choice, sample_light_shape): an instantiation of its own, as in the fp32
+// megakernel -- inlined beside the wave-uniform sampler it cost C3 1.3 % through register allocation alone.
+template <bool MEDIUM, bool COUNT, bool LDSTAB, bool GROUPL = false>
 __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a_by_value) {
     (void)a_by_value;   // (read through KA)
     extern __shared__ double lds64[];
@@ -873,7 +921,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void render_f64_kernel(const Args a
                     if (active) {
                         SECT64(18);
                         D I, wi;
-                        illuminate_object(L, ro, rng, I, wi, dist);
+                        illuminate_object<GROUPL>(L, ro, rng, I, wi, dist);
                         // the light's term of E if it proves visible
                         if (ev_medium) {
                             SECT64(19);
@@ -972,10 +1020,14 @@ namespace rptg {
 template <bool M, bool C>
 static hipError_t launch_f64_t(const rpt64::Args& a, int n_blocks, hipStream_t stream) {
     const size_t lds = size_t(rpt64::kLdsDoubles) * 8u;
-    if (a.sc.n_objects <= rpt64::kLdsObjs && a.sc.n_obj_tris <= rpt64::kLdsTris)
-        hipLaunchKernelGGL((rpt64::render_f64_kernel<M, C, true>), dim3(n_blocks), dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL((rpt64::render_f64_kernel<M, C, false>), dim3(n_blocks), dim3(256), lds, stream, a);
+    const bool tab = a.sc.n_objects <= rpt64::kLdsObjs && a.sc.n_obj_tris <= rpt64::kLdsTris;
+    if (a.group_lights) {
+        if (tab) hipLaunchKernelGGL((rpt64::render_f64_kernel<M, C, true, true>), dim3(n_blocks), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((rpt64::render_f64_kernel<M, C, false, true>), dim3(n_blocks), dim3(256), lds, stream, a);
+    } else {
+        if (tab) hipLaunchKernelGGL((rpt64::render_f64_kernel<M, C, true, false>), dim3(n_blocks), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((rpt64::render_f64_kernel<M, C, false, false>), dim3(n_blocks), dim3(256), lds, stream, a);
+    }
     return hipGetLastError();
 }
 hipError_t launch_render_f64(const rpt64::Args& a, int n_blocks, hipStream_t stream) {
@@ -992,6 +1044,6 @@ hipError_t launch_resolve_f64(const rpt64::Args& a, double scale, double* d_out,
 hipError_t render_f64_occupancy(bool medium, int* blocks_per_cu) {
     const size_t lds = size_t(rpt64::kLdsDoubles) * 8u;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        blocks_per_cu, medium ? (const void*)rpt64::render_f64_kernel<true, false, true> : (const void*)rpt64::render_f64_kernel<false, false, true>, 256, lds);
+        blocks_per_cu, medium ? (const void*)rpt64::render_f64_kernel<true, false, true, false> : (const void*)rpt64::render_f64_kernel<false, false, true, false>, 256, lds);
 }
 }  // namespace rptg

@@ -1571,14 +1571,12 @@ static int check_scene64(const rpt_scene* s) {   // what the mode refuses, befor
         if (depth(o.shape) > int(rpt64::kMaxFrames))
             return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports KdTree groups nested at most three deep");
     for (const auto& l : s->lights)
-        if (l.kind == int(L_OBJECT) && l.obj.shape.d.kind == RPT_SHAPE_GROUP)
-            return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 does not support a KdTree group as a Light::Object");
+        if (l.kind == int(L_OBJECT) && depth(l.obj.shape) > int(rpt64::kMaxFrames))
+            return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports KdTree groups nested at most three deep");
     return RPT_OK;
 }
 static int fill_shape64(const HShape& hs, rpt64::Shape& o, std::vector<rpt64::Tri>& tris, std::vector<double>& tri_pdf,
                         std::unordered_map<const std::vector<double>*, uint32_t>* shared = nullptr) {
-    if (hs.d.kind == RPT_SHAPE_GROUP)
-        return fail(RPT_ERR_UNSUPPORTED, "epsilon_policy = 1 supports sphere, cube, plane and mesh shapes (no KdTree groups)");
     std::memset(&o, 0, sizeof(o));
     o.kind = hs.d.kind;
     Xf x;
@@ -1804,6 +1802,23 @@ static int flatten64(const HShape& hs, const rpt_material& mat, std::vector<uint
     F.shade.push_back(os);
     return RPT_OK;
 }
+// A light's shape tree (a KdTree group as Light::Object): `out` gets the group's record, its children a contiguous block of
+// `pool` (their own children further back), so that KdTree::sample's choice is one index computation.
+static int fill_light_shape64(const HShape& hs, rpt64::Shape& out, std::vector<rpt64::Shape>& pool, Flat64& F) {
+    if (int rc = fill_shape64(hs, out, F.tris, F.tri_pdf, &F.shared_meshes)) return rc;
+    if (hs.d.kind != RPT_SHAPE_GROUP) return RPT_OK;
+    out.kind = rpt64::SH_GROUP;
+    const size_t first = pool.size();
+    out.tri_first = uint32_t(first);
+    out.tri_count = uint32_t(hs.children.size());
+    pool.resize(first + hs.children.size());
+    for (size_t c = 0; c < hs.children.size(); c++) {
+        rpt64::Shape child;   // (pool may grow while the child's own children are filled in)
+        if (int rc = fill_light_shape64(hs.children[c], child, pool, F)) return rc;
+        pool[first + c] = child;
+    }
+    return RPT_OK;
+}
 static int build_scene64(rpt_scene* s) {
     static_assert(sizeof(rpt64::Tri) == 18 * sizeof(double), "a triangle is its 18 doubles");
     if (int rc = check_scene64(s)) return rc;
@@ -1820,6 +1835,7 @@ static int build_scene64(rpt_scene* s) {
     std::vector<double>& tri_pdf = F.tri_pdf;
     const size_t n = recs.size();
     std::vector<rpt64::Light> lights(s->lights.size());
+    std::vector<rpt64::Shape> lshapes;
     const size_t n_obj_tris = tris.size();
     std::vector<rpt64::TriRec> trecs(n_obj_tris);
     std::vector<rpt64::TriShade> tshade(n_obj_tris);
@@ -1834,7 +1850,7 @@ static int build_scene64(rpt_scene* s) {
         L.kind = hl.kind;
         for (int k = 0; k < 3; k++) L.color[k] = hl.color[k];
         if (hl.kind == int(L_OBJECT)) {
-            if (int rc = fill_shape64(hl.obj.shape, L.shape, tris, tri_pdf)) return rc;
+            if (int rc = fill_light_shape64(hl.obj.shape, L.shape, lshapes, F)) return rc;
             fill_mat64(hl.obj.mat, L.mat);
         }
     }
@@ -1856,7 +1872,8 @@ static int build_scene64(rpt_scene* s) {
                     {tri_pdf.data(), tri_pdf.size() * sizeof(double), 0},         {lights.data(), lights.size() * sizeof(rpt64::Light), 0},
                     {F.frames.data(), F.frames.size() * sizeof(rpt64::FrameRec), 0}, {F.fshade.data(), F.fshade.size() * sizeof(rpt64::FrameShade), 0},
                     {s->hdri64.data(), s->hdri64.size() * sizeof(double), 0},
-                    {cull_groups.data(), cull_groups.size() * sizeof(rpt64::CullBox), 0}};
+                    {cull_groups.data(), cull_groups.size() * sizeof(rpt64::CullBox), 0},
+                    {lshapes.data(), lshapes.size() * sizeof(rpt64::Shape), 0}};
     size_t total = 0;
     for (auto& p : parts) { p.off = total; total = (total + p.bytes + 255) & ~size_t(255); }
     total = std::max<size_t>(total, 256);
@@ -1879,6 +1896,7 @@ static int build_scene64(rpt_scene* s) {
     v.fshade = reinterpret_cast<const rpt64::FrameShade*>(base + parts[9].off);
     v.hdri = reinterpret_cast<const double*>(base + parts[10].off);
     v.cull32 = reinterpret_cast<const rpt64::CullBox*>(base + parts[11].off);
+    v.lshapes = reinterpret_cast<const rpt64::Shape*>(base + parts[12].off);
     v.hdri_w = s->hdri64.empty() ? 0u : s->hdri_w;
     v.hdri_h = s->hdri64.empty() ? 0u : s->hdri_h;
     v.n_objects = uint32_t(n);
@@ -1928,6 +1946,9 @@ static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_pa
     q.pull_batch = a.pull_batch;
     q.cull = uint32_t(s->opt.f64_cull);
     q.surf_batch = uint32_t(s->opt.f64_surf_batch);
+    q.group_lights = 0u;
+    for (const auto& l : s->lights)
+        if (l.kind == int(L_OBJECT) && l.obj.shape.d.kind == RPT_SHAPE_GROUP) q.group_lights = 1u;
     q.seed_mixed = a.seed_mixed;
     q.dim = double(std::max(prm->width, prm->height));
     q.queue = a.queue;

@@ -244,6 +244,44 @@ def test_hdri_environment_follows_the_literal_oracle():
         assert abs(got.mean() - exp.mean()) < 2e-4 * exp.mean(), fog
 
 
+@pytest.mark.parametrize("fog", [False, True])
+def test_group_as_object_light_follows_the_literal_oracle(fog):
+    """Light::Object over a KdTree (src/light.rs:38-55 with KdTree::sample, src/kdtree.rs:141-146): a uniformly chosen child, nested
+    groups and per-level transforms included; the same group is also a scene object, the twin the shadow test must meet at exactly
+    the sampled distance (|hit - dist| < 1e-12)."""
+    from rpt_amd import KdTree, Mesh
+    lamp_kids = [
+        sphere().scale(vec3(0.3, 0.3, 0.3)).translate(vec3(-1.5, 2.5, 0.0)),
+        cube().scale(vec3(0.5, 0.1, 0.5)).rotate_y(0.5).translate(vec3(1.5, 2.6, 0.3)),
+        Mesh(scenes.bumpy_torus(4, 3)).scale(vec3(0.4, 0.4, 0.4)).translate(vec3(0.0, 2.4, -1.0)),
+        KdTree([sphere().scale(vec3(0.2, 0.2, 0.2)).translate(vec3(0.0, 0.0, 1.0)),
+                KdTree([sphere().scale(vec3(0.15, 0.3, 0.15)).translate(vec3(0.6, 0.0, 1.2))]).rotate_x(0.2)]).translate(vec3(0.0, 2.3, 0.0)),
+    ]
+    glow = Material.light(vec3(1.0, 0.9, 0.7), 25.0)
+
+    def lamp():
+        return KdTree([k.clone() for k in lamp_kids]).rotate_z(0.1).translate(vec3(0.0, 0.2, 0.0))
+
+    sc = Scene()
+    sc.add(Object(lamp()).material(glow))
+    sc.add(Light.Object(Object(lamp()).material(glow)))
+    sc.add(Object(plane(vec3(0, 1, 0), -1.0)).material(Material.diffuse(vec3(0.8, 0.8, 0.8))))
+    sc.add(Object(sphere().translate(vec3(0.0, 0.0, 0.0))).material(Material.specular(vec3(0.9, 0.5, 0.5), 0.3)))
+    sc.add(Object(cube().translate(vec3(2.0, -0.5, 0.5))).material(Material.diffuse(vec3(0.3, 0.8, 0.4))))
+    if fog:
+        sc.add(Medium.homogeneous_isotropic(0.02, 0.05))
+    cam = Camera.look_at(vec3(0.0, 1.5, 7.0), vec3(0.0, 1.0, 0.0), vec3(0, 1, 0), 0.9)
+    w, h, spp = 80, 60, 32
+    r = _eps_renderer(sc, cam).width(w).height(h).max_bounces(3).seed(9)
+    got = r.sample_array(spp)
+    cnt = _eps_counters(r)
+    exp, oc = _oracle(sc).render(cam, w, h, spp, 3, seed=9, robust=0, counters=True)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert rel_rms(got, exp) < 5e-3 and abs(got.mean() - exp.mean()) < 5e-4 * exp.mean()
+    for k in ("rays", "shadow_tests", "shadow_pass"):
+        assert abs(cnt[k] - oc[k]) <= 2e-3 * max(oc[k], 1) + 2, (k, cnt[k], oc[k])
+
+
 def test_what_the_mode_refuses():
     from rpt_amd import KdTree
     deep = sphere()
@@ -254,9 +292,9 @@ def test_what_the_mode_refuses():
     sc.set_option("epsilon_policy", 1)
     with pytest.raises(RptError):
         Renderer(sc, Camera.look_at(vec3(0, 0, 5), vec3(0, 0, 0), vec3(0, 1, 0), 0.6)).width(8).height(8).sample_array(1)
-    sc = Scene()                                           # a group as a Light::Object
+    sc = Scene()                                           # ... as a Light::Object as well
     sc.add(Object(sphere()).material(Material.diffuse(vec3(1, 1, 1))))
-    sc.add(Light.Object(Object(KdTree([sphere(), sphere().translate(vec3(3, 0, 0))])).material(Material.light(vec3(1, 1, 1), 5.0))))
+    sc.add(Light.Object(Object(deep.clone()).material(Material.light(vec3(1, 1, 1), 5.0))))
     sc.set_option("epsilon_policy", 1)
     with pytest.raises(RptError):
         Renderer(sc, Camera.look_at(vec3(0, 0, 5), vec3(0, 0, 0), vec3(0, 1, 0), 0.6)).width(8).height(8).sample_array(1)
