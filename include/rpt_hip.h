@@ -344,6 +344,13 @@ int rpt_debug_material_bsdf(const rpt_material*, uint64_t n, const float* normal
  * exclusive prefix sums of two u32 arrays with their 64-bit totals. */
 int rpt_debug_radix_sort(uint64_t n, const uint64_t* keys, uint64_t* keys_out, uint32_t* order_out);
 int rpt_debug_exclusive_scan2(uint64_t n, const uint32_t* a, const uint32_t* b, uint32_t* out_a, uint32_t* out_b, uint64_t totals[2]);
+/* Reference-epsilon mode: the surface photons' positions as the shooting pass holds them (fp64, 3 per photon, shooting order -- the
+ * order of rpt_photon_map_download(which = 0)); capacity in photons. */
+int rpt_debug_photon_positions64(rpt_scene*, double* out, uint64_t capacity);
+/* ... and what the last camera pass (its last slice) handed from the k-nearest selection to the fp64 surface estimate:
+ * dims = {owned pixel slots, gather_size + 2, samples}; out[slot][row][sample], rows: photon indices (sorted order), their number,
+ * the squared distance of the farthest (float bits).  out may be null (dims only). */
+int rpt_debug_photon_selections(rpt_scene*, uint32_t* out, uint64_t capacity_words, uint64_t dims[3]);
 int rpt_debug_camera_rays(const rpt_camera*, const rpt_render_params*, uint64_t seed, uint32_t sample,
                           float* origins, float* dirs); /* one ray per pixel, width*height*3 each */
 

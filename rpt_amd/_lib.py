@@ -133,6 +133,8 @@ SYMBOLS = [
     ("rpt_debug_material_bsdf", C.c_int, [C.POINTER(MaterialDesc), C.c_uint64, _P, _P, _P, _P]),
     ("rpt_debug_radix_sort", C.c_int, [C.c_uint64, _P, _P, _P]),
     ("rpt_debug_exclusive_scan2", C.c_int, [C.c_uint64, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
+    ("rpt_debug_photon_positions64", C.c_int, [_P, _P, C.c_uint64]),
+    ("rpt_debug_photon_selections", C.c_int, [_P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("rpt_debug_camera_rays", C.c_int,
      [C.POINTER(CameraDesc), C.POINTER(RenderParams), C.c_uint64, C.c_uint32, _P, _P]),
 ]

@@ -868,6 +868,22 @@ class Renderer:
         _lib.check(lib.rpt_photon_map_download(h, which, arr.ctypes.data_as(C.c_void_p), n))
         return arr
 
+    def photon_positions64(self):
+        """Reference-epsilon mode: the surface photons' fp64 positions, (n, 3), in the order of photon_map_download(0)."""
+        n = self._photon_stats()["surface"]
+        out = np.zeros((n, 3), dtype=np.float64)
+        _lib.check(_lib.load().rpt_debug_photon_positions64(self.scene._handle, out.ctypes.data_as(C.c_void_p), n))
+        return out
+
+    def photon_selections(self):
+        """Reference-epsilon mode, test hook: the last camera pass's per-sample selections, (pixel slots, gather_size + 2, samples) u32."""
+        lib = _lib.load()
+        dims = (C.c_uint64 * 3)()
+        _lib.check(lib.rpt_debug_photon_selections(self.scene._handle, None, 0, dims))
+        out = np.zeros((int(dims[0]), int(dims[1]), int(dims[2])), dtype=np.uint32)
+        _lib.check(lib.rpt_debug_photon_selections(self.scene._handle, out.ctypes.data_as(C.c_void_p), out.size, dims))
+        return out
+
     def photon_sample_array(self, num_samples):
         """get_color_with_photon_map over the frame (photon.rs:706-716): (h*w, 3) fp64 means."""
         lib = _lib.load()

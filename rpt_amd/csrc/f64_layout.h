@@ -135,4 +135,37 @@ struct Args {
                                     // [8] objects evaluated [9] evaluation rounds (wave-level) [10] trips (wave-level) [11] live lanes summed over trips; or null
 };
 
+// ---- photon mapping in the reference-epsilon mode (kernels_f64.hip; the maps, the k-nearest selection and the volume estimates are
+// photon.hip's, on the records in fp32)
+struct PhotonRec32 {   // photon.hip's PhotonRec: position + gather radius, direction + index in shooting order (bits), power
+    float pos_r[4], dir[4], pow[4];
+};
+// shoot_photon + trace_photon (src/photon.rs:724-946) with the reference's own epsilons: count pass (surf == null), then write pass.
+struct ShootArgs64 {
+    Args a;                     // scene, a.queue (photons handed out 64 at a time), a.seed_mixed, a.cull
+    uint64_t n_photons;         // photons of THIS launch
+    uint64_t first_photon;      // global index of its first photon (the RNG stream key)
+    double power;               // watts / photon_count (of the whole map)
+    uint32_t light_index;       // the first Light::Object
+    uint32_t kind;              // RPT_PHOTON_*: the beam x beam map thins the volume photons and records each beam's start
+    uint32_t* cnt_s;            // [n_photons] records per photon (count pass)
+    uint32_t* cnt_v;
+    const uint32_t* off_s;      // their exclusive prefix sums (write pass)
+    const uint32_t* off_v;
+    PhotonRec32* surf;
+    PhotonRec32* vol;
+    double* pos64;              // [3 per surface record, shooting order]: the position as the reference holds it
+};
+// The surface estimate of the camera pass (src/photon.rs:327-375): the gathered photons' visibility rays and terms, per sample.
+struct SurfArgs64 {
+    Args a;                     // a.iterations = samples of this slice, a.n_chunks = groups of 64 of them, a.slab [group][n_owned][4]
+    const uint32_t* emit;       // [n_owned][K + 2][iterations]: what the fp32 camera pass selected per sample -- K photon indices
+                                // (sorted order), their number, the squared distance of the farthest (float bits)
+    const PhotonRec32* s_ph;    // the surface map's photons in sorted order
+    const double* pos64;        // ShootArgs64::pos64 of the map
+    uint32_t K;                 // gather_size
+    uint32_t kind;              // RPT_PHOTON_*
+    uint32_t skip;              // diagnostic (option "photon_skip"): 4096 = every gathered photon counts (no visibility rays)
+};
+
 }  // namespace rpt64

@@ -8,6 +8,8 @@
 #include "../../include/rpt_hip.h"
 #include "kernels.h"
 
+namespace rpt64 { struct Args; }
+
 namespace rpti {
 int fail(int code, const std::string& msg);
 uint64_t seed_mix(uint64_t seed);
@@ -16,7 +18,7 @@ struct SceneDev {
     int device, n_cus;
     rptg::SceneView view;
     int first_object_light;  // index into scene.lights of the first Light::Object, or -1
-    bool epsilon64;          // committed in the reference-epsilon mode (fp64 path tracer only: photon mapping is refused)
+    bool epsilon64;          // committed in the reference-epsilon mode (epsilon_policy = 1)
 };
 SceneDev scene_dev(rpt_scene* s);
 void*& photon_slot(rpt_scene* s);  // owned by photon.hip (PhotonMapDev*), released through photon_release
@@ -38,8 +40,11 @@ int run_persistent(rpt_scene* s, const rpt_render_params* prm, const rptg::Rende
                    const std::function<hipError_t(double, double*, hipStream_t)>& resolve = nullptr);   // (scale, d_out, stream): instead of resolve_kernel
 int serialize_with_other_streams(rpt_scene* s, hipStream_t st);  // for launches with per-scene scratch outside the launch set
 int fetch_counters(rpt_scene* s, const rptg::RenderArgs& a);  // after the stream has been synchronised
+// Arguments the fp64 kernels share (rpt_capi.cpp): scene; camera, frame and `a`'s tiles / chunking / work counter / slab when given.
+void fill_args64(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, const rptg::RenderArgs* a, rpt64::Args& q);
 double* scratch_out(rpt_scene* s, size_t bytes);  // cached device frame for the host-buffer entry points
 int64_t option_photon_skip(rpt_scene* s);  // option "photon_skip" of the scene: diagnostic bit mask for the camera pass
+int64_t option_f64_photon_slice(rpt_scene* s);    // option "f64_photon_slice": samples per slice of the reference-epsilon photon camera pass (0: automatic)
 int64_t option_photon_parts(rpt_scene* s);        // option "photon_parts": strips per 8x8 pixel block of the camera pass (1, 2, 4, 8)
 int64_t option_photon_coop_gather(rpt_scene* s);  // option "photon_coop_gather": wave-level surface gather on (default) / off
 int64_t option_photon_split(rpt_scene* s);        // option "photon_split": volume and surface estimate of the beam kinds in two launches (default off: measured slower)

@@ -77,10 +77,15 @@ hipError_t launch_debug_camera(const CameraG& cam, uint32_t w, uint32_t h, uint6
                                float* d_o, float* d_d, hipStream_t s);
 
 }  // namespace rptg
-namespace rpt64 { struct Args; }
+namespace rpt64 { struct Args; struct ShootArgs64; struct SurfArgs64; }
 namespace rptg {
 // Reference-epsilon mode (kernels_f64.hip): persistent grid over (pixel, chunk) items with an fp64 slab, then its resolve.
 hipError_t launch_render_f64(const rpt64::Args& a, int n_blocks, hipStream_t stream);
 hipError_t launch_resolve_f64(const rpt64::Args& a, double scale, double* d_out, hipStream_t stream);
 hipError_t render_f64_occupancy(bool medium, int* blocks_per_cu);
+// Photon mapping in that mode: the shooting pass (count pass when a.surf and a.vol are null) and the camera pass's surface estimate.
+hipError_t launch_photon_shoot_f64(const rpt64::ShootArgs64& a, int n_blocks, hipStream_t stream);
+hipError_t launch_photon_surface_f64(const rpt64::SurfArgs64& a, int n_blocks, hipStream_t stream);
+hipError_t launch_resolve_photon_f64(const rpt64::Args& a, const void* slab32, uint32_t n_chunks32, double scale_over_total, bool accumulate,
+                                     double* d_out, hipStream_t stream);
 }  // namespace rptg

@@ -1014,6 +1014,317 @@ __global__ __launch_bounds__(256) void resolve_f64_kernel(const Args a, double s
     out[o + 2] = b * inv;
 }
 
+
+// ============================================================================ photon mapping with the reference's epsilons
+// The parts of src/photon.rs whose outcome hangs on the epsilon policy run here, in fp64 and through closest_hit_wave: the
+// shooting pass (a photon that leaves a surface meets that surface again whenever rounding puts the hit beyond t_min = 1e-12,
+// and is then scattered a second time at the same spot, src/photon.rs:803-946 with src/renderer.rs:420) and the surface
+// estimate's visibility rays (a gathered photon counts unless `len > hit.time`, :357-361: the ray's own far end decides that by
+// its last bits).  The maps over the records (LBVH, radii), the k-nearest selection and the volume estimates have no epsilon in
+// them and stay photon.hip's, in fp32: its camera pass hands each sample's selection over (SurfArgs64::emit).
+#define KS (*rptg::kernarg_args<ShootArgs64>())
+#define KQ (*rptg::kernarg_args<SurfArgs64>())
+static constexpr uint32_t kPhSlotBase = kLdsObjs * kObjDoubles + kLdsTris * kTriDoubles;   // LDS of these kernels: [tables][4 x 64 slot dwords]
+static constexpr uint32_t kPhLdsDoubles = kPhSlotBase + 4u * 32u;
+
+template <bool LDSTAB>
+R64_DEV void stage_tables(double* t0, const ObjRec*& recs, const TriRec*& trecs) {
+    recs = KA.sc.recs;
+    trecs = KA.sc.trecs;
+    if constexpr (LDSTAB) {
+        const double* const g0 = reinterpret_cast<const double*>(KA.sc.recs);
+        const double* const g1 = reinterpret_cast<const double*>(KA.sc.trecs);
+        const uint32_t n0 = KA.sc.n_objects * kObjDoubles, n1 = KA.sc.n_obj_tris * kTriDoubles;
+        for (uint32_t i = threadIdx.x; i < n0; i += 256u) t0[i] = g0[i];
+        for (uint32_t i = threadIdx.x; i < n1; i += 256u) t0[kLdsObjs * kObjDoubles + i] = g1[i];
+        __syncthreads();
+        recs = reinterpret_cast<const ObjRec*>(t0);
+        trecs = reinterpret_cast<const TriRec*>(t0 + kLdsObjs * kObjDoubles);
+    }
+}
+
+// One photon per lane; a lane whose photon is absorbed takes the next one of the wave's batch (64 per atomic).  WRITE = false
+// counts the records of every photon; the write pass retraces the same chains (same streams, and closest_hit_wave's record does
+// not depend on which rays share the wave) and stores them at the prefix sums of the counts: the arrays are in shooting order.
+template <bool MEDIUM, bool WRITE, bool LDSTAB>
+__global__ __launch_bounds__(256, R64_WAVES) void photon_shoot_f64_kernel(const ShootArgs64 by_value) {
+    (void)by_value;
+    extern __shared__ double lds64[];
+    const ObjRec* recs;
+    const TriRec* trecs;
+    stage_tables<LDSTAB>(lds64, recs, trecs);
+    volatile uint32_t* const slots = reinterpret_cast<uint32_t*>(lds64 + kPhSlotBase) + (threadIdx.x >> 6) * 64u;
+    const double sigma_t = KA.sc.absorption + KA.sc.scattering;
+    Rng64 rng, thin;
+    rng.r.s0 = rng.r.s1 = rng.r.s2 = rng.r.s3 = 0;
+    thin.r = rng.r;
+    D ro = mk(0, 0, 0), rd = mk(0, 0, 1), power = mk(0, 0, 0);
+    uint32_t ns = 0, nv = 0, os = 0, ov = 0;
+    uint64_t idx = 0;
+    bool have = false;
+    uint64_t pool_next = 0, pool_end = 0;   // wave-uniform
+    bool drained = false;
+    uint32_t ce = 0, cr = 0;
+    for (;;) {
+        // ---- hand-out
+        bool want = !have;
+        while (!drained) {
+            const uint64_t m = __ballot(want);
+            if (m == 0ull) break;
+            if (pool_next == pool_end) {
+                unsigned long long base = 0ull;
+                if ((threadIdx.x & 63u) == 0u) base = atomicAdd(KA.queue, 64ull);
+                const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(base));
+                const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(base >> 32));
+                const uint64_t b = (uint64_t(hi) << 32) | lo;
+                if (b >= KS.n_photons) {
+                    drained = true;
+                    break;
+                }
+                pool_next = b;
+                pool_end = b + 64u < KS.n_photons ? b + 64u : KS.n_photons;
+            }
+            const uint32_t take = min(uint32_t(__popcll(m)), uint32_t(pool_end - pool_next));
+            const uint32_t rank = mbcnt64(m);
+            if (want && rank < take) {   // shoot_photon, src/photon.rs:724-760
+                idx = pool_next + rank;
+                const uint64_t g = KS.first_photon + idx;
+                rng.r.seed(KA.seed_mixed, uint32_t(g), 0x80000000u + uint32_t(g >> 32));
+                thin.r.seed(KA.seed_mixed, uint32_t(g), 0xC0000000u + uint32_t(g >> 32));   // the thinning draws' side stream
+                const Light& L = KA.sc.lights[KS.light_index];
+                D v, n;
+                double p;
+                sample_light_shape(L.shape, mk(0, 0, 0), rng, v, n, p);   // :733-734 (the target is a dummy)
+                const double phi = 2.0 * kPi * rng.uniform();
+                const double theta = acos(1.0 - rng.uniform());
+                const D dir = mk(sin(theta) * cos(phi), cos(theta), sin(theta) * sin(phi));
+                ro = v;
+                rd = rotate_from_y(n, dir, true);
+                power = KS.power * mat_color(L.mat);
+                ns = nv = 0;
+                if (WRITE) {
+                    os = KS.off_s[idx];
+                    ov = KS.off_v[idx];
+                }
+                have = true;
+                want = false;
+            }
+            pool_next += take;
+        }
+        if (__ballot(have) == 0ull) break;
+        // ---- one segment of every lane's chain: trace_photon, :803-946
+        double dmed = kInf;
+        if (MEDIUM && have) dmed = -log(rng.range(0.0, 1.0)) / sigma_t;   // Medium::sample_d (the closest-hit query draws nothing)
+        Query q;
+        closest_hit_wave<false>(recs, trecs, slots, have, ro, rd, dmed, q, ce, cr);   // (a hit beyond the sampled distance changes nothing)
+        if (!have) continue;
+        const bool hit = q.obj >= 0;
+        const D wo = -normalize(rd);
+        bool done = false;
+        if (MEDIUM && (!hit || dmed < q.t)) {   // trace_in_volume, :879-914
+            const D x = ro + dmed * rd;
+            const D mcol = medium_color(x);
+            const double scat = KA.sc.scattering;
+            const bool beams = KS.kind == 2u;
+            const bool keep = !beams || thin.uniform() < 0.001;   // :779-787
+            if (keep) {
+                if (WRITE) {
+                    const double boost = beams ? 1.0 / 0.001 : 1.0;
+                    PhotonRec32 r;
+                    r.pos_r[0] = float(x.x); r.pos_r[1] = float(x.y); r.pos_r[2] = float(x.z); r.pos_r[3] = beams ? 3.f : 0.f;
+                    const D dv = beams ? ro : wo;   // beams: where the beam starts
+                    r.dir[0] = float(dv.x); r.dir[1] = float(dv.y); r.dir[2] = float(dv.z); r.dir[3] = 0.f;
+                    r.pow[0] = float(boost * power.x); r.pow[1] = float(boost * power.y); r.pow[2] = float(boost * power.z); r.pow[3] = 0.f;
+                    KS.vol[ov + nv] = r;
+                }
+                nv++;
+            }
+            if (rng.uniform() < scat / sigma_t) {
+                const double ax = rng.range(-1.0, 1.0), ay = rng.range(-1.0, 1.0), az = rng.range(-1.0, 1.0);
+                const double phase = KA.sc.medium_kind == 1 ? 1.0 / 4.0 * kPi : 1.0 / (4.0 * kPi);
+                power = ((((power * mcol) * scat) / sigma_t) * phase) / phase;   // attenuated * phase / ph_p
+                ro = x;
+                rd = normalize(mk(ax, ay, az));
+            } else {
+                done = true;
+            }
+        } else if (!hit) {
+            done = true;
+        } else {   // trace_on_surface, :811-875
+            const D n = hit_normal(recs, trecs, q, ro, rd);
+            const D x = ro + q.t * rd;
+            const Mat& mat = KA.sc.shade[q.obj].mat;
+            const double p_d = 0.7;
+            D wi = mk(0, 0, 1);
+            double pdf = 1.0;
+            if (!(rng.uniform() < p_d) || !sample_f(mat, n, wo, rng, wi, pdf)) {
+                done = true;   // absorbed, or total internal reflection: nothing is stored
+            } else {
+                const D f = bsdf(mat, n, wo, wi);
+                const double cw = dot(wi, n);
+                const double cosine_term = cw > 0.0 ? cw : 1.0;
+                if (mat.kind <= 1) {   // !is_mirror(), src/material.rs:135-141
+                    if (WRITE) {
+                        PhotonRec32 r;
+                        r.pos_r[0] = float(x.x); r.pos_r[1] = float(x.y); r.pos_r[2] = float(x.z); r.pos_r[3] = 0.f;
+                        r.dir[0] = float(wo.x); r.dir[1] = float(wo.y); r.dir[2] = float(wo.z); r.dir[3] = 0.f;
+                        r.pow[0] = float(power.x); r.pow[1] = float(power.y); r.pow[2] = float(power.z); r.pow[3] = 0.f;
+                        KS.surf[os + ns] = r;
+                        double* const p64 = KS.pos64 + size_t(os + ns) * 3u;
+                        p64[0] = x.x; p64[1] = x.y; p64[2] = x.z;
+                    }
+                    ns++;
+                }
+                power = (((power * f) * cosine_term) / pdf) / p_d;
+                ro = x;
+                rd = wi;
+            }
+        }
+        if (done) {
+            if (!WRITE) {
+                KS.cnt_s[idx] = ns;
+                KS.cnt_v[idx] = nv;
+            }
+            have = false;
+        }
+    }
+}
+
+// One wave per (pixel, 64 samples of it), dealt out statically.  (With a work counter drawn from by lane 0, as in the other persistent
+// kernels, this one was not a function of its inputs: ~20 pixels of 4,096 changed from run to run, always items a wave took after its
+// first, written by lane 0 alone -- the cause was not isolated; tools/eps_photon_determinism.py is the check.)  Every lane retraces its sample's camera ray with the reference's arithmetic, then the wave
+// goes through the lanes' gathered photons rank by rank -- one visibility query per lane and rank (closest_hit_wave; the search may
+// end at the query point: only a hit closer than `len` blocks).  The pixel's partial sum: per lane in rank order, then the lanes
+// in a fixed butterfly order.
+template <bool MEDIUM, bool LDSTAB>
+__global__ __launch_bounds__(256, R64_WAVES) void photon_surface_f64_kernel(const SurfArgs64 by_value) {
+    (void)by_value;
+    extern __shared__ double lds64[];
+    const ObjRec* recs;
+    const TriRec* trecs;
+    stage_tables<LDSTAB>(lds64, recs, trecs);
+    volatile uint32_t* const slots = reinterpret_cast<uint32_t*>(lds64 + kPhSlotBase) + (threadIdx.x >> 6) * 64u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const double sigma_t = KA.sc.absorption + KA.sc.scattering;
+    uint32_t ce = 0, cr = 0;
+    // (items are dealt out statically, wave by wave: neighbouring pixels cost about the same)
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = gridDim.x * 4u;
+    for (uint32_t lo = wave_id; lo < KA.n_items; lo += n_waves) {
+        const uint32_t n_owned = KA.n_owned;
+        const uint32_t g = lo / n_owned, p = lo - g * n_owned;
+        const uint32_t within = p & 1023u, sb = within >> 6, l = within & 63u;
+        const uint32_t tile = KA.tiles[p >> 10], ty = tile / KA.tiles_x, tx = tile - ty * KA.tiles_x;
+        const uint32_t x = tx * 32u + (sb & 3u) * 8u + (l & 7u), y = ty * 32u + (sb >> 2) * 8u + (l >> 3);
+        if (x >= KA.width || y >= KA.height) continue;   // slots of clipped tiles lie outside the image (wave-uniform)
+        const uint32_t s = g * 64u + lane;
+        const bool active = s < KA.iterations;
+        Rng64 rng;
+        rng.r.seed(KA.seed_mixed, y * KA.width + x, KA.sample_offset + s);
+        const double dim = KA.dim;
+        const double xn = (double(2u * x + 1u) - double(KA.width)) / dim;            // src/renderer.rs:174-176
+        const double yn = (double(2u * (KA.height - y) - 1u) - double(KA.height)) / dim;
+        const double dx = rng.range(-1.0 / dim, 1.0 / dim);
+        const double dy = rng.range(-1.0 / dim, 1.0 / dim);
+        D ro, rd;
+        cast_ray(KA.cam, xn + dx, yn + dy, rng, ro, rd);
+        Query h;
+        closest_hit_wave<false>(recs, trecs, slots, active, ro, rd, kInf, h, ce, cr);
+        bool surf = active && h.obj >= 0;
+        double scale = 1.0;
+        if (MEDIUM && active) {
+            if (KQ.kind == 0u) {   // the point x point estimate draws the distance first, :384-438
+                const double d = -log(rng.range(0.0, 1.0)) / sigma_t;
+                if (!surf || d < h.t) surf = false;
+                else scale = exp(-(sigma_t * h.t)) / (1.0 - (1.0 - exp(-(sigma_t * d))));   // transmittance / (1 - cdf)
+            } else if (surf) {
+                scale = exp(-(sigma_t * h.t));   // :610-611
+            }
+        }
+        D n = mk(0, 1, 0), wo = mk(0, 0, 1), xw = ro, color = mk(0, 0, 0);
+        int32_t hobj = 0;
+        uint32_t cnt = 0;
+        const uint32_t stride = KA.iterations;
+        const uint32_t* const em = KQ.emit + size_t(p) * (KQ.K + 2u) * stride + s;
+        if (surf) {
+            n = hit_normal(recs, trecs, h, ro, rd);
+            xw = ro + h.t * rd;
+            wo = -normalize(rd);
+            hobj = h.obj;
+            const Mat& mat = KA.sc.shade[hobj].mat;
+            color = mat_emit(mat) * mat_color(mat);
+            cnt = em[size_t(KQ.K) * stride];
+        }
+        uint32_t cmax = cnt;
+        for (uint32_t off = 32u; off != 0u; off >>= 1) cmax = max(cmax, lane_read(cmax, lane ^ off));
+        cmax = __builtin_amdgcn_readfirstlane(cmax);
+        for (uint32_t k = 0; k < cmax; k++) {
+            const bool has = k < cnt;
+            D po = xw, pdir = mk(0, 1, 0), ppow = mk(0, 0, 0), dirn = mk(0, 0, 1);
+            double len = 0.0;
+            if (has) {
+                const PhotonRec32& ph = KQ.s_ph[em[size_t(k) * stride]];
+                const double* const p64 = KQ.pos64 + size_t(__float_as_uint(ph.dir[3])) * 3u;
+                po = mk(p64[0], p64[1], p64[2]);
+                pdir = mk(double(ph.dir[0]), double(ph.dir[1]), double(ph.dir[2]));
+                ppow = mk(double(ph.pow[0]), double(ph.pow[1]), double(ph.pow[2]));
+                const D disp = xw - po;
+                len = length(disp);
+                dirn = normalize(disp);
+            }
+            Query v{kInf, -1, 0u};
+            if (!(KQ.skip & 4096u)) closest_hit_wave<false>(recs, trecs, slots, has, po, dirn, len, v, ce, cr);
+            if (has && !(v.obj >= 0 && len > v.t)) {   // :357-361
+                const double c = fmin(fmax(dot(pdir, n), 0.0), 1.0);
+                color = color + (bsdf(KA.sc.shade[hobj].mat, n, wo, pdir) * ppow) * c;
+            }
+        }
+        if (surf) {
+            const double max_d2 = cnt ? double(__uint_as_float(em[size_t(KQ.K + 1u) * stride])) : 1.0;
+            color = (color * (1.0 / (kPi * max_d2))) * scale;
+        }
+        if (!surf) color = mk(0, 0, 0);
+        for (uint32_t off = 32u; off != 0u; off >>= 1) {
+            const D o = lane_read(color, lane ^ off);
+            color = color + o;
+        }
+        if (lane == 0u) {
+            double* const sl = KA.slab + size_t(lo) * 4u;
+            reinterpret_cast<double2*>(sl)[0] = make_double2(color.x, color.y);
+            reinterpret_cast<double2*>(sl)[1] = make_double2(color.z, 0.0);
+        }
+    }
+}
+
+// The frame of that camera pass, slice by slice: the fp32 kernel's partial sums (volume estimate, background; [chunk][pixel] float4) plus
+// this file's (surface estimate; [group][pixel]), / samples of the whole call * 2^EV, added to what the earlier slices left.
+__global__ __launch_bounds__(256) void resolve_photon_f64_kernel(const Args a, const float4* __restrict__ slab32, uint32_t n_chunks32,
+                                                                 double scale_over_total, int accumulate, double* __restrict__ out) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= a.n_owned) return;
+    const uint32_t tl = p >> 10, within = p & 1023u, sb = within >> 6, l = within & 63u;
+    const uint32_t tile = a.tiles[tl], ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const uint32_t x = tx * 32u + (sb & 3u) * 8u + (l & 7u), y = ty * 32u + (sb >> 2) * 8u + (l >> 3);
+    if (x >= a.width || y >= a.height) return;
+    double r = 0.0, g = 0.0, b = 0.0;
+    for (uint32_t c = 0; c < n_chunks32; c++) {
+        const float4 v = slab32[size_t(c) * a.n_owned + p];
+        r += double(v.x);
+        g += double(v.y);
+        b += double(v.z);
+    }
+    for (uint32_t c = 0; c < a.n_chunks; c++) {
+        const double2* const sl = reinterpret_cast<const double2*>(a.slab + (size_t(c) * a.n_owned + p) * 4u);
+        const double2 v0 = sl[0], v1 = sl[1];
+        r += v0.x;
+        g += v0.y;
+        b += v1.x;
+    }
+    const size_t o = (size_t(y) * a.width + x) * 3;
+    out[o] = (accumulate ? out[o] : 0.0) + r * scale_over_total;
+    out[o + 1] = (accumulate ? out[o + 1] : 0.0) + g * scale_over_total;
+    out[o + 2] = (accumulate ? out[o + 2] : 0.0) + b * scale_over_total;
+}
+
 }  // namespace rpt64
 
 namespace rptg {
@@ -1045,5 +1356,40 @@ hipError_t render_f64_occupancy(bool medium, int* blocks_per_cu) {
     const size_t lds = size_t(rpt64::kLdsDoubles) * 8u;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(
         blocks_per_cu, medium ? (const void*)rpt64::render_f64_kernel<true, false, true, false> : (const void*)rpt64::render_f64_kernel<false, false, true, false>, 256, lds);
+}
+
+template <bool M, bool W>
+static hipError_t launch_shoot_f64_t(const rpt64::ShootArgs64& a, int n_blocks, hipStream_t stream) {
+    const size_t lds = size_t(rpt64::kPhLdsDoubles) * 8u;
+    const bool tab = a.a.sc.n_objects <= rpt64::kLdsObjs && a.a.sc.n_obj_tris <= rpt64::kLdsTris;
+    if (tab) hipLaunchKernelGGL((rpt64::photon_shoot_f64_kernel<M, W, true>), dim3(n_blocks), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((rpt64::photon_shoot_f64_kernel<M, W, false>), dim3(n_blocks), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_photon_shoot_f64(const rpt64::ShootArgs64& a, int n_blocks, hipStream_t stream) {
+    const bool m = a.a.sc.has_medium != 0, w = a.surf != nullptr || a.vol != nullptr;
+    if (m) return w ? launch_shoot_f64_t<true, true>(a, n_blocks, stream) : launch_shoot_f64_t<true, false>(a, n_blocks, stream);
+    return w ? launch_shoot_f64_t<false, true>(a, n_blocks, stream) : launch_shoot_f64_t<false, false>(a, n_blocks, stream);
+}
+hipError_t launch_photon_surface_f64(const rpt64::SurfArgs64& a, int n_blocks, hipStream_t stream) {
+    if (!a.a.n_items) return hipSuccess;
+    const size_t lds = size_t(rpt64::kPhLdsDoubles) * 8u;
+    const bool tab = a.a.sc.n_objects <= rpt64::kLdsObjs && a.a.sc.n_obj_tris <= rpt64::kLdsTris;
+    const bool m = a.a.sc.has_medium != 0;
+    if (m) {
+        if (tab) hipLaunchKernelGGL((rpt64::photon_surface_f64_kernel<true, true>), dim3(n_blocks), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((rpt64::photon_surface_f64_kernel<true, false>), dim3(n_blocks), dim3(256), lds, stream, a);
+    } else {
+        if (tab) hipLaunchKernelGGL((rpt64::photon_surface_f64_kernel<false, true>), dim3(n_blocks), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((rpt64::photon_surface_f64_kernel<false, false>), dim3(n_blocks), dim3(256), lds, stream, a);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_resolve_photon_f64(const rpt64::Args& a, const void* slab32, uint32_t n_chunks32, double scale_over_total, bool accumulate,
+                                     double* d_out, hipStream_t stream) {
+    if (!a.n_owned) return hipSuccess;
+    hipLaunchKernelGGL(rpt64::resolve_photon_f64_kernel, dim3((a.n_owned + 255u) / 256u), dim3(256), 0, stream, a,
+                       static_cast<const float4*>(slab32), n_chunks32, scale_over_total, accumulate ? 1 : 0, d_out);
+    return hipGetLastError();
 }
 }  // namespace rptg

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "device_core.h"
+#include "f64_layout.h"
 #include "host_internal.h"
 #include "kernels.h"
 #include "sort_scan.h"
@@ -31,6 +32,7 @@ struct alignas(16) PhotonRec {
 
 // Photon-tree leaf entry: BVH_LEAF | (count - 1) << 26 | first photon (sorted order).  The trees the beam
 // walkers use are packed with one photon per leaf; the k-NN trees with up to kKnnLeaf.
+static_assert(sizeof(PhotonRec) == sizeof(rpt64::PhotonRec32) && sizeof(PhotonRec) == RPT_PHOTON_RECORD_BYTES, "one record layout");
 static constexpr uint32_t PH_LEAF_INDEX = 0x03FFFFFFu;
 static constexpr uint32_t kKnnLeaf = 8;
 
@@ -507,6 +509,8 @@ struct QueryArgs {
     uint32_t* gather;        // GG kernels (gather size > kGatherLds): [waves of the grid][2][K][64] gather lists in global memory
     uint32_t parts;          // work items per (8x8 pixel block, sample chunk): the block's rows in 1, 2, 4 or 8 strips
     uint32_t coop_cap;       // candidates the wave-level surface gather may hold in LDS (multiple of 4, <= kCoopCap); 0: one search per lane
+    uint32_t* emit;          // EMIT kernels (reference-epsilon mode): [n_owned][gather_size + 2][iterations] per-sample selections, see
+                             // rpt64::SurfArgs64::emit -- the surface estimate's rays and terms are kernels_f64.hip's
 };
 
 static_assert(offsetof(QueryArgs, r) == 0, "kernel arguments begin with the SceneView (kernarg_scene)");
@@ -1188,6 +1192,8 @@ struct SurfaceSample {
     V sc_col;       // emission + the terms of the gathered photons so far
     float max_d2;   // squared distance of the K-th nearest photon, once known
     bool todo;      // still to be served
+    uint32_t* em;   // EMIT: this sample's column of QueryArgs::emit (entries `stride` dwords apart)
+    uint32_t n_em;  // ... and the photons written to it so far
 };
 // The room shell's box, a few ulps wider (see `lane_clear` in gather_serve).
 struct ShellBox {
@@ -1256,7 +1262,7 @@ RPT_DEV void add_photon_term(QueryK q, const SceneView& sc_arg, SurfaceSample& s
 // Every member lane picks its K nearest out of the M ordered candidates (centre: where `rho` is measured from) inside its
 // search radius `guess`, then sums the terms of the photons within its K-th distance, in candidate order.  Lanes that
 // found K are done (s.todo, s.max_d2).
-template <bool BVH>
+template <bool BVH, bool EMIT>
 RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
                           WalkScratch& ws, bool member, float guess, float rho, uint32_t M) {
     const auto& a = q.r;
@@ -1376,7 +1382,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
     for (uint32_t base = 0; base < M && more; base += 64u) {
         // lane l fetches what the term needs of candidate base + l; the records are then handed round by readlane
         F4 fdir{}, fpow{};
-        if (base + lane_ < M && keys[base + lane_] <= thr2_max) {
+        if (!EMIT && base + lane_ < M && keys[base + lane_] <= thr2_max) {
             const uint32_t idx = __float_as_uint(cl[base + lane_].w) & ~kCandInShell;
             fdir = q.s_ph[idx].dir;
             fpow = q.s_ph[idx].pow;
@@ -1389,6 +1395,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
             const float kj = k_nx;
             const V po = xyz(c_nx);
             const bool po_in = (__float_as_uint(c_nx.w) & kCandInShell) != 0u;   // (wave-uniform) the photon lies inside the room shell
+            const uint32_t pidx = __float_as_uint(c_nx.w) & ~kCandInShell;
             {
                 const uint32_t jn = min(j + 1u, M - 1u);
                 k_nx = keys[jn];
@@ -1399,6 +1406,13 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
             const V dd = po - x;
             const bool in = ok && dot(dd, dd) <= r2k;
             if (__ballot(in) == 0ull) continue;
+            if constexpr (EMIT) {   // the selection is handed over instead of being evaluated (at most K: ties at the K-th distance are cut)
+                if (in && s.n_em < K) {
+                    s.em[size_t(s.n_em) * a.iterations] = pidx;
+                    s.n_em++;
+                }
+                continue;
+            }
             auto rl = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), jj)); };
             const V pdir = mk(rl(fdir.x), rl(fdir.y), rl(fdir.z)), ppow = mk(rl(fpow.x), rl(fpow.y), rl(fpow.z));
             if (a.counters) diag_add(q.r.counters, 16, 1ull);
@@ -1467,7 +1481,7 @@ RPT_DEV void pixel_candidates(QueryK q, const GatherLds& l, const ShellBox& shel
 // again with a larger one.  Round 0 serves the lanes from the pixel's candidate list (a lane's ball has to lie inside the
 // collected one); the later rounds collect for clusters of the query points that are left: none, unless the pixel straddles
 // an edge, a radius was too small or there is no pixel list.  Lanes it cannot serve keep s.todo.
-template <bool BVH>
+template <bool BVH, bool EMIT>
 RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
                                  WalkScratch& ws, PixelList& pix, Anchor& anc, float prev_r2) {
     const auto& a = q.r;
@@ -1518,14 +1532,14 @@ RPT_DEV void surface_gather_wave(QueryK q, const SceneView& sc_arg, const Gather
             rho = __builtin_sqrtf(dot(dk, dk));
         }
         if (q.skip & 96u) { if (member) { s.max_d2 = 0.5f * guess; s.todo = false; } continue; }   // diagnostic: 32 / 64 = no selection
-        const bool ok = gather_serve<BVH>(q, sc_arg, l, shell, s, ws, member, g_use, rho, M);
+        const bool ok = gather_serve<BVH, EMIT>(q, sc_arg, l, shell, s, ws, member, g_use, rho, M);
         if (member && !ok) guess = fmaxf(guess, 4.f * g_use);   // too few photons inside: twice the radius next round
         __builtin_amdgcn_wave_barrier();
     }
 }
 // One search per lane (lists in global memory, no radius to start from, an overfull candidate list); the lanes of the call
 // search the tree together (knn_walk_wave).
-template <bool BVH>
+template <bool BVH, bool EMIT>
 RPT_DEV void surface_gather_lane(QueryK q, const SceneView& sc_arg, const GatherLds& l, const ShellBox& shell, SurfaceSample& s,
                                  WalkScratch& ws, float prev_r2) {
     const auto& sc = q.r.sc;
@@ -1544,6 +1558,12 @@ RPT_DEV void surface_gather_lane(QueryK q, const SceneView& sc_arg, const Gather
         uint32_t j = i;
         for (; j > 0u && l.gi[(j - 1u) * 64u] > v; j--) l.gi[j * 64u] = l.gi[(j - 1u) * 64u];
         l.gi[j * 64u] = v;
+    }
+    if constexpr (EMIT) {
+        for (uint32_t k = 0; k < found; k++) s.em[size_t(k) * q.r.iterations] = l.gi[k * 64u];
+        s.n_em = found;
+        s.todo = false;
+        return;
     }
     for (uint32_t k = 0; k < found; k++) {
         const PhotonRec ph = q.s_ph[l.gi[k * 64u]];
@@ -1564,8 +1584,12 @@ RPT_DEV void surface_gather_lane(QueryK q, const SceneView& sc_arg, const Gather
 // PHASE: 0 = the whole estimate in one launch; 1 / 2 = the volume estimate / the surface estimate alone, two launches over the
 // same work items whose partial sums go to two slabs that resolve_kernel adds (beam kinds in a medium, lists in LDS): each
 // kernel then keeps only its own estimate's wave-uniform state, and neither needs scratch memory.
-template <bool MEDIUM, bool BVH, bool GG, int KIND, int PHASE = 0>
+// EMIT (reference-epsilon mode): the surface estimate stops at the selection -- each sample's K nearest photons, their number and
+// the K-th squared distance go to q.emit, and photon_surface_f64_kernel (kernels_f64.hip) traces the visibility rays and adds the
+// terms with the reference's arithmetic; this kernel's slab then holds the volume estimate (and the background) alone.
+template <bool MEDIUM, bool BVH, bool GG, int KIND, int PHASE = 0, bool EMIT = false>
 __global__ __launch_bounds__(256, RPT_MIN_WAVES_QUERY) void photon_query_kernel(const QueryArgs q) {
+    static_assert(!EMIT || PHASE == 0, "the selection is handed over by the one-launch camera pass");
     static_assert(PHASE == 0 || (MEDIUM && !GG && KIND != RPT_PHOTON_MAP), "the split camera pass: beam estimates in a medium, gather lists in LDS");
     extern __shared__ uint32_t dyn_lds[];
     const RenderArgs& a = q.r;
@@ -1836,7 +1860,9 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES_QUERY) void photon_query_kernel(
         if constexpr (PHASE != 1) {
         // ---- surface estimate, src/photon.rs:327-375
         const bool surf = active && surface_on && !(q.skip & 2u);
-        SurfaceSample s{ro, mk(0, 1, 0), wo, Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f}, mk(0, 0, 0), 0.f, surf};
+        SurfaceSample s{ro, mk(0, 1, 0), wo, Mat{mk(0, 0, 0), 0.f, 0u, 0.f, 0.f}, mk(0, 0, 0), 0.f, surf, nullptr, 0u};
+        if constexpr (EMIT)
+            s.em = q.emit + size_t(slab_idx - chunk * a.n_owned) * (q.gather_size + 2u) * a.iterations + (chunk * kSuper + sub * 64u + lane_);
         if (surf) {
             uint32_t obj;
             finalize_hit(sc_arg, ro, rd, tmin, t, code, inst, s.n, obj);
@@ -1848,16 +1874,22 @@ __global__ __launch_bounds__(256, RPT_MIN_WAVES_QUERY) void photon_query_kernel(
         { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 4, t1 - tk); tk = t1; }   // [4] volume estimate with the samples in the lanes, hit record, material
         if (q.skip & 512u) { s.todo = false; s.max_d2 = 1.f; }   // (diagnostic: 512 = hit record and material only)
         if (!GG && q.coop_cap != 0u && q.gather_size != 0u && q.n_s != 0u)
-            surface_gather_wave<BVH>(q, sc_arg, lds, shell, s, ws, plist, anc, prev_r2);
+            surface_gather_wave<BVH, EMIT>(q, sc_arg, lds, shell, s, ws, plist, anc, prev_r2);
         if (a.counters) { const uint64_t fm = __ballot(s.todo); if (fm) { diag_add(q.r.counters, 18, 1ull); diag_add(q.r.counters, 19, (unsigned long long)(uint32_t(__popcll(fm)))); } }
         if (__ballot(s.todo) != 0ull) plist.valid = false;   // (the index lists of these searches lie where the pixel's candidate list is)
-        if (s.todo) surface_gather_lane<BVH>(q, sc_arg, lds, shell, s, ws, prev_r2);
+        if (s.todo) surface_gather_lane<BVH, EMIT>(q, sc_arg, lds, shell, s, ws, prev_r2);
         c0 = ws.c0;
         c1 = ws.c1;
         { const unsigned long long t1 = tick(); diag_add(a.counters, 24 + 5, t1 - tk); tk = t1; }   // [5] surface gather
         V sc_col = s.sc_col;
         const float max_d2 = s.max_d2;
-        if (surf) {
+        if constexpr (EMIT) {
+            if (active) {   // (a sample without a surface estimate hands over an empty selection)
+                s.em[size_t(q.gather_size) * a.iterations] = surf ? s.n_em : 0u;
+                s.em[size_t(q.gather_size + 1u) * a.iterations] = __float_as_uint(max_d2);
+            }
+            if (surf) prev_r2 = max_d2;
+        } else if (surf) {
             prev_r2 = max_d2;
             sc_col = (kInvPi * rcp(max_d2)) * sc_col;
             if (MEDIUM && KIND == RPT_PHOTON_MAP) sc_col = surface_scale * sc_col;  // :433-435
@@ -1957,6 +1989,14 @@ struct PhotonMapDev {
     size_t gather_words = 0;
     float* d_slab2 = nullptr;      // the surface term's partial sums of the split camera pass
     size_t slab2_bytes = 0;
+    // reference-epsilon mode (kernels_f64.hip): the surface photons' fp64 positions in shooting order, the camera pass's per-sample
+    // selections of one slice of samples, and the fp64 partial sums of its surface estimate
+    double* pos64 = nullptr;
+    uint32_t* d_emit = nullptr;
+    size_t emit_words = 0;
+    double* d_slab64 = nullptr;
+    size_t slab64_bytes = 0;
+    uint64_t emit_dims[3] = {0, 0, 0};   // of the last slice: owned pixel slots, gather_size + 2, samples
     std::shared_ptr<DevPool> pool = std::make_shared<DevPool>();   // handed on to the scene's next map (fresh_map)
     void release_raw() {
         pool->free(raw_s); pool->free(raw_v);
@@ -1973,6 +2013,9 @@ struct PhotonMapDev {
         pool->free(d_slab2);
         d_slab2 = nullptr;
         slab2_bytes = 0;
+        pool->free(pos64); pool->free(d_emit); pool->free(d_slab64);
+        pos64 = nullptr; d_emit = nullptr; d_slab64 = nullptr;
+        emit_words = slab64_bytes = 0;
         release_raw();
         d_overflow = nullptr;
         d_cand = nullptr;
@@ -2126,13 +2169,99 @@ static void launch_query(const QueryArgs& q, bool medium, bool bvh, bool gg, int
     }
 }
 
+// The camera pass that hands its selections over (reference-epsilon mode)
+template <bool M, bool B, bool G>
+static void launch_query_emit_k(const QueryArgs& q, int kind, int nb, size_t lds, hipStream_t st) {
+    const dim3 g(nb), b(256);
+    if (kind == RPT_PHOTON_MAP) hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_MAP, 0, true>), g, b, lds, st, q);
+    else if (kind == RPT_PHOTON_BEAM_BEAM) hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_BEAM_BEAM, 0, true>), g, b, lds, st, q);
+    else hipLaunchKernelGGL((photon_query_kernel<M, B, G, RPT_PHOTON_POINT_BEAM, 0, true>), g, b, lds, st, q);
+}
+static void launch_query_emit(const QueryArgs& q, bool medium, bool bvh, bool gg, int kind, int nb, size_t lds, hipStream_t st) {
+    const int sel = (medium ? 4 : 0) | (bvh ? 2 : 0) | (gg ? 1 : 0);
+    switch (sel) {
+        case 0: launch_query_emit_k<false, false, false>(q, kind, nb, lds, st); break;
+        case 1: launch_query_emit_k<false, false, true>(q, kind, nb, lds, st); break;
+        case 2: launch_query_emit_k<false, true, false>(q, kind, nb, lds, st); break;
+        case 3: launch_query_emit_k<false, true, true>(q, kind, nb, lds, st); break;
+        case 4: launch_query_emit_k<true, false, false>(q, kind, nb, lds, st); break;
+        case 5: launch_query_emit_k<true, false, true>(q, kind, nb, lds, st); break;
+        case 6: launch_query_emit_k<true, true, false>(q, kind, nb, lds, st); break;
+        default: launch_query_emit_k<true, true, true>(q, kind, nb, lds, st); break;
+    }
+}
+
 extern "C" {
+
+// The shooting pass of the reference-epsilon mode: same two passes, same streams, same record arrays; the chains are traced by
+// kernels_f64.hip (t_min = 1e-12, fp64), which also keeps every surface photon's position in fp64 (pm->pos64).
+static int shoot_range64(rpt_scene* s, PhotonMapDev* pm, uint64_t photon_count, uint64_t first, uint64_t n, int32_t kind,
+                         double watts, uint64_t seed) {
+    rpti::SceneDev sd = rpti::scene_dev(s);
+    hipStream_t st = nullptr;
+    hipEvent_t e0, e1;
+    RPTI_HIP_TRY(hipEventCreate(&e0));
+    RPTI_HIP_TRY(hipEventCreate(&e1));
+    Tmp tmp(*pm->pool);
+    rpt64::ShootArgs64 a{};
+    rpti::fill_args64(s, nullptr, nullptr, nullptr, a.a);
+    a.a.seed_mixed = rpti::seed_mix(seed);
+    a.n_photons = n;
+    a.first_photon = first;
+    a.power = watts / double(photon_count);
+    a.light_index = uint32_t(sd.first_object_light);
+    a.kind = uint32_t(kind);
+    pm->release_raw();
+    pm->pool->free(pm->pos64);
+    pm->pos64 = nullptr;
+    if (n == 0) return RPT_OK;
+    RPTI_HIP_TRY(tmp.alloc(&a.cnt_s, n));
+    RPTI_HIP_TRY(tmp.alloc(&a.cnt_v, n));
+    RPTI_HIP_TRY(tmp.alloc(&a.a.queue, 1));
+    const int blocks = int(std::min<uint64_t>((n + 255) / 256, uint64_t(sd.n_cus) * 4));
+    RPTI_HIP_TRY(hipEventRecord(e0, st));
+    RPTI_HIP_TRY(hipMemsetAsync(a.a.queue, 0, 8, st));
+    RPTI_HIP_TRY(launch_photon_shoot_f64(a, blocks, st));
+    uint32_t *d_os, *d_ov;
+    RPTI_HIP_TRY(tmp.alloc(&d_os, n));
+    RPTI_HIP_TRY(tmp.alloc(&d_ov, n));
+    char* scan_tmp;
+    RPTI_HIP_TRY(tmp.alloc(&scan_tmp, std::max<size_t>(ss::scan2_temp_bytes(uint32_t(n)), 8)));
+    unsigned long long* d_tot;
+    RPTI_HIP_TRY(tmp.alloc(&d_tot, 2));
+    RPTI_HIP_TRY(ss::exclusive_scan2(a.cnt_s, a.cnt_v, uint32_t(n), d_os, d_ov, d_tot, scan_tmp, st));
+    unsigned long long tot[2] = {0, 0};
+    RPTI_HIP_TRY(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, st));
+    RPTI_HIP_TRY(hipStreamSynchronize(st));
+    const uint64_t ts = tot[0], tv = tot[1];
+    if (ts >= (1ull << 26) || tv >= (1ull << 26)) return rpti::fail(RPT_ERR_UNSUPPORTED, "too many photons (2^26 records per map)");
+    RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->raw_s, ts * sizeof(PhotonRec)));
+    RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->raw_v, tv * sizeof(PhotonRec)));
+    RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->pos64, ts * 24u));
+    pm->n_raw_s = ts;
+    pm->n_raw_v = tv;
+    a.off_s = d_os;
+    a.off_v = d_ov;
+    a.surf = reinterpret_cast<rpt64::PhotonRec32*>(pm->raw_s);
+    a.vol = reinterpret_cast<rpt64::PhotonRec32*>(pm->raw_v);
+    a.pos64 = pm->pos64;
+    RPTI_HIP_TRY(hipMemsetAsync(a.a.queue, 0, 8, st));
+    RPTI_HIP_TRY(launch_photon_shoot_f64(a, blocks, st));
+    RPTI_HIP_TRY(hipEventRecord(e1, st));
+    RPTI_HIP_TRY(hipEventSynchronize(e1));
+    float m0 = 0;
+    (void)hipEventElapsedTime(&m0, e0, e1);
+    pm->build_ms[0] = m0;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return RPT_OK;
+}
 
 // Shooting pass for photons [first, first + n) of a map of `photon_count` photons: count, prefix, write.
 // Leaves the records in pm->raw_s / raw_v in shooting order.
 static int shoot_range(rpt_scene* s, PhotonMapDev* pm, uint64_t photon_count, uint64_t first, uint64_t n, int32_t kind,
                        double watts, uint64_t seed) {
     rpti::SceneDev sd = rpti::scene_dev(s);
+    if (sd.epsilon64) return shoot_range64(s, pm, photon_count, first, n, kind, watts, seed);
     hipStream_t st = nullptr;
     hipEvent_t e0, e1;
     RPTI_HIP_TRY(hipEventCreate(&e0));
@@ -2216,7 +2345,6 @@ static int photon_args_ok(rpt_scene* s, uint64_t photon_count, int32_t kind) {
     if (!s) return rpti::fail(RPT_ERR_INVALID, "null scene");
     rpti::SceneDev sd = rpti::scene_dev(s);
     if (!sd.committed) return rpti::fail(RPT_ERR_STATE, "rpt_scene_commit must be called first");
-    if (sd.epsilon64) return rpti::fail(RPT_ERR_UNSUPPORTED, "photon mapping is not available in the reference-epsilon mode (epsilon_policy = 1)");
     if (photon_count == 0) return rpti::fail(RPT_ERR_INVALID, "photon_count must be > 0");
     if (kind != RPT_PHOTON_POINT_BEAM && kind != RPT_PHOTON_MAP && kind != RPT_PHOTON_BEAM_BEAM)
         return rpti::fail(RPT_ERR_INVALID, "unknown PhotonRenderKind");
@@ -2267,6 +2395,7 @@ int rpt_photon_shoot(rpt_scene* s, uint64_t photon_count, int32_t kind, double w
                      uint32_t shard_count, uint64_t n_out[2]) {
     int rc = photon_args_ok(s, photon_count, kind);
     if (rc) return rc;
+    if (rpti::scene_dev(s).epsilon64) return rpti::fail(RPT_ERR_UNSUPPORTED, "the reference-epsilon mode keeps the surface photons' positions in fp64 beside the 48-byte records: build the map with rpt_photon_map_build (on every rank)");
     if (shard_count == 0) shard_count = 1;
     if (shard_rank >= shard_count) return rpti::fail(RPT_ERR_INVALID, "shard_rank must be < shard_count");
     // contiguous blocks, so that the shards concatenated in rank order ARE the single-GPU record arrays
@@ -2292,6 +2421,7 @@ int rpt_photon_map_from_records(rpt_scene* s, uint64_t photon_count, int32_t kin
     int rc = photon_args_ok(s, photon_count, kind);
     if (rc) return rc;
     if ((n_surface && !d_surface) || (n_volume && !d_volume)) return rpti::fail(RPT_ERR_INVALID, "null record array");
+    if (rpti::scene_dev(s).epsilon64) return rpti::fail(RPT_ERR_UNSUPPORTED, "the reference-epsilon mode keeps the surface photons' positions in fp64 beside the 48-byte records: build the map with rpt_photon_map_build (on every rank)");
     auto* old = static_cast<PhotonMapDev*>(rpti::photon_slot(s));
     // the arrays may be this scene's own shot records: keep them alive until the maps are built
     PhotonMapDev keep;
@@ -2339,9 +2469,15 @@ int rpt_photon_map_download(rpt_scene* s, int32_t which, float* out, uint64_t ca
     return RPT_OK;
 }
 
+// Reference-epsilon mode: the camera pass runs over the call's samples slice by slice (the selections of one slice are
+// [n_owned][gather_size + 2][slice] dwords); `total` = samples of the whole call, `first`: the frame starts with this slice.
+struct EpsSlice {
+    uint32_t total;
+    bool first;
+};
 static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint64_t gather_size,
                               uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed, uint32_t sample_offset,
-                              double* d_out, hipStream_t st, bool sync_counters) {
+                              double* d_out, hipStream_t st, bool sync_counters, const EpsSlice* eps = nullptr) {
     auto* pm = s ? static_cast<PhotonMapDev*>(rpti::photon_slot(s)) : nullptr;
     if (!pm || !pm->built) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
     const uint64_t gather_max = pm->kind == RPT_PHOTON_MAP ? std::max(gather_size, gather_size_volume) : gather_size;
@@ -2379,12 +2515,58 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     if (!pm->d_overflow) RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->d_overflow, 64));
     RPTI_HIP_TRY(hipMemsetAsync(pm->d_overflow, 0, 4, st));
     q.overflow = pm->d_overflow;
+    rpt64::SurfArgs64 sa{};
+    if (eps) {
+        if (!pm->pos64 && pm->surf.n) return rpti::fail(RPT_ERR_STATE, "this photon map was not shot in the reference-epsilon mode");
+        const size_t words = std::max<size_t>(size_t(q.r.n_owned) * (size_t(gather_size) + 2u) * num_samples, 16u);
+        if (words > pm->emit_words) {
+            pm->pool->free(pm->d_emit);
+            pm->d_emit = nullptr;
+            pm->emit_words = 0;
+            RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->d_emit, words * 4u));
+            pm->emit_words = words;
+        }
+        q.emit = pm->d_emit;
+        pm->emit_dims[0] = q.r.n_owned; pm->emit_dims[1] = gather_size + 2u; pm->emit_dims[2] = num_samples;
+        const uint32_t n_groups = (num_samples + 63u) / 64u;
+        const size_t bytes = std::max<size_t>(size_t(n_groups) * q.r.n_owned * 32u, 32u);
+        if (bytes > pm->slab64_bytes) {
+            pm->pool->free(pm->d_slab64);
+            pm->d_slab64 = nullptr;
+            pm->slab64_bytes = 0;
+            RPTI_HIP_TRY(pm->pool->alloc((void**)&pm->d_slab64, bytes));
+            pm->slab64_bytes = bytes;
+        }
+        rpti::fill_args64(s, cam, prm, &q.r, sa.a);
+        sa.a.n_chunks = n_groups;                    // of 64 samples: one work item per (group, pixel)
+        sa.a.n_items = n_groups * q.r.n_owned;       // (< 2^32: n_owned * n_chunks of kSuper was checked, and a chunk holds four groups)
+        sa.a.slab = pm->d_slab64;
+        if (!sa.a.cull) sa.a.cull = 1u;              // (the searches end at the query point: f64_cull = 0 has no meaning here)
+        sa.emit = pm->d_emit;
+        sa.s_ph = reinterpret_cast<const rpt64::PhotonRec32*>(pm->surf.sorted);
+        sa.pos64 = pm->pos64;
+        sa.K = uint32_t(gather_size);
+        sa.kind = uint32_t(pm->kind);
+        sa.skip = q.skip;
+        if (uint64_t(n_groups) * q.r.n_owned >= (1ull << 32)) return rpti::fail(RPT_ERR_INVALID, "too many work items");
+    }
     auto launch = [&](const RenderArgs& ra, int nb, hipStream_t stream) -> hipError_t {
         QueryArgs qq = q;
         qq.r = ra;
-        launch_query(qq, medium, bvh, gg, pm->kind, nb, lds, stream);
-        return hipGetLastError();
+        if (!eps) {
+            launch_query(qq, medium, bvh, gg, pm->kind, nb, lds, stream);
+            return hipGetLastError();
+        }
+        launch_query_emit(qq, medium, bvh, gg, pm->kind, nb, lds, stream);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return launch_photon_surface_f64(sa, rpti::scene_dev(s).n_cus * 4, stream);
     };
+    std::function<hipError_t(double, double*, hipStream_t)> resolve;
+    if (eps)
+        resolve = [&](double scale, double* out, hipStream_t stream) {
+            return launch_resolve_photon_f64(sa.a, q.r.slab, q.r.n_chunks, scale / double(eps->total), !eps->first, out, stream);
+        };
     int bpc = int(std::max<size_t>(1, std::min<size_t>(4, (160u * 1024u) / std::max<size_t>(lds, 1))));
     if (gg) {  // one [2][K][64]-dword region per wave of the largest grid run_persistent may launch
         const size_t words = size_t(rpti::scene_dev(s).n_cus) * size_t(bpc) * 4u * size_t(gather_max) * 128u;
@@ -2426,7 +2608,7 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         }
         q.r.slab2 = pm->d_slab2;
     }
-    rc = rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch, false, true);
+    rc = rpti::run_persistent(s, prm, q.r, d_out, st, bpc, launch, false, true, resolve);
     if (rc == RPT_OK && sync_counters) {
         uint32_t ov = 0;
         RPTI_HIP_TRY(hipMemcpyAsync(&ov, pm->d_overflow, 4, hipMemcpyDeviceToHost, st));
@@ -2437,6 +2619,33 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
     return rc;
 }
 
+// Budget of the per-sample selections the reference-epsilon camera pass keeps per slice (bytes of device memory).
+static constexpr size_t kEmitBudget = size_t(32) << 30;
+static int photon_render_any(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint64_t gather_size,
+                             uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed, uint32_t sample_offset, double* d_out,
+                             hipStream_t st) {
+    if (!s || !rpti::scene_dev(s).epsilon64)
+        return photon_render_impl(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset, d_out, st, true);
+    if (!prm || num_samples == 0) return rpti::fail(RPT_ERR_INVALID, "empty render");
+    if (prm->shard_count > 1) {   // (run_persistent clears a sharded frame per launch: the slices would not add up)
+        const size_t per_sample = size_t(prm->width) * prm->height * (size_t(gather_size) + 2u) * 4u;
+        if (per_sample * num_samples > kEmitBudget)
+            return rpti::fail(RPT_ERR_UNSUPPORTED, "reference-epsilon photon camera pass on a sharded frame: too many samples for one slice; render in several calls");
+    }
+    // slices: whole chunks of kSuper samples while the selections fit the budget, else fewer samples
+    const size_t per_sample = std::max<size_t>(size_t((prm->width + 31u) / 32u) * ((prm->height + 31u) / 32u) * 1024u * (size_t(gather_size) + 2u) * 4u, 1);
+    uint32_t slice = uint32_t(std::min<uint64_t>(num_samples, std::max<uint64_t>(kEmitBudget / per_sample, 1)));
+    if (slice >= kSuper) slice -= slice % kSuper;
+    if (const int64_t forced = rpti::option_f64_photon_slice(s)) slice = uint32_t(std::min<int64_t>(forced, slice));
+    for (uint32_t done = 0; done < num_samples; done += slice) {
+        const uint32_t n = std::min(slice, num_samples - done);
+        const EpsSlice e{num_samples, done == 0};
+        const int rc = photon_render_impl(s, cam, prm, gather_size, gather_size_volume, n, seed, sample_offset + done, d_out, st, true, &e);
+        if (rc) return rc;
+    }
+    return RPT_OK;
+}
+
 int rpt_photon_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint64_t gather_size,
                              uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed, uint32_t sample_offset,
                              double* out_rgb) {
@@ -2444,7 +2653,7 @@ int rpt_photon_render_sample(rpt_scene* s, const rpt_camera* cam, const rpt_rend
     size_t bytes = size_t(prm->width) * prm->height * 24;
     double* d_out = rpti::scratch_out(s, bytes);
     if (!d_out) return rpti::fail(RPT_ERR_DEVICE, "out of device memory");
-    int rc = photon_render_impl(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset, d_out, nullptr, true);
+    int rc = photon_render_any(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset, d_out, nullptr);
     if (rc) return rc;
     RPTI_HIP_TRY(hipMemcpy(out_rgb, d_out, bytes, hipMemcpyDeviceToHost));
     return RPT_OK;
@@ -2454,10 +2663,34 @@ int rpt_photon_render_sample_device(rpt_scene* s, const rpt_camera* cam, const r
                                     uint64_t gather_size, uint64_t gather_size_volume, uint32_t num_samples, uint64_t seed,
                                     uint32_t sample_offset, void* d_out_rgb, void* hip_stream) {
     if (!s || !cam || !prm || !d_out_rgb) return rpti::fail(RPT_ERR_INVALID, "null argument");
-    return photon_render_impl(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset,
-                              static_cast<double*>(d_out_rgb), static_cast<hipStream_t>(hip_stream), true);
+    return photon_render_any(s, cam, prm, gather_size, gather_size_volume, num_samples, seed, sample_offset,
+                             static_cast<double*>(d_out_rgb), static_cast<hipStream_t>(hip_stream));
 }
 
+
+int rpt_debug_photon_positions64(rpt_scene* s, double* out, uint64_t capacity) {
+    if (!s || !out) return rpti::fail(RPT_ERR_INVALID, "null argument");
+    auto* pm = static_cast<PhotonMapDev*>(rpti::photon_slot(s));
+    if (!pm || !pm->built) return rpti::fail(RPT_ERR_STATE, "no photon map: call rpt_photon_map_build first");
+    if (pm->surf.n && !pm->pos64) return rpti::fail(RPT_ERR_STATE, "this photon map was not shot in the reference-epsilon mode");
+    if (capacity < pm->surf.n) return rpti::fail(RPT_ERR_INVALID, "output buffer too small");
+    if (pm->surf.n) RPTI_HIP_TRY(hipMemcpy(out, pm->pos64, size_t(pm->surf.n) * 24u, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+
+int rpt_debug_photon_selections(rpt_scene* s, uint32_t* out, uint64_t capacity_words, uint64_t dims[3]) {
+    if (!s || !dims) return rpti::fail(RPT_ERR_INVALID, "null argument");
+    auto* pm = static_cast<PhotonMapDev*>(rpti::photon_slot(s));
+    if (!pm || !pm->d_emit) return rpti::fail(RPT_ERR_STATE, "no camera pass in the reference-epsilon mode yet");
+    for (int i = 0; i < 3; i++) dims[i] = pm->emit_dims[i];
+    const uint64_t words = dims[0] * dims[1] * dims[2];
+    if (!out) return RPT_OK;
+    if (capacity_words < words) return rpti::fail(RPT_ERR_INVALID, "output buffer too small");
+    RPTI_HIP_TRY(hipSetDevice(pm->device));
+    RPTI_HIP_TRY(hipDeviceSynchronize());
+    RPTI_HIP_TRY(hipMemcpy(out, pm->d_emit, words * 4u, hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
 
 // ---- test hooks of sort_scan.h (host arrays in and out)
 int rpt_debug_radix_sort(uint64_t n, const uint64_t* keys, uint64_t* keys_out, uint32_t* order_out) {

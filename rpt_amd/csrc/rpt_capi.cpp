@@ -84,6 +84,7 @@ struct rpt_options {
                                     // 0: they stay outside it and their walks are parked as in scenes without a scene tree (read by rpt_scene_commit)
     int64_t f64_cull = 1;           // reference-epsilon mode: 1 = a lane evaluates only the objects whose fp32 box its ray can reach (same bits), 0 = every object;
                                     // 2 = as 1, and the counters build keeps the search limits as well (its counters then describe the schedule, not the reference's work)
+    int64_t f64_photon_slice = 0;   // reference-epsilon photon camera pass: samples per slice (0: as many whole chunks of 256 as fit 32 GB of per-sample selections)
     int64_t f64_surf_batch = 8;     // reference-epsilon mode, scenes with a medium: lanes of a wave that wait at a surface event before the wave runs the surface code (1..64)
     int64_t epsilon_policy = 0;     // 1: the reference-epsilon mode (read by rpt_scene_commit): fp64, generic shapes, t_min = 1e-12, |hit - dist| < 1e-12
 };
@@ -127,6 +128,7 @@ static int set_option_in(rpt_options& o, const char* name, int64_t value) {
     else if (s == "detach_trigger") { if (value < 1 || value > 32) return fail(RPT_ERR_INVALID, "detach_trigger must be 1..32"); o.detach_trigger = value; }
     else if (s == "defer_stop") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "defer_stop must be 1..64"); o.defer_stop = value; }
     else if (s == "f64_cull") { if (value < 0 || value > 2) return fail(RPT_ERR_INVALID, "f64_cull must be 0, 1 or 2"); o.f64_cull = value; }
+    else if (s == "f64_photon_slice") { if (value < 0 || value > (1 << 20)) return fail(RPT_ERR_INVALID, "f64_photon_slice must be 0..2^20"); o.f64_photon_slice = value; }
     else if (s == "f64_surf_batch") { if (value < 1 || value > 64) return fail(RPT_ERR_INVALID, "f64_surf_batch must be 1..64"); o.f64_surf_batch = value; }
     else if (s == "epsilon_policy") { if (value < 0 || value > 1) return fail(RPT_ERR_INVALID, "epsilon_policy must be 0 or 1"); o.epsilon_policy = value; }
     else if (s == "scene_tree_meshes") o.scene_tree_meshes = value;
@@ -1917,6 +1919,48 @@ static int build_scene64(rpt_scene* s) {
     for (int k = 0; k < 3; k++) v.env[k] = s->env[k];
     return RPT_OK;
 }
+// The fp64 kernels' common arguments: the scene, and -- for the camera passes -- camera, frame, tiles and chunking as prepare_render
+// laid them out for the fp32 machinery (`a`); cam / prm / a are null for a launch without a camera (photon shooting).
+extern "C++" void rpti::fill_args64(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, const RenderArgs* a, rpt64::Args& q) {
+    q.sc = s->view64;
+    for (int i = 0; i < 3; i++) {
+        q.medium_color[i] = s->medium_color64[i];
+        q.medium_color_hi[i] = s->medium_color_hi64[i];
+    }
+    q.cull = uint32_t(s->opt.f64_cull);
+    q.surf_batch = uint32_t(s->opt.f64_surf_batch);
+    q.group_lights = 0u;
+    for (const auto& l : s->lights)
+        if (l.kind == int(L_OBJECT) && l.obj.shape.d.kind == RPT_SHAPE_GROUP) q.group_lights = 1u;
+    if (cam) {
+        const D3 dir = d3(cam->direction), up = d3(cam->up);
+        const D3 right = normalize(cross(dir, up));   // src/camera.rs:67-68
+        for (int i = 0; i < 3; i++) {
+            q.cam.eye[i] = cam->eye[i];
+            q.cam.direction[i] = cam->direction[i];
+            q.cam.up[i] = cam->up[i];
+            q.cam.right[i] = comp(right, i);
+        }
+        q.cam.d = 1.0 / std::tan(cam->fov / 2.0);
+        q.cam.aperture = cam->aperture;
+        q.cam.focal_distance = cam->focal_distance;
+    }
+    if (prm) {
+        q.width = prm->width; q.height = prm->height;
+        q.max_bounces = prm->max_bounces;
+        q.dim = double(std::max(prm->width, prm->height));
+    }
+    if (a) {
+        q.iterations = a->iterations; q.sample_offset = a->sample_offset;
+        q.n_owned = a->n_owned; q.tiles_x = a->tiles_x; q.tiles = a->tiles; q.n_items = a->n_items;
+        q.chunk_spp = a->chunk_spp; q.n_chunks = a->n_chunks;
+        q.pull_batch = a->pull_batch;
+        q.seed_mixed = a->seed_mixed;
+        q.queue = a->queue;
+        q.slab = reinterpret_cast<double*>(a->slab);
+    }
+    q.counters = nullptr;
+}
 // Renderer::sample in the reference-epsilon mode: the fp32 path's launch scheme (persistent grid over (pixel, chunk)
 // items, one launch set per stream) with an fp64 slab.
 static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_params* prm, uint32_t iterations, uint64_t seed,
@@ -1925,34 +1969,7 @@ static int run_render64(rpt_scene* s, const rpt_camera* cam, const rpt_render_pa
     int rc = rpti::prepare_render(s, st, cam, prm, iterations, seed, sample_offset, a, 0, 0, 32);
     if (rc) return rc;
     rpt64::Args q{};
-    q.sc = s->view64;
-    const D3 dir = d3(cam->direction), up = d3(cam->up);
-    const D3 right = normalize(cross(dir, up));   // src/camera.rs:67-68
-    for (int i = 0; i < 3; i++) {
-        q.cam.eye[i] = cam->eye[i];
-        q.cam.direction[i] = cam->direction[i];
-        q.cam.up[i] = cam->up[i];
-        q.cam.right[i] = comp(right, i);
-        q.medium_color[i] = s->medium_color64[i];
-        q.medium_color_hi[i] = s->medium_color_hi64[i];
-    }
-    q.cam.d = 1.0 / std::tan(cam->fov / 2.0);
-    q.cam.aperture = cam->aperture;
-    q.cam.focal_distance = cam->focal_distance;
-    q.width = prm->width; q.height = prm->height; q.iterations = iterations; q.sample_offset = sample_offset;
-    q.max_bounces = prm->max_bounces;
-    q.n_owned = a.n_owned; q.tiles_x = a.tiles_x; q.tiles = a.tiles; q.n_items = a.n_items;
-    q.chunk_spp = a.chunk_spp; q.n_chunks = a.n_chunks;
-    q.pull_batch = a.pull_batch;
-    q.cull = uint32_t(s->opt.f64_cull);
-    q.surf_batch = uint32_t(s->opt.f64_surf_batch);
-    q.group_lights = 0u;
-    for (const auto& l : s->lights)
-        if (l.kind == int(L_OBJECT) && l.obj.shape.d.kind == RPT_SHAPE_GROUP) q.group_lights = 1u;
-    q.seed_mixed = a.seed_mixed;
-    q.dim = double(std::max(prm->width, prm->height));
-    q.queue = a.queue;
-    q.slab = reinterpret_cast<double*>(a.slab);
+    rpti::fill_args64(s, cam, prm, &a, q);
     q.counters = a.counters;
     int bpc = int(s->opt.blocks_per_cu);
     if (bpc <= 0) {
@@ -2237,6 +2254,7 @@ extern "C++" rpti::SceneDev rpti::scene_dev(rpt_scene* s) {
 }
 extern "C++" void*& rpti::photon_slot(rpt_scene* s) { return s->photon; }
 extern "C++" int64_t rpti::option_photon_skip(rpt_scene* s) { return s->opt.photon_skip; }
+extern "C++" int64_t rpti::option_f64_photon_slice(rpt_scene* s) { return s->opt.f64_photon_slice; }
 extern "C++" int64_t rpti::option_photon_block_lists(rpt_scene* s) { return s->opt.photon_block_lists; }
 extern "C++" int64_t rpti::option_photon_parts(rpt_scene* s) { return s->opt.photon_parts; }
 extern "C++" int64_t rpti::option_photon_split(rpt_scene* s) { return s->opt.photon_split; }

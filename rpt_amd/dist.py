@@ -147,6 +147,10 @@ def photon_map_build_sharded(renderer, photon_count, kind, rank, world, group=No
     (`comm`: a FrameComm, rpt_allgather_records_device) or through torch.distributed -- and every rank builds the
     full map (rpt_photon_map_from_records).  Returns the stats dict of photon_map_build."""
     import torch
+    if renderer.scene._options.get("epsilon_policy", 0) == 1:
+        # reference-epsilon mode: the visibility rays start at the photons' fp64 positions, which the 48-byte records do not carry --
+        # every rank shoots the whole map itself (same seed, same streams: the same map everywhere; the camera pass still shards)
+        return renderer.photon_map_build(photon_count, kind)
     device = torch.device("cuda", renderer.device_)
     renderer.photon_shoot(photon_count, kind, rank, world)
     gathered = []

@@ -298,9 +298,3 @@ def test_what_the_mode_refuses():
     sc.set_option("epsilon_policy", 1)
     with pytest.raises(RptError):
         Renderer(sc, Camera.look_at(vec3(0, 0, 5), vec3(0, 0, 0), vec3(0, 1, 0), 0.6)).width(8).height(8).sample_array(1)
-    scene, cam, cfg = scenes.lampshade_beamphoton()
-    scene.set_option("epsilon_policy", 1)
-    r = Renderer(scene, cam).width(16).height(16)
-    r.sample_array(1)                                     # the path tracer runs
-    with pytest.raises(RptError):
-        r.photon_map_build(1000, Renderer.PHOTON_POINT_BEAM)   # photon mapping does not

@@ -1,0 +1,157 @@
+"""Photon mapping in the reference-epsilon mode (option "epsilon_policy" = 1): the shooting pass and the surface estimate's
+visibility rays run in fp64 with rpt's own epsilons (kernels_f64.hip: t_min = 1e-12, a gathered photon counts unless
+`len > hit.time`, src/photon.rs:357-361); maps, k-nearest selection and volume estimates are the fp32 machinery's.  Checked against
+the oracle's literal restatement (robust = 0).  The comparison is statistical where photon chains are concerned: whether a photon
+meets the surface it has just left again is decided by the last bits of its ray, and the device's libm and the host's differ there,
+so the two maps hold different photons wherever a chain met such a self-intersection."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from rpt_amd import Renderer, RptError, scenes
+from tests.util import rel_rms
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(scene):
+    from oracle.pyoracle import OracleScene
+    return OracleScene(scene)
+
+
+def _renderers(name, size, n, gather=20, gather_volume=3):
+    out = []
+    for eps in (1, 0):
+        scene, cam, cfg = scenes.CONFIGS[name]()
+        if eps:
+            scene.set_option("epsilon_policy", 1)
+        out.append(Renderer(scene, cam).width(size).height(size).watts(14.65 * n).gather_size(gather).gather_size_volume(gather_volume))
+    return out
+
+
+@pytest.mark.parametrize("name", ["C4", "C2"])
+def test_shooting_and_camera_pass_follow_the_literal_reference(name):
+    """20 k photons, 64 x 64 x 16 spp, beam x point map.  The fp32 policy's frame lies ~1.1 % above the literal reference's (C4 and
+    C2 alike); the reference-epsilon mode's lies within 0.3 % of it, and the rest of its distance is that of two maps whose chains
+    parted at the self-intersections (the robust oracle's distance to the literal one, with the bias taken out, is the same)."""
+    n, size, spp = 20000, 64, 16
+    r_eps, r_f32 = _renderers(name, size, n)
+    scene, cam, cfg = scenes.CONFIGS[name]()
+    lit = _oracle(scene).photon_map(n, 1, 14.65 * n, 20, 3, seed=7, robust=0)
+    rob = _oracle(scene).photon_map(n, 1, 14.65 * n, 20, 3, seed=7, robust=1)
+    st = r_eps.seed(7).photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    st32 = r_f32.seed(7).photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    n_lit, n_rob = [len(lit.photons(0)), len(lit.photons(1))], [len(rob.photons(0)), len(rob.photons(1))]
+    print({"device_eps": [st["surface"], st["volume"]], "device_f32": [st32["surface"], st32["volume"]], "literal": n_lit, "robust": n_rob})
+    # the self-intersections store a photon a second time: the literal map holds more surface photons than the robust one
+    assert n_lit[0] > n_rob[0]
+    assert abs(st["surface"] - n_lit[0]) < 0.5 * (n_lit[0] - n_rob[0]) + 3
+    assert abs(st["volume"] - n_lit[1]) <= 2e-3 * max(n_lit[1], 1)
+    got = r_eps.seed(0).photon_sample_array(spp)
+    got32 = r_f32.seed(0).photon_sample_array(spp)
+    exp = lit.render(cam, size, size, spp, seed=0)
+    exp_rob = rob.render(cam, size, size, spp, seed=0)
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    err, bias = rel_rms(got, exp), (got.mean() - exp.mean()) / exp.mean()
+    err32, bias32 = rel_rms(got32, exp), (got32.mean() - exp.mean()) / exp.mean()
+    rob_bias = (exp_rob.mean() - exp.mean()) / exp.mean()
+    rob_spread = rel_rms(exp_rob / (1.0 + rob_bias), exp)
+    print({"eps_vs_literal": [err, bias], "f32_vs_literal": [err32, bias32], "robust_oracle_vs_literal": [rel_rms(exp_rob, exp), rob_bias],
+           "robust_oracle_vs_literal_bias_removed": rob_spread})
+    assert bias32 > 8e-3                      # what the mode is for
+    assert abs(bias) < 3e-3
+    assert err < 1.25 * rob_spread + 1e-3
+
+
+def test_the_frame_does_not_depend_on_the_slices():
+    """The camera pass of a call runs slice by slice when the per-sample selections of all its samples would not fit the budget
+    (option "f64_photon_slice" forces small slices here): the same samples, added up in another order."""
+    n, size = 5000, 48
+    r_eps, _ = _renderers("C4", size, n)
+    r_eps.seed(3).photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    whole = r_eps.seed(0).photon_sample_array(24)
+    for slice_ in (16, 5, 64):
+        r_eps.scene.set_option("f64_photon_slice", slice_)
+        r_eps._sample_offset = 0
+        got = r_eps.photon_sample_array(24)
+        rel = np.abs(got - whole) / np.abs(whole)
+        print(slice_, "max rel", rel.max(), "entries above 1e-6:", (rel > 1e-6).sum(), "of", rel.size)
+        # the partial sums of the volume estimate are fp32 and regroup with the slices (1e-7); measured besides: 2 of 6,912 entries off by
+        # 1e-4 -- one photon sphere accepted by one grouping's beam walk and not by the other's
+        assert (rel > 2e-6).sum() <= 4 and rel.max() < 1e-3, slice_
+    r_eps.scene.set_option("f64_photon_slice", 0)
+    r_eps._sample_offset = 0          # ... and two calls with the sample offset moved on
+    a = r_eps.photon_sample_array(16)
+    b = r_eps.photon_sample_array(8)
+    rel = np.abs((16 * a + 8 * b) / 24 - whole) / np.abs(whole)
+    assert (rel > 2e-6).sum() <= 4 and rel.max() < 1e-3
+
+
+def test_the_camera_pass_is_a_function_of_its_inputs():
+    n, size, spp = 20000, 64, 16
+    r_eps, _ = _renderers("C4", size, n)
+    r_eps.seed(7).photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    first = r_eps.seed(0).photon_sample_array(spp)
+    for _ in range(4):
+        r_eps._sample_offset = 0
+        assert np.array_equal(first, r_eps.photon_sample_array(spp))
+
+
+@pytest.mark.parametrize("kind", [Renderer.PHOTON_MAP, Renderer.PHOTON_BEAM_BEAM])
+def test_the_other_two_estimators(kind):
+    """photon x photon (the distance drawn first decides between the volume gather and the surface estimate, src/photon.rs:384-438)
+    and beam x beam (thinned volume photons, :779-787) through the same two fp64 passes."""
+    n, size, spp = 20000, 48, 16
+    r_eps, r_f32 = _renderers("C4", size, n, 20, 8)
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    lit = _oracle(scene).photon_map(n, kind, 14.65 * n, 20, 8, seed=5, robust=0)
+    r_eps.seed(5).photon_map_build(n, kind)
+    got = r_eps.seed(0).photon_sample_array(spp)
+    exp = lit.render(cam, size, size, spp, seed=0)
+    err, bias = rel_rms(got, exp), (got.mean() - exp.mean()) / exp.mean()
+    print({"kind": kind, "eps_vs_literal": [err, bias]})
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    # (the beam x beam map keeps one volume photon in a thousand -- ~40 beams here --, drawn from a side stream in path order: a chain
+    # that parts from the oracle's at a self-intersection changes which beams are kept; measured +0.9 % / 1.1e-2, against 1e-5 / 1.4e-3
+    # for the photon x photon map)
+    if kind == Renderer.PHOTON_BEAM_BEAM:
+        assert abs(bias) < 3e-2 and err < 5e-2
+    else:
+        assert abs(bias) < 2e-3 and err < 5e-3
+
+
+def test_c4_at_its_configured_size_against_the_literal_reference():
+    """Config C4 as the bench runs it (1 M photons, 1024 x 1024 x 256 spp) on a 2,048-pixel subset, against the oracle's literal map
+    and camera pass; written to gpurun_out/parity_full_C4eps.json."""
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    scene.set_option("epsilon_policy", 1)
+    n, watts, w, h = cfg["photons"], cfg["renderer_watts"], 1024, 1024
+    r = Renderer(scene, cam).width(w).height(h).watts(watts).gather_size(cfg["gather_size"]).gather_size_volume(cfg["gather_size_volume"]).seed(7)
+    st = r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    pix = np.sort(np.random.default_rng(5).choice(w * h, size=2048, replace=False)).astype(np.uint32)
+    got = r.seed(0).photon_sample_array(256)[pix]
+    scene0, _, _ = scenes.CONFIGS["C4"]()
+    lit = _oracle(scene0).photon_map(n, 1, watts, cfg["gather_size"], cfg["gather_size_volume"], seed=7, robust=0)
+    exp = lit.render(cam, w, h, 256, seed=0, pixels=pix)[pix]
+    counts = [len(lit.photons(0)), len(lit.photons(1))]
+    err, bias = rel_rms(got, exp), (got.mean() - exp.mean()) / exp.mean()
+    out = {"config": "C4 (epsilon_policy = 1)", "size": [w, h, 256], "pixels": int(len(pix)), "photons": n,
+           "rel_rms_vs_literal_oracle_256spp": err, "mean_bias_vs_literal_256spp": float(bias),
+           "stored_photons_device": [st["surface"], st["volume"]], "stored_photons_literal_oracle": counts}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_full_C4eps.json", "w") as f:
+        json.dump(out, f, indent=1)
+    print(out)
+    assert np.all(np.isfinite(got))
+    assert abs(st["surface"] - counts[0]) < 1e-3 * counts[0] and abs(st["volume"] - counts[1]) < 1e-3 * counts[1]
+    assert abs(bias) < 2e-3 and err < 6e-3
+
+
+def test_what_photon_mapping_in_the_mode_refuses():
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    scene.set_option("epsilon_policy", 1)
+    r = Renderer(scene, cam).width(16).height(16).watts(1000.0)
+    with pytest.raises(RptError):
+        r.photon_shoot(1000, Renderer.PHOTON_POINT_BEAM, 0, 2)   # the 48-byte records do not carry the fp64 positions
