@@ -53,11 +53,14 @@ SCENE_FILES = {"C2": "examples/cornell.rs", "C3": "examples/volumetric_pathtrace
                "C4": "examples/volumetric_beamphoton_lampshade.rs", "C5": "examples/dragon.rs layout, procedural 100,352-triangle mesh",
                "C5G": "C5's mesh inside a KdTree<Box<dyn Bounded>> of 64 spheres (the shape of examples/fractal_teapots.rs:56 with one large mesh)",
                "C3eps": "examples/volumetric_pathtrace_lampshade.rs, reference-epsilon mode (option epsilon_policy = 1: fp64, rpt's own 1e-12 tests)",
-               "C2eps": "examples/cornell.rs, reference-epsilon mode (option epsilon_policy = 1)"}
+               "C2eps": "examples/cornell.rs, reference-epsilon mode (option epsilon_policy = 1)",
+               "C4eps": "examples/volumetric_beamphoton_lampshade.rs, reference-epsilon mode (option epsilon_policy = 1: shooting pass and the surface "
+                        "estimate's visibility rays in fp64 with rpt's own 1e-12 tests; maps, k-nearest selection and beam estimate on the fp32 records)"}
 WORKLOAD_NAMES = {"C2": "C2 cornell box path trace", "C3": "C3 lampshade-in-fog path trace",
                   "C4": "C4 lampshade beam x point photon map", "C5": "C5 100k-triangle mesh in fog path trace",
                   "C5G": "C5G (not a BASELINE configuration) 100k-triangle mesh in a kd-tree group of 64 spheres, in fog",
-                  "C3eps": "C3 lampshade-in-fog path trace, reference-epsilon mode (fp64)", "C2eps": "C2 cornell box path trace, reference-epsilon mode (fp64)"}
+                  "C3eps": "C3 lampshade-in-fog path trace, reference-epsilon mode (fp64)", "C2eps": "C2 cornell box path trace, reference-epsilon mode (fp64)",
+                  "C4eps": "C4 lampshade beam x point photon map, reference-epsilon mode (fp64 shooting + visibility rays)"}
 
 
 def usable_cpus():
@@ -585,19 +588,33 @@ def measure(workload, args, steps, warmup, streams_opt, torch, dist, rank, local
         ray_flops = (56 + 25) * stats["spheres"] + (56 + 30) * cubes + 12 * stats["planes"] + 75 * tris
         flops_ps = ray_flops + 300 + (20.0 * cnt["bvh_nodes"] + 25.0 * cnt["bvh_tris"]) / samples_c + 40.0 * cfg["gather_size"]
         ach_tflops = flops_ps * local_samples / (k_ms * 1e-3) / 1e12
-        out["config"] = {"workload": f"{WORKLOAD_NAMES['C4']} {width}x{height}x{spp}spp, {n_photons} photons shot + map build + "
-                                     f"camera pass per step", "scene": SCENE_FILES["C4"], "parallelism": parallelism,
+        out["config"] = {"workload": f"{WORKLOAD_NAMES[workload]} {width}x{height}x{spp}spp, {n_photons} photons shot + map build + "
+                                     f"camera pass per step", "scene": SCENE_FILES[workload], "parallelism": parallelism,
                          "streams": n_streams, "camera_pass_kernel_ms": round(k_ms, 3),
                          "beam_tests_per_sample": round(cnt["bvh_nodes"] / samples_c, 1),
                          "beam_accepted_per_sample": round(cnt["bvh_tris"] / samples_c, 1)}
-        out["roofline"] = roofline_block("rptg::photon_query_kernel", k_ms, k_src, grid_blocks, pmc, pmc_path, pmc_current, compulsory, model, True)
-        out.update({"valu_frac": round(ach_tflops / FP32_PEAK_TFLOPS, 4), "valu_tflops": round(ach_tflops, 3),
-                    "valu_peak_tflops": FP32_PEAK_TFLOPS, "algorithmic_flops_per_sample": round(flops_ps, 1),
-                    "valu_frac_is": "camera pass only (the map build is ~10 % of a step): camera ray on the reference's object list + 20 per "
-                                    "tested and 25 per accepted (ray, photon) pair + 40 per gathered surface photon; visibility rays not counted",
+        kernel = "rptg::photon_query_kernel"
+        peak, frac_is = FP32_PEAK_TFLOPS, ("camera pass only (the map build is ~10 % of a step): camera ray on the reference's object list + 20 per "
+                                           "tested and 25 per accepted (ray, photon) pair + 40 per gathered surface photon; visibility rays not counted")
+        if eps:
+            # two kernels per camera pass: the fp32 one (beam estimate, k-nearest selection handed over per sample: gather_size + 2 dwords
+            # written, then read) and the fp64 one (camera ray again, one visibility ray per gathered photon, the terms) with its fp64 slab
+            kernel = "rptg::photon_query_kernel<EMIT> + rpt64::photon_surface_f64_kernel"
+            model += n_owned_px * spp * (cfg["gather_size"] + 2) * 4.0 * 2.0 + n_owned_px * 64.0 * n_chunks
+            flops_ps += ray_flops * (1 + cfg["gather_size"])   # here every visibility ray is traced, as in the reference
+            ach_tflops = flops_ps * local_samples / (k_ms * 1e-3) / 1e12
+            peak, frac_is = FP64_PEAK_TFLOPS, ("camera pass only, both kernels, priced against the fp64 vector peak although the beam estimate runs in fp32: "
+                                              "as for C4, plus the fp64 camera ray and one visibility ray per gathered photon on the reference's object list")
+        out["roofline"] = roofline_block(kernel, k_ms, k_src, grid_blocks, pmc, pmc_path, pmc_current, compulsory, model, True)
+        out.update({"valu_frac": round(ach_tflops / peak, 4), "valu_tflops": round(ach_tflops, 3),
+                    "valu_peak_tflops": peak, "algorithmic_flops_per_sample": round(flops_ps, 1),
+                    "valu_frac_is": frac_is,
                     "valu_issue_frac": issue, "active_lanes": lanes, "s_waitcnt_share": wait, "pmc_source": pmc_path if pmc_current else None})
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, r.watts_)
+            key = ("photon", workload[:-3] if eps else workload, width, height, spp, n_photons)   # (C4 and C4eps share the leg: the literal oracle either way)
+            if key not in _CPU_LEG:
+                _CPU_LEG[key] = cpu_baseline_photon(scene, cam, cfg, width, height, spp, n_photons, r.watts_)
+            out["cpu_baseline"] = _CPU_LEG[key]
         mirror_issue_figures(out)
         return out
 
@@ -700,12 +717,12 @@ def main(argv=None):
     default_run = args.workload == "C3" and not (args.width or args.height or args.spp or args.chunk_spp or args.emulate_shard)
     if world == 1 and dist is None and default_run and not args.no_secondary:
         secondary = []
-        for wl in ("C3eps", "C2", "C2eps", "C4", "C5", "C5G"):
+        for wl in ("C3eps", "C2", "C2eps", "C4", "C4eps", "C5", "C5G"):
             entry = measure(wl, args, 2, 1, 1, torch, None, rank, local_rank, world, False)
             entry = dict({"workload": wl}, **entry)
             secondary.append(entry)
         out["secondary"] = secondary
-        out["secondary_note"] = ("C3eps (and C2eps): the headline configuration (and C2) in the reference-epsilon mode (option epsilon_policy = 1: fp64, rpt's own 1e-12 tests -- "
+        out["secondary_note"] = ("C3eps (and C2eps, C4eps): the headline configuration (and C2, C4) in the reference-epsilon mode (option epsilon_policy = 1: fp64, rpt's own 1e-12 tests -- "
                                  "the mode that is within 1e-3 of the reference per pixel); then the other BASELINE configurations at their configured sizes (and C5G: the scene-tree + parked-mesh-walk flavour, "
                                  "2048x2048x256), 2 timed steps each after 1 warm-up, strictly one stream (ms_per_step = wall_clock_s x 1000), "
                                  "same definitions as the headline")

@@ -323,9 +323,15 @@ int rpt_frame_unpack_device(uint32_t width, uint32_t height, uint32_t rank, uint
  * rpt_render_into_buffer), same RNG streams, same sharding; 4-5 times slower than the fp32 path (C3: 2.9 Gsamples/s).
  * Supported: spheres, cubes, planes, meshes (scanned triangle by triangle), KdTree groups of them as objects and as
  * Light::Objects (nested at most three deep), all materials, lights and media, Environment::Color and Environment::Hdri.
- * Refused with RPT_ERR_UNSUPPORTED: groups nested deeper, photon mapping.
+ * Photon mapping (rpt_photon_map_build, rpt_photon_render_sample*): the shooting pass and the surface estimate's visibility rays run in
+ * fp64 with the reference's tests (t_min = 1e-12; a gathered photon counts unless len > hit.time, src/photon.rs:357-361); the maps, the
+ * k-nearest selection and the volume estimates are those of the fp32 records.
+ * Refused with RPT_ERR_UNSUPPORTED: groups nested deeper; rpt_photon_shoot / rpt_photon_map_from_records (the 48-byte records do not
+ * carry the photons' fp64 positions: every rank builds the whole map with rpt_photon_map_build).
  * Options of the mode: "f64_cull" (1; 0 = full scan, 2 = the counters build keeps the search limits), "f64_surf_batch"
  * (8: lanes of a wave that wait at a surface event in a medium before the wave runs the surface code).
+ * "f64_photon_slice" (0 = automatic: as many whole chunks of 256 samples as keep the per-sample selections, (gather_size + 2) dwords
+ * each, within 32 GB): samples per slice of the photon camera pass.  "photon_skip" bit 4096: no visibility rays (diagnostic).
  * rpt_debug_epsilon_counters (option "counters" = 1): [0] closest-hit queries, [1] accepted hits, [2] accepted hits with
  * t < 1e-9 (1 + |origin|) -- a ray hitting the surface it starts on --, [3] shadow tests, [4] passed, [5] failed although
  * |hit - dist| < 1e-6 dist -- the light's own surface missed by rounding --, [6] camera samples, [7] path vertices; the

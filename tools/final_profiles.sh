@@ -22,7 +22,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_default" -o s --output-format csv -- python3 "$REPO/bench.py" --no-cpu-baseline > "$OUT/stats_default.log" 2>&1
 echo "stats default done"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_c3" -o s --output-format csv -- python3 "$REPO/bench.py" --streams 1 --no-cpu-baseline --no-secondary > "$OUT/stats_c3.log" 2>&1
-for wl in C3eps C2 C2eps C4 C5 C5G; do
+for wl in C3eps C2 C2eps C4 C4eps C5 C5G; do
   rocprofv3 --kernel-trace --stats -d "$OUT/stats_$wl" -o s --output-format csv -- python3 "$REPO/bench.py" --workload $wl --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/stats_$wl.log" 2>&1
   echo "stats $wl done"
 done
