@@ -90,6 +90,8 @@ def lib():
         L.orc_light_illuminate.argtypes = [P, C.c_int, D, C.c_uint64, C.c_uint32, C.c_uint32, D, D, D]
         L.orc_photon_map_build.restype = P
         L.orc_photon_map_build.argtypes = [P, C.c_uint64, C.c_int, C.c_double, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+        L.orc_photon_map_from_photons.restype = P
+        L.orc_photon_map_from_photons.argtypes = [C.c_uint64, C.c_int, C.c_double, C.c_uint64, C.c_uint64, P, C.c_uint64, P, C.c_uint64]
         L.orc_photon_map_free.argtypes = [P]
         L.orc_photon_map_get.restype = C.c_uint64
         L.orc_photon_map_get.argtypes = [P, C.c_int, P]
@@ -187,6 +189,11 @@ class OracleScene:
                             t.ctypes.data_as(C.c_void_p), obj.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p))
         return t, obj, nrm
 
+    def photon_map_from_photons(self, photon_count, kind, watts, gather_size, gather_size_volume, surface, volume, robust=0):
+        """The maps of PhotonMap::new over photon lists handed in ((n, 10) arrays laid out as OraclePhotonMap.photons returns them):
+        a camera pass on the very photons another implementation shot."""
+        return OraclePhotonMap(self, photon_count, kind, watts, gather_size, gather_size_volume, 0, robust, photons=(surface, volume))
+
     def photon_map(self, photon_count, kind, watts, gather_size=50, gather_size_volume=50, seed=0, robust=0):
         """Renderer::photon_render's shooting + map build (src/photon.rs:655-704)."""
         return OraclePhotonMap(self, photon_count, kind, watts, gather_size, gather_size_volume, seed, robust)
@@ -206,9 +213,15 @@ class OracleScene:
 class OraclePhotonMap:
     PHOTON_MAP, POINT_BEAM, BEAM_BEAM = 0, 1, 2
 
-    def __init__(self, oscene, photon_count, kind, watts, gather_size, gather_size_volume, seed, robust):
+    def __init__(self, oscene, photon_count, kind, watts, gather_size, gather_size_volume, seed, robust, photons=None):
         self.oscene = oscene
         self.robust = robust
+        if photons is not None:
+            ps = np.ascontiguousarray(photons[0], dtype=np.float64).reshape(-1, 10)
+            pv = np.ascontiguousarray(photons[1], dtype=np.float64).reshape(-1, 10)
+            self.h = lib().orc_photon_map_from_photons(photon_count, kind, watts, gather_size, gather_size_volume,
+                                                       ps.ctypes.data_as(C.c_void_p), len(ps), pv.ctypes.data_as(C.c_void_p), len(pv))
+            return
         self.h = lib().orc_photon_map_build(oscene.h, photon_count, kind, watts, gather_size, gather_size_volume,
                                             C.c_uint64(seed), robust)
         if not self.h:

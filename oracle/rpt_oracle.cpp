@@ -1827,6 +1827,34 @@ orc_photon_map* orc_photon_map_build(orc_scene* s, uint64_t photon_count, int ki
     return m;
 }
 void orc_photon_map_free(orc_photon_map* m) { delete m; }
+// Test hook: the maps of PhotonMap::new (src/photon.rs:181-311) over photon lists handed in -- n * 10 doubles each, laid out as
+// orc_photon_map_get writes them (position, direction or start of the beam, power, unused) -- instead of lists this oracle shot: lets
+// a camera pass be compared on the very photons of another implementation's shooting pass.
+orc_photon_map* orc_photon_map_from_photons(uint64_t photon_count, int kind, double watts, uint64_t gather_size, uint64_t gather_size_volume,
+                                            const double* surface, uint64_t n_surface, const double* volume, uint64_t n_volume) {
+    auto* m = new orc_photon_map();
+    m->pp = PhotonParams{photon_count, kind, watts, gather_size, gather_size_volume};
+    m->pm.kind = kind;
+    auto fill = [&](const double* in, uint64_t n, std::vector<Photon>& out, bool beams) {
+        out.resize(n);
+        for (uint64_t i = 0; i < n; i++) {
+            const double* o = in + i * 10;
+            out[i].position = V3(o[0], o[1], o[2]);
+            out[i].power = V3(o[6], o[7], o[8]);
+            if (beams) {
+                out[i].starting_position = V3(o[3], o[4], o[5]);
+                out[i].direction = -normalize(out[i].position - out[i].starting_position);
+            } else {
+                out[i].direction = V3(o[3], o[4], o[5]);
+                out[i].starting_position = out[i].position;
+            }
+        }
+    };
+    fill(surface, n_surface, m->pm.list.surface, false);
+    fill(volume, n_volume, m->pm.list.volume, kind == PK_BEAM_BEAM);
+    m->pm.build();
+    return m;
+}
 // which: 0 surface, 1 volume.  out (may be null): n * 10 doubles: position, direction, power, radius (volume, point-beam)
 uint64_t orc_photon_map_get(orc_photon_map* m, int which, double* out) {
     const std::vector<Photon>& v = which == 0 ? m->pm.list.surface : m->pm.list.volume;

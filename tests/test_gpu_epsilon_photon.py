@@ -65,6 +65,35 @@ def test_shooting_and_camera_pass_follow_the_literal_reference(name):
     assert err < 1.25 * rob_spread + 1e-3
 
 
+def _device_photons(r):
+    """The device's map as the oracle takes photon lists: shooting order; surface positions as the shooting pass holds them (fp64)."""
+    ps = r.photon_map_download(0).astype(np.float64)
+    ps[:, :3] = r.photon_positions64()
+    return ps, r.photon_map_download(1).astype(np.float64)
+
+
+@pytest.mark.parametrize("name", ["C4", "C2"])
+def test_camera_pass_on_the_devices_own_photons(name):
+    """The camera pass alone: the oracle builds its maps over the DEVICE's photons (oracle test hook photon_map_from_photons) and runs
+    its literal camera pass -- no parted chains between the two frames, only the pass's own arithmetic: the fp32 selection and beam
+    estimate, and the visibility rays' lottery wherever a last bit of the query point differs."""
+    n, size, spp = 20000, 64, 16
+    r_eps, r_f32 = _renderers(name, size, n)
+    scene, cam, cfg = scenes.CONFIGS[name]()
+    r_eps.seed(7).photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    ps, pv = _device_photons(r_eps)
+    assert np.abs(ps[:, :3] - r_eps.photon_map_download(0)[:, :3]).max() < 1e-4      # (the records hold these positions rounded to fp32)
+    pm = _oracle(scene).photon_map_from_photons(n, 1, 14.65 * n, 20, 3, ps, pv, robust=0)
+    exp = pm.render(cam, size, size, spp, seed=0)
+    got = r_eps.seed(0).photon_sample_array(spp)
+    err, bias = rel_rms(got, exp), (got.mean() - exp.mean()) / exp.mean()
+    # the same photons under the robust policy, for scale: what the epsilon policy alone is worth in the camera pass
+    exp_rob = _oracle(scene).photon_map_from_photons(n, 1, 14.65 * n, 20, 3, ps, pv, robust=1).render(cam, size, size, spp, seed=0)
+    print({"name": name, "eps_vs_literal_same_photons": [err, bias], "robust_vs_literal_same_photons": [rel_rms(exp_rob, exp), (exp_rob.mean() - exp.mean()) / exp.mean()]})
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert err < 3e-3 and abs(bias) < 1e-3
+
+
 def test_the_frame_does_not_depend_on_the_slices():
     """The camera pass of a call runs slice by slice when the per-sample selections of all its samples would not fit the budget
     (option "f64_photon_slice" forces small slices here): the same samples, added up in another order."""
@@ -137,8 +166,14 @@ def test_c4_at_its_configured_size_against_the_literal_reference():
     exp = lit.render(cam, w, h, 256, seed=0, pixels=pix)[pix]
     counts = [len(lit.photons(0)), len(lit.photons(1))]
     err, bias = rel_rms(got, exp), (got.mean() - exp.mean()) / exp.mean()
+    # ... and the camera pass alone: the oracle's literal pass over the device's own photons
+    ps, pv = _device_photons(r)
+    own = _oracle(scene0).photon_map_from_photons(n, 1, watts, cfg["gather_size"], cfg["gather_size_volume"], ps, pv, robust=0)
+    exp_own = own.render(cam, w, h, 256, seed=0, pixels=pix)[pix]
+    err_own, bias_own = rel_rms(got, exp_own), (got.mean() - exp_own.mean()) / exp_own.mean()
     out = {"config": "C4 (epsilon_policy = 1)", "size": [w, h, 256], "pixels": int(len(pix)), "photons": n,
            "rel_rms_vs_literal_oracle_256spp": err, "mean_bias_vs_literal_256spp": float(bias),
+           "camera_pass_alone_rel_rms_vs_literal_oracle_on_the_device_photons": err_own, "camera_pass_alone_mean_bias": float(bias_own),
            "stored_photons_device": [st["surface"], st["volume"]], "stored_photons_literal_oracle": counts}
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/parity_full_C4eps.json", "w") as f:
@@ -147,6 +182,7 @@ def test_c4_at_its_configured_size_against_the_literal_reference():
     assert np.all(np.isfinite(got))
     assert abs(st["surface"] - counts[0]) < 1e-3 * counts[0] and abs(st["volume"] - counts[1]) < 1e-3 * counts[1]
     assert abs(bias) < 2e-3 and err < 6e-3
+    assert abs(bias_own) < 5e-4 and err_own < 1.5e-3
 
 
 def test_what_photon_mapping_in_the_mode_refuses():

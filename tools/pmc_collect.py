@@ -26,7 +26,8 @@ args, _ = ap.parse_known_args()
 from rpt_amd import scenes  # noqa: E402  (pure Python: scene constants only)
 eps = args.workload.endswith("eps")
 cfg = scenes.CONFIGS[args.workload[:-3] if eps else args.workload]()[2]
-kernel = "render_f64_kernel" if eps else "photon_query_kernel" if "photons" in cfg else "render_kernel"
+kernel = (("photon_surface_f64_kernel" if eps else "photon_query_kernel") if "photons" in cfg
+          else "render_f64_kernel" if eps else "render_kernel")   # (C4eps: the fp64 half of the camera pass)
 tot, launches, durations = defaultdict(float), defaultdict(set), []
 for f in glob.glob(args.out + "/pass*/**/*counter_collection.csv", recursive=True):
     rows = [row for row in csv.DictReader(open(f)) if kernel in row.get("Kernel_Name", "")]
