@@ -54,7 +54,7 @@ struct CullBox {
     float lo[3];
     uint32_t unbounded;
     float hi[3];
-    uint32_t _pad;
+    uint32_t slab_test;   // 1: a cube -- its intersection is a slab test that a 0 / 0 corrupts (kernels_f64.hip, cull32); 2: a union box (Scene::cull32) with a cube in it
 };
 // What Shape::intersect of one object needs, read per lane (every lane may hold a different object): 176 bytes.
 // A shape inside `KdTree<Box<dyn Bounded>>` groups (src/kdtree.rs:103-146) is a record of its own -- the group's kd-tree is an
@@ -111,6 +111,11 @@ struct Scene {
     double env[3];
     const double* hdri;         // Environment::Hdri (src/environment.rs:3-52): width x height x 3, row-major; hdri_w = 0: Environment::Color(env)
     uint32_t hdri_w, hdri_h;
+    // Where the cubes' faces lie, per axis, as 64 buckets over [face_base, face_base + 64 / face_inv_cell): a ray with a zero direction
+    // component takes part in cull32's extra test only if its origin's coordinate on that axis falls into a marked bucket (every face
+    // marks the buckets of its coordinate -+ the test's tolerance, so the lane's own bucket suffices).
+    float face_base[3], face_inv_cell[3];
+    unsigned long long face_bits[3];
 };
 struct Camera {   // src/camera.rs:9-27, with `d` and `right` of cast_ray (:67-68) evaluated once, in fp64, on the host
     double eye[3], direction[3], up[3], right[3];

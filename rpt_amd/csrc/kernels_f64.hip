@@ -249,6 +249,15 @@ R64_DEV PairHit eval_pair(RP recs, TP trecs, uint32_t i, D o, D d) {
 // their extent and of their coordinates), the ray's origin error is covered by `eo`, and the slab interval is widened
 // by 4e-6 relative before it is compared -- three orders of magnitude above what fp32 rounding of the fp64 ray and of
 // the slab arithmetic can move it.  A NaN (0 * inf) compares false and keeps the object.
+// One exception to "an object whose box the ray misses cannot be hit": a ray that runs exactly parallel to an axis (a direction
+// component that is 0 -- a visibility ray between two points of one axis-aligned wall, y = 0 = y) and starts exactly in a face plane of
+// a cube makes the reference's slab test divide 0 by 0, and with a NaN in one axis's interval its comparisons no longer hold the other
+// axes' entry times (src/shape/cube.rs:23-60): the reference then reports a hit for a ray that passes BESIDE the cube.  (A mesh's or a
+// group's bounds gate can be fooled the same way, but only into letting the ray in: the hit itself is a triangle's or a child's, whose own
+// box the ray must then cross.)  So a cube (CullBox::slab_test) is also kept when the ray has a zero component in an axis in which its
+// origin lies within the padding of one of the box's two faces (a zero component shows as an infinite reciprocal; the extra test runs only in
+// waves that hold such a ray).
+template <bool ANY_ZERO>
 R64_DEV uint32_t cull32(const CullBox* boxes, uint32_t base, uint32_t nb, float ox, float oy, float oz, float ix, float iy, float iz,
                         float eo, float tlim) {
     uint32_t mask = 0u;
@@ -267,7 +276,18 @@ R64_DEV uint32_t cull32(const CullBox* boxes, uint32_t base, uint32_t nb, float 
         const float tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
         const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
         const float tn_lo = tn - 4e-6f * fabsf(tn), tf_hi = tf + 4e-6f * fabsf(tf);
-        const bool out = tn_lo > tf_hi || tf_hi < 0.f || tn_lo > tlim;
+        bool out = tn_lo > tf_hi || tf_hi < 0.f || tn_lo > tlim;
+        if (ANY_ZERO && __float_as_uint(hi.w) != 0u) {   // (wave-uniform: such a ray in the wave, and a cube -- or a union box that holds one)
+            // the faces lie within two paddings (a group's child is padded twice) of the stored ones: 1e-5 of the box's size and of its coordinates each
+            const float size = fmaxf(fmaxf(hi.x - lo.x, hi.y - lo.y), hi.z - lo.z);
+            const float mag = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
+            const float tol = 5e-5f * (size + mag) + eo;
+            const bool zx = fabsf(ix) == __builtin_huge_valf(), zy = fabsf(iy) == __builtin_huge_valf(), zz = fabsf(iz) == __builtin_huge_valf();   // 1 / (+-0)
+            const bool on_face = (zx && (fabsf(ox - lo.x) <= tol || fabsf(ox - hi.x) <= tol)) ||
+                                 (zy && (fabsf(oy - lo.y) <= tol || fabsf(oy - hi.y) <= tol)) ||
+                                 (zz && (fabsf(oz - lo.z) <= tol || fabsf(oz - hi.z) <= tol));
+            if (on_face || (__float_as_uint(hi.w) == 2u && (zx || zy || zz))) out = false;
+        }
         if (!out) mask |= 1u << j;
     }
     return mask;
@@ -310,6 +330,18 @@ R64_DEV void closest_hit_wave(RP recs, TP trecs, volatile uint32_t* slots, bool 
     const float ix = __builtin_amdgcn_rcpf(float(d.x)), iy = __builtin_amdgcn_rcpf(float(d.y)), iz = __builtin_amdgcn_rcpf(float(d.z));
     const float eo = 1e-6f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
     const float tl = float(tlim) * 1.00001f;
+    // direction components that are zero (or too small for fp32: treated alike): see cull32
+    // a zero direction component whose origin coordinate lies in a bucket some cube's face marked (Scene::face_bits): see cull32
+    auto near_face = [&](int k, float dk, float ok) {
+        if (dk != 0.f) return false;
+        const float f = (ok - KA.sc.face_base[k]) * KA.sc.face_inv_cell[k];
+        return f >= 0.f && f < 64.f && ((KA.sc.face_bits[k] >> uint32_t(f)) & 1ull) != 0ull;
+    };
+    bool any_zero = false;   // wave-uniform
+#ifndef R64_NO_SLAB_EXCEPTION   // (defined in A/B builds only: tools/build_variant.sh)
+    if (__ballot(mine && (float(d.x) == 0.f || float(d.y) == 0.f || float(d.z) == 0.f)) != 0ull)
+        any_zero = __ballot(mine && (near_face(0, float(d.x), ox) || near_face(1, float(d.y), oy) || near_face(2, float(d.z), oz))) != 0ull;
+#endif
     for (uint32_t base = 0; base < n; base += 32u) {
         const uint32_t nb = min(32u, n - base);
         uint32_t mask = 0u;
@@ -317,8 +349,13 @@ R64_DEV void closest_hit_wave(RP recs, TP trecs, volatile uint32_t* slots, bool 
             mask = nb == 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
             if (cull) {
                 // scenes of many objects: the 32 records' union box first (one test instead of 32 where no ray of the wave comes near)
-                if (n > 32u && cull32(KA.sc.cull32, base >> 5, 1u, ox, oy, oz, ix, iy, iz, eo, tl) == 0u) mask = 0u;
-                if (__ballot(mask != 0u) != 0ull) mask = mask ? cull32(KA.sc.cull, base, nb, ox, oy, oz, ix, iy, iz, eo, tl) : 0u;
+                if (any_zero) {   // (rare: the loops with the extra test)
+                    if (n > 32u && cull32<true>(KA.sc.cull32, base >> 5, 1u, ox, oy, oz, ix, iy, iz, eo, tl) == 0u) mask = 0u;
+                    if (__ballot(mask != 0u) != 0ull) mask = mask ? cull32<true>(KA.sc.cull, base, nb, ox, oy, oz, ix, iy, iz, eo, tl) : 0u;
+                } else {
+                    if (n > 32u && cull32<false>(KA.sc.cull32, base >> 5, 1u, ox, oy, oz, ix, iy, iz, eo, tl) == 0u) mask = 0u;
+                    if (__ballot(mask != 0u) != 0ull) mask = mask ? cull32<false>(KA.sc.cull, base, nb, ox, oy, oz, ix, iy, iz, eo, tl) : 0u;
+                }
             }
         }
         while (__ballot(mask != 0u) != 0ull) {   // one chunk of whole ranks per iteration
@@ -1272,7 +1309,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void photon_surface_f64_kernel(cons
                 dirn = normalize(disp);
             }
             Query v{kInf, -1, 0u};
-            if (!(KQ.skip & 4096u)) closest_hit_wave<false>(recs, trecs, slots, has, po, dirn, len, v, ce, cr);
+            if (!(KQ.skip & 4096u)) closest_hit_wave<false>(recs, trecs, slots, has, po, dirn, (KQ.skip & 16384u) ? kInf : len, v, ce, cr);   // (16384: DEBUG no search limit)
             if (has && !(v.obj >= 0 && len > v.t)) {   // :357-361
                 const double c = fmin(fmax(dot(pdir, n), 0.0), 1.0);
                 color = color + (bsdf(KA.sc.shade[hobj].mat, n, wo, pdir) * ppow) * c;

@@ -2541,7 +2541,6 @@ static int photon_render_impl(rpt_scene* s, const rpt_camera* cam, const rpt_ren
         sa.a.n_chunks = n_groups;                    // of 64 samples: one work item per (group, pixel)
         sa.a.n_items = n_groups * q.r.n_owned;       // (< 2^32: n_owned * n_chunks of kSuper was checked, and a chunk holds four groups)
         sa.a.slab = pm->d_slab64;
-        if (!sa.a.cull) sa.a.cull = 1u;              // (the searches end at the query point: f64_cull = 0 has no meaning here)
         sa.emit = pm->d_emit;
         sa.s_ph = reinterpret_cast<const rpt64::PhotonRec32*>(pm->surf.sorted);
         sa.pos64 = pm->pos64;

@@ -1768,6 +1768,7 @@ static int flatten64(const HShape& hs, const rpt_material& mat, std::vector<uint
     if (sh.kind == rpt64::SH_PLANE) r.b[3] = sh.plane[3];
     // the fp32 world box: the shape's own box under its matrix, then under the groups' matrices, innermost first
     rpt64::CullBox cb = cull_box64(sh);
+    cb.slab_test = sh.kind == rpt64::SH_CUBE ? 1u : 0u;
     if (!cb.unbounded && !outer.empty()) {
         double lo[3], hi[3];
         for (int k = 0; k < 3; k++) { lo[k] = cb.lo[k]; hi[k] = cb.hi[k]; }
@@ -1862,6 +1863,7 @@ static int build_scene64(rpt_scene* s) {
         for (int k = 0; k < 3; k++) { u.lo[k] = HUGE_VALF; u.hi[k] = -HUGE_VALF; }
         for (size_t i = 32 * g; i < std::min(n, 32 * g + 32); i++) {
             if (cull[i].unbounded) u.unbounded = 1u;
+            if (cull[i].slab_test) u.slab_test = 2u;
             for (int k = 0; k < 3; k++) { u.lo[k] = std::min(u.lo[k], cull[i].lo[k]); u.hi[k] = std::max(u.hi[k], cull[i].hi[k]); }
         }
         if (u.unbounded) for (int k = 0; k < 3; k++) u.lo[k] = u.hi[k] = 0.f;
@@ -1902,6 +1904,40 @@ static int build_scene64(rpt_scene* s) {
     v.hdri_w = s->hdri64.empty() ? 0u : s->hdri_w;
     v.hdri_h = s->hdri64.empty() ? 0u : s->hdri_h;
     v.n_objects = uint32_t(n);
+    // the buckets of the cubes' face coordinates (f64_layout.h, Scene::face_bits; the tolerance is cull32's, kernels_f64.hip)
+    for (int k = 0; k < 3; k++) {
+        float lo = HUGE_VALF, hi = -HUGE_VALF;
+        for (size_t i = 0; i < n; i++)
+            if (cull[i].slab_test && !cull[i].unbounded) { lo = std::min(lo, cull[i].lo[k]); hi = std::max(hi, cull[i].hi[k]); }
+        v.face_bits[k] = 0;
+        v.face_base[k] = 0.f;
+        v.face_inv_cell[k] = 0.f;
+        if (!(lo <= hi)) continue;   // no cube: no bucket is marked
+        float tol_max = 0.f;
+        for (size_t i = 0; i < n; i++)
+            if (cull[i].slab_test && !cull[i].unbounded) {
+                float size = 0.f, mag = 0.f;
+                for (int a = 0; a < 3; a++) { size = std::max(size, cull[i].hi[a] - cull[i].lo[a]); mag = std::max({mag, std::fabs(cull[i].lo[a]), std::fabs(cull[i].hi[a])}); }
+                tol_max = std::max(tol_max, 5e-5f * (size + mag));
+            }
+        const float mag_all = std::max(std::fabs(lo), std::fabs(hi));
+        const float T = 2.f * tol_max + 4e-6f * mag_all + 1e-30f;   // cull32's tolerance (its `eo` is 1e-6 of the origin, which lies within T of the face), twice
+        const float base = lo - 2.f * T, span = (hi + 2.f * T) - base;
+        const float inv = 64.f / (span * 1.0001f);
+        v.face_base[k] = base;
+        v.face_inv_cell[k] = inv;
+        auto mark = [&](float c) {
+            for (float x : {c - T, c, c + T}) {
+                const float f = (x - base) * inv;
+                if (f >= 0.f && f < 64.f) v.face_bits[k] |= 1ull << unsigned(f);
+            }
+            // (c - T and c + T may lie more than one bucket apart when the buckets are narrower than 2 T: mark the run)
+            const float f0 = std::max((c - T - base) * inv, 0.f), f1 = std::min((c + T - base) * inv, 63.f);
+            for (int b = int(f0); b <= int(f1); b++) v.face_bits[k] |= 1ull << unsigned(b);
+        };
+        for (size_t i = 0; i < n; i++)
+            if (cull[i].slab_test && !cull[i].unbounded) { mark(cull[i].lo[k]); mark(cull[i].hi[k]); }
+    }
     v.n_lights = uint32_t(lights.size());
     v.n_tris = uint32_t(tris.size());
     v.n_obj_tris = uint32_t(n_obj_tris);

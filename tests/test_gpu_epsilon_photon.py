@@ -91,7 +91,15 @@ def test_camera_pass_on_the_devices_own_photons(name):
     exp_rob = _oracle(scene).photon_map_from_photons(n, 1, 14.65 * n, 20, 3, ps, pv, robust=1).render(cam, size, size, spp, seed=0)
     print({"name": name, "eps_vs_literal_same_photons": [err, bias], "robust_vs_literal_same_photons": [rel_rms(exp_rob, exp), (exp_rob.mean() - exp.mean()) / exp.mean()]})
     assert np.all(np.isfinite(got)) and exp.mean() > 0
-    assert err < 3e-3 and abs(bias) < 1e-3
+    # measured: C4 9.4e-6 / -3e-6, C2 1.2e-4 / -5e-6 (the robust policy on the same photons: 1.4e-2 / +1.1 %, 3.5e-2 / +1.3 %)
+    assert err < 5e-4 and abs(bias) < 5e-5
+    # The visibility rays between two points of one axis-aligned wall have a direction component that is exactly 0; where such a ray
+    # starts in the plane of a cube's face (the boxes stand on the floor), the reference's slab test divides 0 by 0 and reports a hit
+    # for a ray that passes beside the cube (src/shape/cube.rs:23-60) -- 2.5 % of the floor's radiance next to the boxes.  The box
+    # culling keeps such cubes (kernels_f64.hip, cull32): the frame is the full scan's bit for bit.
+    r_eps.scene.set_option("f64_cull", 0)
+    r_eps._sample_offset = 0
+    assert np.array_equal(got, r_eps.photon_sample_array(spp))
 
 
 def test_the_frame_does_not_depend_on_the_slices():
@@ -182,7 +190,7 @@ def test_c4_at_its_configured_size_against_the_literal_reference():
     assert np.all(np.isfinite(got))
     assert abs(st["surface"] - counts[0]) < 1e-3 * counts[0] and abs(st["volume"] - counts[1]) < 1e-3 * counts[1]
     assert abs(bias) < 2e-3 and err < 6e-3
-    assert abs(bias_own) < 5e-4 and err_own < 1.5e-3
+    assert abs(bias_own) < 5e-5 and err_own < 3e-4
 
 
 def test_what_photon_mapping_in_the_mode_refuses():
