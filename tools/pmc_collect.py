@@ -26,26 +26,33 @@ args, _ = ap.parse_known_args()
 from rpt_amd import scenes  # noqa: E402  (pure Python: scene constants only)
 eps = args.workload.endswith("eps")
 cfg = scenes.CONFIGS[args.workload[:-3] if eps else args.workload]()[2]
-kernel = (("photon_surface_f64_kernel" if eps else "photon_query_kernel") if "photons" in cfg
-          else "render_f64_kernel" if eps else "render_kernel")   # (C4eps: the fp64 half of the camera pass)
-tot, launches, durations = defaultdict(float), defaultdict(set), []
-for f in glob.glob(args.out + "/pass*/**/*counter_collection.csv", recursive=True):
-    rows = [row for row in csv.DictReader(open(f)) if kernel in row.get("Kernel_Name", "")]
-    if kernel == "photon_query_kernel" and rows:
-        # the camera pass has no separate counters instantiation: the LAST launch of a bench.py run is its untimed counters pass
-        # (diagnostic timers and atomics: ten times slower) and does not belong in the means
-        last = max(int(row["Dispatch_Id"]) for row in rows)
-        rows = [row for row in rows if int(row["Dispatch_Id"]) != last]
-    for row in rows:
-        name = row.get("Kernel_Name", "")
-        if kernel == "render_f64_kernel" and re.search(r"render_f64_kernel<\w+, true", name):
-            continue  # (the counters instantiation)
-        if kernel == "render_kernel" and (re.search(r"render_kernel<\w+, \d, true[,>]", name) or re.search(r"render_kernelILb[01]ELi\dELb1E", name)):
-            continue  # the timed launches only (the COUNT = true instantiation is bench.py's untimed counter pass)
-        tot[row["Counter_Name"]] += float(row["Counter_Value"])
-        launches[row["Counter_Name"]].add(row.get("Dispatch_Id"))
-res = {k: tot[k] / max(1, len(launches[k])) for k in sorted(tot)}
-res["_launches_per_counter"] = {k: len(v) for k, v in launches.items()}
+# (C4eps: a camera pass is two kernels -- the fp32 one that hands the selections over, then the fp64 one: their per-launch means are added)
+kernels = ((["photon_query_kernel", "photon_surface_f64_kernel"] if eps else ["photon_query_kernel"]) if "photons" in cfg
+           else ["render_f64_kernel"] if eps else ["render_kernel"])
+kernel = " + ".join(kernels)
+res, launches_per_counter, durations = defaultdict(float), {}, []
+for kern in kernels:
+    tot, launches = defaultdict(float), defaultdict(set)
+    for f in glob.glob(args.out + "/pass*/**/*counter_collection.csv", recursive=True):
+        rows = [row for row in csv.DictReader(open(f)) if kern in row.get("Kernel_Name", "")]
+        if kern.startswith("photon_") and rows:
+            # the camera pass has no separate counters instantiation: the LAST launch of a bench.py run is its untimed counters pass
+            # (diagnostic timers and atomics: ten times slower; one sample per pixel) and does not belong in the means
+            last = max(int(row["Dispatch_Id"]) for row in rows)
+            rows = [row for row in rows if int(row["Dispatch_Id"]) != last]
+        for row in rows:
+            name = row.get("Kernel_Name", "")
+            if kern == "render_f64_kernel" and re.search(r"render_f64_kernel<\w+, true", name):
+                continue  # (the counters instantiation)
+            if kern == "render_kernel" and (re.search(r"render_kernel<\w+, \d, true[,>]", name) or re.search(r"render_kernelILb[01]ELi\dELb1E", name)):
+                continue  # the timed launches only (the COUNT = true instantiation is bench.py's untimed counter pass)
+            tot[row["Counter_Name"]] += float(row["Counter_Value"])
+            launches[row["Counter_Name"]].add(row.get("Dispatch_Id"))
+    for k in tot:
+        res[k] += tot[k] / max(1, len(launches[k]))
+        launches_per_counter[f"{kern}:{k}"] = len(launches[k])
+res = {k: res[k] for k in sorted(res)}
+res["_launches_per_counter"] = launches_per_counter
 res["_kernel"] = kernel
 res["_config"] = {"workload": args.workload, "width": args.width or cfg["width"], "height": args.height or cfg["height"],
                   "spp": args.spp or cfg["spp"], "n_gpus": 1}
