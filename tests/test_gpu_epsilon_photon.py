@@ -102,6 +102,48 @@ def test_camera_pass_on_the_devices_own_photons(name):
     assert np.array_equal(got, r_eps.photon_sample_array(spp))
 
 
+def test_gather_lists_in_global_memory_and_records_outside_lds():
+    """The other instantiations: a gather size above what the fp32 pass keeps in LDS (one k-nearest search per lane hands the
+    selection over), and a scene whose triangle records do not fit the fp64 kernels' LDS tables (a 960-triangle mesh, a plane, fog) --
+    the camera pass over the device's own photons against the oracle's literal pass."""
+    from rpt_amd import Camera, Light, Material, Medium, Mesh, Object, Scene, plane, polygon, vec3
+    n, size, spp = 20000, 48, 8
+    scene, cam, cfg = scenes.CONFIGS["C2"]()
+    scene.set_option("epsilon_policy", 1)
+    r = Renderer(scene, cam).width(size).height(size).watts(14.65 * n).gather_size(100).gather_size_volume(3).seed(2)
+    r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    ps, pv = _device_photons(r)
+    scene0, _, _ = scenes.CONFIGS["C2"]()
+    exp = _oracle(scene0).photon_map_from_photons(n, 1, 14.65 * n, 100, 3, ps, pv, robust=0).render(cam, size, size, spp, seed=0)
+    got = r.seed(0).photon_sample_array(spp)
+    print({"gather 100": [rel_rms(got, exp), (got.mean() - exp.mean()) / exp.mean()]})
+    assert rel_rms(got, exp) < 5e-4 and abs(got.mean() - exp.mean()) < 5e-5 * exp.mean()
+
+    def mesh_scene():
+        sc = Scene()
+        sc.add(Object(Mesh(scenes.bumpy_torus(24, 20)).scale(vec3(1.5, 1.5, 1.5)).rotate_x(0.5)).material(Material.diffuse(vec3(0.8, 0.6, 0.3))))
+        sc.add(Object(plane(vec3(0, 1, 0), -1.2)).material(Material.diffuse(vec3(0.7, 0.7, 0.7))))
+        sc.add(Object(polygon([vec3(1.0, 3.0, -1.0), vec3(1.0, 3.0, 1.0), vec3(-1.0, 3.0, 1.0), vec3(-1.0, 3.0, -1.0)])).material(Material.light(vec3(1, 1, 1), 40.0)))
+        sc.add(Light.Object(Object(polygon([vec3(1.0, 3.0, -1.0), vec3(1.0, 3.0, 1.0), vec3(-1.0, 3.0, 1.0), vec3(-1.0, 3.0, -1.0)]))
+                            .material(Material.light(vec3(1, 1, 1), 40.0))))
+        sc.add(Medium.homogeneous_isotropic(0.02, 0.08))
+        return sc
+    cam = Camera.look_at(vec3(0.0, 1.5, 5.0), vec3(0.0, 0.0, 0.0), vec3(0, 1, 0), 0.8)
+    n, size, spp, watts = 6000, 32, 4, 300.0
+    sc = mesh_scene()
+    sc.set_option("epsilon_policy", 1)
+    r = Renderer(sc, cam).width(size).height(size).watts(watts).gather_size(12).gather_size_volume(3).seed(11)
+    st = r.photon_map_build(n, Renderer.PHOTON_POINT_BEAM)
+    lit = _oracle(mesh_scene()).photon_map(n, 1, watts, 12, 3, seed=11, robust=0)
+    assert abs(st["surface"] - len(lit.photons(0))) <= 0.01 * len(lit.photons(0)) + 5 and abs(st["volume"] - len(lit.photons(1))) <= 0.01 * len(lit.photons(1)) + 5
+    ps, pv = _device_photons(r)
+    exp = _oracle(mesh_scene()).photon_map_from_photons(n, 1, watts, 12, 3, ps, pv, robust=0).render(cam, size, size, spp, seed=0)
+    got = r.seed(0).photon_sample_array(spp)
+    print({"mesh in fog": [rel_rms(got, exp), (got.mean() - exp.mean()) / exp.mean()], "photons": [st["surface"], st["volume"]]})
+    assert np.all(np.isfinite(got)) and exp.mean() > 0
+    assert rel_rms(got, exp) < 2e-3 and abs(got.mean() - exp.mean()) < 5e-4 * exp.mean()
+
+
 def test_the_frame_does_not_depend_on_the_slices():
     """The camera pass of a call runs slice by slice when the per-sample selections of all its samples would not fit the budget
     (option "f64_photon_slice" forces small slices here): the same samples, added up in another order."""
