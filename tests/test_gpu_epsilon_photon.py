@@ -235,6 +235,30 @@ def test_c4_at_its_configured_size_against_the_literal_reference():
     assert abs(bias_own) < 5e-5 and err_own < 3e-4
 
 
+def test_builder_entry_point_and_tile_shards():
+    """Renderer::photon_point_query_beam_render (src/photon.rs:642-644) through the mode, and the frame over two tile shards: every rank
+    builds the whole map (same seed, same streams), the camera pass of a rank covers its tiles, and the shards add up to the frame."""
+    size = 64
+
+    def make(rank=0, count=1):
+        s2, c2, _ = scenes.CONFIGS["C4"]()
+        s2.set_option("epsilon_policy", 1)
+        return Renderer(s2, c2).width(size).height(size).num_samples(2).gather_size(20).gather_size_volume(3) \
+            .watts(14.65 * 4000).seed(1).shard(rank, count)
+    img = make().photon_point_query_beam_render(4000)
+    assert img.shape == (size, size, 3) and img.dtype == np.uint8 and img.max() > 0
+    full = make()
+    full.photon_map_build(4000, 1)
+    whole = full.photon_sample_array(2)
+    parts = []
+    for rk in range(2):
+        r = make(rk, 2)
+        r.photon_map_build(4000, 1)
+        parts.append(r.photon_sample_array(2))
+    assert np.all(parts[0][parts[1] != 0] == 0)               # disjoint tiles
+    assert np.array_equal(parts[0] + parts[1], whole)
+
+
 def test_what_photon_mapping_in_the_mode_refuses():
     scene, cam, cfg = scenes.CONFIGS["C4"]()
     scene.set_option("epsilon_policy", 1)
