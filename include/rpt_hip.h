@@ -331,7 +331,8 @@ int rpt_frame_unpack_device(uint32_t width, uint32_t height, uint32_t rank, uint
  * Options of the mode: "f64_cull" (1; 0 = full scan, 2 = the counters build keeps the search limits), "f64_surf_batch"
  * (8: lanes of a wave that wait at a surface event in a medium before the wave runs the surface code).
  * "f64_photon_slice" (0 = automatic: as many whole chunks of 256 samples as keep the per-sample selections, (gather_size + 2) dwords
- * each, within 32 GB): samples per slice of the photon camera pass.  "photon_skip" bit 4096: no visibility rays (diagnostic).
+ * each, within 32 GB): samples per slice of the photon camera pass.  "photon_skip" bits 4096 / 16384: no visibility rays / visibility rays without
+ * the search limit at the query point (diagnostics).
  * rpt_debug_epsilon_counters (option "counters" = 1): [0] closest-hit queries, [1] accepted hits, [2] accepted hits with
  * t < 1e-9 (1 + |origin|) -- a ray hitting the surface it starts on --, [3] shadow tests, [4] passed, [5] failed although
  * |hit - dist| < 1e-6 dist -- the light's own surface missed by rounding --, [6] camera samples, [7] path vertices; the

@@ -14,7 +14,9 @@
 // padded world box in fp32 (wave-uniform records from the scalar cache, full rate), then each lane evaluates only its
 // own candidates in fp64, in scene order, a different object in every lane, from per-lane records in LDS.  Objects the
 // box test drops cannot change the reference's HitRecord, so hit, time and normal are those of the full scan bit for
-// bit (`cull` = 0 runs the full scan; tests/test_gpu_epsilon.py compares the two frames for equality).
+// bit (`cull` = 0 runs the full scan; tests/test_gpu_epsilon.py compares the two frames for equality).  The box test
+// knows the one case in which the reference reports a hit for a ray that misses an object's box: a NaN in its cube test
+// (cull32 below).
 #include <hip/hip_runtime.h>
 
 #include "device_core.h"   // Rng (the fp32 path's stream, bit for bit)
@@ -1309,7 +1311,7 @@ __global__ __launch_bounds__(256, R64_WAVES) void photon_surface_f64_kernel(cons
                 dirn = normalize(disp);
             }
             Query v{kInf, -1, 0u};
-            if (!(KQ.skip & 4096u)) closest_hit_wave<false>(recs, trecs, slots, has, po, dirn, (KQ.skip & 16384u) ? kInf : len, v, ce, cr);   // (16384: DEBUG no search limit)
+            if (!(KQ.skip & 4096u)) closest_hit_wave<false>(recs, trecs, slots, has, po, dirn, (KQ.skip & 16384u) ? kInf : len, v, ce, cr);   // (diagnostic: 16384 = no search limit)
             if (has && !(v.obj >= 0 && len > v.t)) {   // :357-361
                 const double c = fmin(fmax(dot(pdir, n), 0.0), 1.0);
                 color = color + (bsdf(KA.sc.shade[hobj].mat, n, wo, pdir) * ppow) * c;

@@ -1359,7 +1359,7 @@ RPT_DEV bool gather_serve(QueryK q, const SceneView& sc_arg, const GatherLds& l,
     // -- the terms of the photons within each lane's radius, in candidate order
     uint64_t vis_mask = ~0ull;
     bool touched = true;   // some scanned record comes near this lane's ball
-    if (!BVH) vis_mask = scan_mask_for_ball(sc_arg, ok, x, __builtin_sqrtf(r2k) * (1.f + 1e-4f) + 1e-6f, &touched);
+    if (!BVH && !EMIT) vis_mask = scan_mask_for_ball(sc_arg, ok, x, __builtin_sqrtf(r2k) * (1.f + 1e-4f) + 1e-6f, &touched);   // (EMIT: no ray is traced here)
     // A lane's test cannot be blocked when no scanned record comes near its ball, the scene has no plane, and both
     // ends of the segment lie inside the room shell: its faces bound a convex box, a segment between two points of
     // the closed box meets a face at its ends only, and those the search interval leaves out.  (The scan itself is

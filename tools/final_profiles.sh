@@ -13,7 +13,7 @@ bash tools/pmc_passes.sh "$OUT/pmc_c3" C3 > "$OUT/pmc_c3.log" 2>&1
 echo "pmc c3 done"
 bash tools/pmc_passes.sh "$OUT/pmc_C3eps" C3eps > "$OUT/pmc_C3eps.log" 2>&1
 echo "pmc C3eps done"
-for wl in C5 C4 C2 C2eps C5G; do
+for wl in C5 C4 C4eps C2 C2eps C5G; do
   bash tools/pmc_passes.sh "$OUT/pmc_$wl" $wl quick > "$OUT/pmc_$wl.log" 2>&1
   echo "pmc $wl done"
 done
