@@ -214,3 +214,21 @@ def test_beam_beam_estimate_matches_brute_force():
         nonzero += int(ok.any())
         assert np.allclose(got[pix], total, rtol=1e-9, atol=1e-15)
     assert nonzero > 5
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_maps_over_photon_lists_handed_in_equal_the_oracles_own(kind):
+    """The test hook the device's camera pass is checked with (tests/test_gpu_epsilon_photon.py): maps built over photon lists handed
+    in.  Handing the oracle its own lists back gives its own frame, for all three estimators and both policies."""
+    scene, cam, cfg = scenes.CONFIGS["C4"]()
+    n, watts = 3000, 14.65 * 3000
+    o = OracleScene(scene)
+    for robust in (0, 1):
+        pm = o.photon_map(n, kind, watts, 20, 8, seed=7, robust=robust)
+        again = o.photon_map_from_photons(n, kind, watts, 20, 8, pm.photons(0), pm.photons(1), robust=robust)
+        a, b = pm.render(cam, 12, 12, 2, seed=0), again.render(cam, 12, 12, 2, seed=0)
+        assert a.mean() > 0
+        if kind == 2:   # (a beam's direction is rebuilt from its two ends: the last bit of -normalize(end - start))
+            assert np.allclose(a, b, rtol=1e-12, atol=0)
+        else:
+            assert np.array_equal(a, b)
