@@ -34,8 +34,9 @@ def _renderers(name, size, n, gather=20, gather_volume=3):
 @pytest.mark.parametrize("name", ["C4", "C2"])
 def test_shooting_and_camera_pass_follow_the_literal_reference(name):
     """20 k photons, 64 x 64 x 16 spp, beam x point map.  The fp32 policy's frame lies ~1.1 % above the literal reference's (C4 and
-    C2 alike); the reference-epsilon mode's lies within 0.3 % of it, and the rest of its distance is that of two maps whose chains
-    parted at the self-intersections (the robust oracle's distance to the literal one, with the bias taken out, is the same)."""
+    C2 alike); the reference-epsilon mode's lies within 0.1 % of it (measured: C4 3.8e-3 / -0.10 %, C2 6.6e-3 / +0.04 %), and the rest of
+    its distance is that of two maps whose chains parted at the self-intersections (the robust oracle's distance to the literal one,
+    with the bias taken out, is 1.4e-2 / 4.9e-2)."""
     n, size, spp = 20000, 64, 16
     r_eps, r_f32 = _renderers(name, size, n)
     scene, cam, cfg = scenes.CONFIGS[name]()
@@ -61,8 +62,8 @@ def test_shooting_and_camera_pass_follow_the_literal_reference(name):
     print({"eps_vs_literal": [err, bias], "f32_vs_literal": [err32, bias32], "robust_oracle_vs_literal": [rel_rms(exp_rob, exp), rob_bias],
            "robust_oracle_vs_literal_bias_removed": rob_spread})
     assert bias32 > 8e-3                      # what the mode is for
-    assert abs(bias) < 3e-3
-    assert err < 1.25 * rob_spread + 1e-3
+    assert abs(bias) < 2e-3
+    assert err < 0.6 * rob_spread + 1e-3
 
 
 def _device_photons(r):
@@ -193,7 +194,7 @@ def test_the_other_two_estimators(kind):
     print({"kind": kind, "eps_vs_literal": [err, bias]})
     assert np.all(np.isfinite(got)) and exp.mean() > 0
     # (the beam x beam map keeps one volume photon in a thousand -- ~40 beams here --, drawn from a side stream in path order: a chain
-    # that parts from the oracle's at a self-intersection changes which beams are kept; measured +0.9 % / 1.1e-2, against 1e-5 / 1.4e-3
+    # that parts from the oracle's at a self-intersection changes which beams are kept; measured +0.2 % / 5.1e-3, against -5e-5 / 1.3e-3
     # for the photon x photon map)
     if kind == Renderer.PHOTON_BEAM_BEAM:
         assert abs(bias) < 3e-2 and err < 5e-2
